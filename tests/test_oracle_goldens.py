@@ -1,0 +1,143 @@
+"""Pin the CPU oracle (oracle/clane_oracle.py) against outputs of the real reference.
+
+The fixtures under tests/golden/ were produced by oracle/make_goldens.py, which
+imports /root/reference in the build container.  These tests need neither the
+reference nor a GPU.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clane_oracle as O
+from .conftest import load_golden, write_data_root, csr_from_golden_edges
+
+KARATE_LIKE = ["g4_karate_d2.npz", "g4_karate_d16.npz", "g5_symkarate_d16_g0.5.npz",
+               "g5_symkarate_d16_g0.76.npz", "g5_symkarate_d2_g0.76.npz", "g7_readme5.npz", "g6_tiny_f64.npz"]
+
+
+def _csr_of(g):
+    idx = g["A_indices"]
+    V = g["X"].shape[0]
+    return O.build_csr(V, idx[0], idx[1])
+
+
+def test_g1_cosine_known_answers():
+    g = load_golden("g1_cosine.npz")
+    v = torch.tensor([1.0, 2.0, 3.0])
+    assert O.cosine_similarity(v, v).numpy() == pytest.approx(g["same"], abs=1e-6)
+    assert O.cosine_similarity(torch.tensor([0.0, 1.0]), torch.tensor([1.0, 0.0])).numpy() == pytest.approx(g["orth"], abs=1e-7)
+    assert O.cosine_similarity(v, -v).numpy() == pytest.approx(g["opp"], abs=1e-6)
+    out = O.cosine_similarity(torch.from_numpy(g["a4"]), torch.from_numpy(g["b4"]))
+    np.testing.assert_array_equal(out.numpy(), g["out4"])          # same torch ops: bit-exact
+    out64 = O.cosine_similarity(torch.from_numpy(g["a64"]), torch.from_numpy(g["b64"]))
+    assert out64.dtype == torch.float64
+    np.testing.assert_array_equal(out64.numpy(), g["out64"])
+    # batched result is NOT a per-pair cosine (global denominators, similarity.py:37)
+    true_cos = torch.nn.functional.cosine_similarity(torch.from_numpy(g["a4"]), torch.from_numpy(g["b4"]))
+    assert not np.allclose(g["out4"], true_cos.numpy(), atol=1e-2)
+    assert np.isnan(g["zeros_ones"]).all() and torch.isnan(O.cosine_similarity(torch.zeros(3), torch.ones(3))).all()
+
+
+def test_g2_karate_files_and_csr(tmp_path):
+    g = load_golden("g2_karate_csr.npz")
+    root = write_data_root(tmp_path / "k", g["vertex_ids"], g["edge_src"], g["edge_dst"])
+    vids, src, dst = O.read_graph_files(root)
+    assert len(vids) == 34 and len(src) == int(g["num_E"]) == 78
+    rowptr, colidx = O.build_csr(34, src, dst)
+    rows = np.repeat(np.arange(34), np.diff(rowptr))
+    np.testing.assert_array_equal(np.stack([rows, colidx]), g["A_indices"])
+    assert O.get_nbrs(rowptr, colidx, 33).tolist() == [8, 9, 13, 14, 15, 18, 19, 20, 22, 23, 26, 27, 28, 29, 30, 31, 32]
+    for i in range(34):
+        np.testing.assert_array_equal(O.get_nbrs(rowptr, colidx, i), g["nbrs"][i])
+    sinks = [i for i in range(34) if rowptr[i + 1] == rowptr[i]]
+    assert sinks == [0, 14, 15, 18, 20, 22, 23, 24, 26]
+
+
+@pytest.mark.parametrize("name", KARATE_LIKE)
+def test_build_P_matches_reference(name):
+    g = load_golden(name)
+    rowptr, colidx = _csr_of(g)
+    X = torch.from_numpy(g["X"])
+    P = O.build_P_values(rowptr, colidx, X)
+    assert P.dtype == X.dtype
+    np.testing.assert_allclose(P.numpy(), g["P0_values"], rtol=2e-6, atol=1e-7)
+    # literal path (gather + similarity call) agrees with the closed form
+    P_lit = O.build_P_values(rowptr, colidx, X, similarity=O.cosine_similarity)
+    np.testing.assert_allclose(P_lit.numpy(), g["P0_values"], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", KARATE_LIKE)
+def test_first_sweep_and_final_Z(name):
+    g = load_golden(name)
+    rowptr, colidx = _csr_of(g)
+    X = torch.from_numpy(g["X"])
+    tol = 1e-12 if X.dtype == torch.float64 else 1e-6
+    P = O.build_P_values(rowptr, colidx, X)
+    Z1, _ = O.sweep(rowptr, colidx, P, X, X.clone(), float(g["gamma"]))
+    assert O.rel_l2(Z1, torch.from_numpy(g["Z_sweep1"])) < tol
+    emb = O.OracleEmbedder(rowptr, colidx, X, gamma=float(g["gamma"]), tolerence=int(g["tolerence"]))
+    Z = emb.iterate()
+    assert O.rel_l2(Z, torch.from_numpy(g["Z_final"])) < tol
+    # sinks never move (embedder.py:88-89)
+    sink = np.diff(rowptr) == 0
+    np.testing.assert_array_equal(Z.numpy()[sink], g["X"][sink])
+    # size-independent property: converged Z is the fixed point of the LAST P
+    P_last = O.build_P_values(rowptr, colidx, Z)
+    Zs = O.fixed_point(rowptr, colidx, P_last, X, float(g["gamma"]))
+    assert O.rel_l2(Z, Zs) < 1e-5
+
+
+def test_g4_karate_d2_sweep_schedule():
+    # karate is a DAG (P nilpotent): the first propagate runs depth+1 sweeps to an exact 0
+    # delta and then endures `tolerence` more.  Later counts depend on last-ulp noise in P
+    # (SURVEY H4), so only the first is pinned exactly; the rest are bounded.
+    g = load_golden("g4_karate_d2.npz")
+    rowptr, colidx = _csr_of(g)
+    emb = O.OracleEmbedder(rowptr, colidx, torch.from_numpy(g["X"]), gamma=0.76, tolerence=10)
+    emb.iterate()
+    ref = g["sweep_counts"].tolist()
+    assert emb.sweep_counts[0] == ref[0] == 17
+    assert abs(len(emb.sweep_counts) - len(ref)) <= 2
+    assert all(11 <= c <= 17 for c in emb.sweep_counts) and emb.sweep_counts[-1] == ref[-1] == 11
+
+
+def test_g6_duplicates_selfloop_sink_f64(tmp_path):
+    g = load_golden("g6_tiny_f64.npz")
+    root = write_data_root(tmp_path / "g6", g["vertex_ids"], g["edge_src"], g["edge_dst"])
+    vids, src, dst = O.read_graph_files(root)
+    assert len(src) == int(g["num_E"]) == 5          # len(g.E) counts duplicate lines
+    rowptr, colidx = O.build_csr(4, src, dst)
+    assert len(colidx) == 4                          # ... A merges them
+    assert rowptr.tolist() == [0, 2, 3, 3, 4] and colidx.tolist() == [1, 2, 0, 3]
+    P = O.build_P_values(rowptr, colidx, torch.from_numpy(g["X"]))
+    dense = O.as_sparse(rowptr, colidx, P).to_dense().numpy()
+    np.testing.assert_allclose(dense, g["P0_dense"], rtol=1e-13, atol=1e-15)
+    assert dense[3, 3] == pytest.approx(1.0) and dense[2].sum() == 0
+
+
+def test_g8_corashape_one_literal_sweep():
+    g = load_golden("g8_corashape.npz")
+    V, d = int(g["V"]), int(g["d"])
+    X = torch.zeros(V, d)
+    X[torch.from_numpy(g["X_nz_row"].astype(np.int64)), torch.from_numpy(g["X_nz_col"].astype(np.int64))] = 1.0
+    rowptr, colidx = O.build_csr(V, g["src"], g["dst"])
+    rows = np.repeat(np.arange(V), np.diff(rowptr))
+    np.testing.assert_array_equal(np.stack([rows, colidx]), g["A_indices"])
+    P = O.build_P_values(rowptr, colidx, X)
+    np.testing.assert_allclose(P.numpy(), g["P_values"], rtol=2e-6)
+    Z1, delta = O.sweep(rowptr, colidx, P, X, X.clone(), 0.76)
+    np.testing.assert_allclose(Z1[:24].numpy(), g["Z1_head"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(Z1.norm(dim=1).numpy(), g["Z1_rownorm"], rtol=1e-5)
+    np.testing.assert_allclose(Z1.sum(1).numpy(), g["Z1_rowsum"], rtol=1e-5)
+    assert float(delta) == pytest.approx(float(g["delta1"]), rel=1e-5)
+
+
+def test_read_graph_files_errors(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        O.read_graph_files(tmp_path / "missing")
+    root = write_data_root(tmp_path / "bad", ["1", "2"], ["1"], ["3"])
+    with pytest.raises(ValueError):
+        O.read_graph_files(root)
+    (root / "E").write_text("1 2\n")
+    with pytest.raises(ValueError):
+        O.read_graph_files(root)
