@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: embedding-update sweeps/sec + achieved HBM GB/s of the K3 SpMM kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat2m|rmat200k|tiny]
+
+One "step" = one Jacobi sweep  Z <- X + gamma * P Z  over the whole graph, P frozen: the K3
+kernels, the deterministic L1-delta reduction, the host read-back of that scalar (the
+reference decides after every sweep, embedder.py:94-105) and, for N > 1, the all-gather of
+the updated rows + the scalar all-reduce.  Inputs are resident in HBM before the timed region.
+N > 1 is launched by torchrun (one rank per GPU, RCCL); rows are partitioned over the ranks
+with the graph fixed, so scaling is STRONG.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    # name: (V, E, d, graph seed, X seed)            -- SURVEY.md section 8d
+    "rmat2m": (2_000_000, 40_000_000, 256, 3, 4),      # BASELINE config 3 (headline metric)
+    "rmat200k": (200_000, 4_000_000, 128, 1, 2),       # BASELINE config 2
+    "tiny": (20_000, 200_000, 64, 7, 8),
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(csr, X, P_host, gamma, Z1_gpu, budget_s=25.0):
+    """Oracle sweep (PyTorch-CPU sparse mm, the 'port') timed on this box's host cores."""
+    from oracle import clane_oracle as O
+    threads = torch.get_num_threads()
+    Ps = O.as_sparse(csr.rowptr, csr.colidx, P_host)
+    Z = X.clone()
+    t0 = time.perf_counter()
+    Z, _ = O.sweep(csr.rowptr, csr.colidx, P_host, X, Z, gamma, Ps)          # warm-up, also the parity sweep
+    first = time.perf_counter() - t0
+    parity = O.rel_l2(Z1_gpu, Z)
+    n = int(max(1, min(10, budget_s // max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        Z, _ = O.sweep(csr.rowptr, csr.colidx, P_host, X, Z, gamma, Ps)
+    per = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / per, "unit": "sweeps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} full sweeps of the same graph (oracle/clane_oracle.py sweep, torch.sparse.mm, "
+                      f"{threads} threads), P taken from the GPU build_P"}, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="rmat2m", choices=sorted(WORKLOADS))
+    ap.add_argument("--gamma", type=float, default=0.76)
+    ap.add_argument("--chunks", type=int, default=None)
+    ap.add_argument("--long-threshold", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from clane_amd import _hip, synth
+    from clane_amd.engine import SweepEngine, DEFAULT_LONG_THRESHOLD
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    dev = _hip.require_gpu(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    pg = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    V, E, d, gseed, xseed = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    csr = synth.rmat_csr(V, E, seed=gseed, device=str(dev))
+    X = synth.gaussian_X(V, d, seed=xseed)
+    log(f"{args.workload}: |V|={V} |E|={csr.num_edges} d={d} max outdeg={int(np.diff(csr.rowptr).max())} "
+        f"generated in {time.perf_counter() - t0:.1f}s")
+
+    t0 = time.perf_counter()
+    eng = SweepEngine(csr, X, dev, process_group=pg, chunks=args.chunks,
+                      long_threshold=DEFAULT_LONG_THRESHOLD if args.long_threshold is None else args.long_threshold)
+    torch.cuda.synchronize()
+    log(f"engine up in {time.perf_counter() - t0:.1f}s; rank rows={eng.part.n_local} edges={eng.E_loc} "
+        f"long rows={sum(0 if l is None else l.numel() for l in eng.long_rows)}")
+
+    # build_P once (timed separately, not part of a step), P frozen afterwards
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.build_P()
+    torch.cuda.synchronize()
+    build_p_ms = (time.perf_counter() - t0) * 1e3
+
+    Z1 = None
+    for i in range(args.warmup):
+        eng.sweep(args.gamma)
+        if i == 0 and world == 1 and not args.no_cpu_baseline:
+            Z1 = eng.get_Z()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.time_kernels = True
+    eng.kernel_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        delta = eng.sweep(args.gamma)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.time_kernels = False
+    ktimes = eng.kernel_times_ms()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # roofline of the dominant kernel (spmm_update_kernel, the main pass), HIP events on its stream;
+    # one launch per chunk, so per-launch bytes = main-pass bytes / chunks.
+    main_ms = float(np.mean([a for a, _ in ktimes]))
+    long_ms = float(np.mean([b for _, b in ktimes]))
+    chunks = eng.part.chunks
+    bytes_main_launch = eng.main_pass_bytes() / chunks
+    achieved = bytes_main_launch / (main_ms * 1e-3) / 1e9
+    pass_bytes = eng.algorithmic_bytes_per_sweep()
+    pass_gbps = pass_bytes / ((main_ms + long_ms) * chunks * 1e-3) / 1e9
+    traffic = None
+    tfile = ROOT / "profiles" / "traffic.json"
+    if tfile.exists():
+        traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}", {}).get("bytes_per_launch")
+
+    result = {
+        "metric": "embedding-update iters/sec (Jacobi sweeps of Z <- X + gamma*P*Z, P frozen)",
+        "value": args.steps / elapsed, "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"R-MAT |V|={V} |E|={E} d={d} fp32, gamma={args.gamma}, CosineSimilarity "
+                               f"(reference mode), seeds {gseed}/{xseed}",
+                   "parallelism": f"row-partition x{world}, {chunks} chunk(s)/sweep"
+                                  + (", in-place RCCL all-gather per chunk + scalar all-reduce" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "kernel": "spmm_update_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": bytes_main_launch, "avg_launch_ms": main_ms,
+                     "k3_pass": {"kernels": "spmm_update_kernel + spmm_long_kernel", "bytes": pass_bytes,
+                                 "ms": (main_ms + long_ms) * chunks, "GBps": pass_gbps,
+                                 "frac": pass_gbps / HBM_PEAK_GBPS}},
+        "build_P_ms": build_p_ms, "last_delta": delta,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        base, parity = cpu_baseline(csr, X, eng.P[:eng.E_loc].cpu(), args.gamma, Z1)
+        result["cpu_baseline"] = base
+        result["parity_rel_l2_vs_oracle_after_1_sweep"] = parity
+        if not parity < 1e-4:
+            raise SystemExit(f"parity check failed: rel-L2 {parity}")
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""CLI -- ``python -m clane_amd [embedding] --data_root D --output_root O --config_file C``.
+
+Mirrors the reference's ``clane/__main__.py`` (same flags, same YAML keys, same outputs:
+``output_root/Z.npy`` and, with ``--save_history``, ``output_root/{outer}/Z_{sweep}.npy``).
+The README form ``clane embedding ...`` (README.md:11) is accepted too: the reference's parser
+rejects the ``embedding`` token, here it is an optional no-op.  The loop always
+runs on the GPU; ``--gpu`` only selects where ``Embedder.device`` points, as upstream.
+"""
+from __future__ import annotations
+
+import argparse
+from pathlib import Path
+
+import numpy as np
+import torch
+import yaml
+
+from . import similarity
+from .embedder import Embedder, IterativeEmbedder
+from .graph import Graph
+
+
+def embedding(args):
+    print('[Embedding]', end='\n')
+
+    if args.config_file.absolute().exists():
+        with open(args.config_file.absolute(), 'r') as config_io:
+            hparams = yaml.load(config_io, Loader=yaml.FullLoader)
+    else:
+        raise FileNotFoundError(f"Config file not found. {args.config_file.absolute()}")
+
+    device = torch.device('cuda') if args.gpu else torch.device('cpu')
+    g = Graph(data_root=args.data_root, **hparams["graph"])
+
+    print("Graph Loaded.")
+    print(f" - {len(g)} vertices")
+    print(f" - {len(g.E)} edges")
+    print(" - Content Embeddings:")
+    print(f"     - dim : {g.d:3d}")
+    print(f"     - mean: {g.X.mean():5.2f}")
+    print(f"     - std : {g.X.std():5.2f}")
+
+    try:
+        similarity_measure = getattr(similarity, hparams["similarity"]["method"])
+    except AttributeError:
+        raise AttributeError(f'Given similarity method {hparams["similarity"]["method"]} not found.')
+
+    similarity_measure = similarity_measure(**hparams['similarity']['kwargs'])
+
+    embedder_cls = IterativeEmbedder if hasattr(similarity_measure, 'parameters') else Embedder
+    extra = {"num_workers": args.num_workers} if embedder_cls is IterativeEmbedder else {}
+    embedder = embedder_cls(graph=g, similarity_measure=similarity_measure, device=device,
+                            save_history=args.save_history, **extra, **hparams["embedder"])
+    embedder.iterate()
+
+    print("Saving the results.")
+    if not args.output_root.exists():
+        args.output_root.mkdir(parents=True, exist_ok=True)
+
+    if args.save_history:
+        for outer, history_Z in enumerate(embedder.history["Z"]):
+            args.output_root.joinpath(f'{outer}').mkdir(parents=True, exist_ok=True)
+            for sweep, Z in enumerate(history_Z):
+                np.save(args.output_root.joinpath(f'{outer}/Z_{sweep}.npy'), Z.cpu().numpy())
+    np.save(args.output_root.joinpath('Z.npy'), g.Z.cpu().numpy())
+
+    print(f"The embeddings are stored in {args.output_root.joinpath('Z.npy').absolute()}.")
+
+
+def get_parser():
+    parser = argparse.ArgumentParser(prog="clane")
+    parser.add_argument("command", nargs="?", choices=["embedding"], default="embedding",
+                        help="Optional; the only command is 'embedding'.")
+    parser.add_argument("--data_root", type=Path, help="Path to the data root directory.")
+    parser.add_argument("--output_root", type=Path, help="Path to the root for the experiment results to be stored.")
+    parser.add_argument("--config_file", type=Path, help="Path to the training configuration yaml file.")
+    parser.add_argument("--save_history", action='store_true',
+                        help="If true, it saves the embeddings for every iteration.")
+    parser.add_argument("--num_workers", type=int, default=0)
+    parser.add_argument("--gpu", action='store_true')
+    return parser
+
+
+def main():
+    parser = get_parser()
+    args = parser.parse_args()
+    embedding(args)
+
+
+if __name__ == "__main__":
+    main()

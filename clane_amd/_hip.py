@@ -1,0 +1,222 @@
+"""ctypes binding of ``libclane_hip.so`` (C ABI: ``include/clane_hip.h``).
+
+This is the only door between the Python host code and the gfx950 kernels.  There is no
+CPU implementation behind it: if the library is missing or a call fails, it raises.
+
+``HipKernels`` exposes one method per ABI entry point, taking torch tensors (device memory
+is owned by torch -- plumbing only) and picking the ``_f32`` / ``_f64`` / ``_bf16`` symbol
+from the tensor dtype.  Work is enqueued on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+LIB_NAME = "libclane_hip.so"
+LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
+ABI_VERSION = 1
+
+SCORE_REFERENCE, SCORE_PER_EDGE, SCORE_RAW_DOT = 0, 1, 2
+SCORE_MODES = {"reference": SCORE_REFERENCE, "per_edge": SCORE_PER_EDGE, "raw_dot": SCORE_RAW_DOT}
+
+_p, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
+
+# symbol -> (restype, argtypes); every symbol include/clane_hip.h declares.
+SIGNATURES = {
+    "clane_abi_version": (C.c_int, []),
+    "clane_last_error": (C.c_char_p, []),
+    "clane_spmm_partials_len": (_i64, [_i64, _i64]),
+    "clane_reduce_ws_len": (_i64, []),
+    "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p]),
+}
+for _s in ("f32", "f64", "bf16"):
+    SIGNATURES[f"clane_row_sqnorm_{_s}"] = (C.c_int, [_p, _i64, _i32, _i64, _p, _p])
+    SIGNATURES[f"clane_edge_score_{_s}"] = (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p])
+    _g = C.c_double if _s == "f64" else C.c_float
+    SIGNATURES[f"clane_spmm_update_{_s}"] = (
+        C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _p, _p])
+    SIGNATURES[f"clane_spmm_update_long_{_s}"] = (
+        C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p])
+    SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
+for _s in ("f32", "f64"):
+    SIGNATURES[f"clane_degree_weighted_sums_{_s}"] = (C.c_int, [_p, _p, _p, _i64, _p, _p, _p])
+    SIGNATURES[f"clane_segment_softmax_{_s}"] = (C.c_int, [_p, _i64, _p, _p])
+    SIGNATURES[f"clane_pair_cosine_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
+
+_SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
+_ACC = {torch.float32: torch.float32, torch.float64: torch.float64, torch.bfloat16: torch.float32}
+VEC_ELEMS = {torch.float32: 4, torch.float64: 2, torch.bfloat16: 8}  # elements per 16-byte pack
+
+
+class ClaneHipError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[Path] = None) -> C.CDLL:
+    """dlopen the library and bind every declared symbol.  Raises if anything is missing."""
+    path = Path(path) if path is not None else LIB_PATH
+    if not path.exists():
+        raise ClaneHipError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C clane_amd/csrc`) -- clane_amd has no CPU fallback.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    got = lib.clane_abi_version()
+    if got != ABI_VERSION:
+        raise ClaneHipError(f"{path}: ABI version {got}, expected {ABI_VERSION}")
+    return lib
+
+
+def acc_dtype(dtype: torch.dtype) -> torch.dtype:
+    """dtype of P / scores / squared norms for a given storage dtype of Z."""
+    try:
+        return _ACC[dtype]
+    except KeyError:
+        raise TypeError(f"clane_amd supports float32, float64 and bfloat16 embeddings, not {dtype}") from None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _mat(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a row-major 2-D tensor with unit column stride, got {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    return t.data_ptr(), t.stride(0)
+
+
+def _vec(t: torch.Tensor, dtype: torch.dtype, name: str):
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: need a contiguous {dtype} tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+class HipKernels:
+    """Tensor-level view of the C ABI.  One instance per process is enough (stateless)."""
+
+    def __init__(self, lib: Optional[C.CDLL] = None):
+        self.lib = lib if lib is not None else load_library()
+
+    # -- helpers ------------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise ClaneHipError(f"{what} failed ({rc}): {self.lib.clane_last_error().decode()}")
+
+    @staticmethod
+    def _stream(t: torch.Tensor):
+        if not t.is_cuda:
+            raise ClaneHipError("HipKernels needs tensors in GPU memory (got a CPU tensor); there is no CPU path")
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    def _fn(self, base: str, dtype: torch.dtype):
+        try:
+            return getattr(self.lib, f"{base}_{_SUFFIX[dtype]}")
+        except KeyError:
+            raise TypeError(f"{base}: unsupported dtype {dtype}") from None
+
+    # -- sizes --------------------------------------------------------------------------
+    def spmm_partials_len(self, nrows: int, n_long: int) -> int:
+        return int(self.lib.clane_spmm_partials_len(nrows, n_long))
+
+    def reduce_ws_len(self) -> int:
+        return int(self.lib.clane_reduce_ws_len())
+
+    # -- K0 -----------------------------------------------------------------------------
+    def row_sqnorm(self, Z: torch.Tensor, d: int, sq: torch.Tensor):
+        zp, ldz = _mat(Z, "Z")
+        self._check(self._fn("clane_row_sqnorm", Z.dtype)(
+            zp, Z.shape[0], d, ldz, _vec(sq, acc_dtype(Z.dtype), "sq"), self._stream(Z)), "clane_row_sqnorm")
+
+    def degree_weighted_sums(self, sq, rowptr, indeg, nrows: int, ws, out2):
+        self._check(self._fn("clane_degree_weighted_sums", sq.dtype)(
+            _ptr(sq), _vec(rowptr, torch.int64, "rowptr"), _vec(indeg, torch.int32, "indeg"), nrows,
+            _vec(ws, torch.float64, "ws"), _vec(out2, torch.float64, "out2"), self._stream(out2)),
+            "clane_degree_weighted_sums")
+
+    # -- K1 / K2 ------------------------------------------------------------------------
+    def edge_score(self, rowptr, colidx, nrows: int, row0: int, Z, d: int, mode: int, sums2, sq, scores):
+        zp, ldz = _mat(Z, "Z")
+        self._check(self._fn("clane_edge_score", Z.dtype)(
+            _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"), nrows, row0, zp, ldz, d, mode,
+            _ptr(sums2), _ptr(sq), _vec(scores, acc_dtype(Z.dtype), "scores"), self._stream(Z)), "clane_edge_score")
+
+    def segment_softmax(self, rowptr, nrows: int, vals):
+        self._check(self._fn("clane_segment_softmax", vals.dtype)(
+            _vec(rowptr, torch.int64, "rowptr"), nrows, vals.data_ptr(), self._stream(vals)),
+            "clane_segment_softmax")
+
+    # -- K3 -----------------------------------------------------------------------------
+    def spmm_update(self, rowptr, colidx, P, nrows: int, row0: int, Z_old, X, gamma: float, Z_new, d: int,
+                    long_threshold: int, partials):
+        """Main pass: every row of <= long_threshold edges (0 = all rows)."""
+        zo, ldz = _mat(Z_old, "Z_old")
+        xp, ldx = _mat(X, "X")
+        zn, ldo = _mat(Z_new, "Z_new")
+        if not (Z_old.dtype == X.dtype == Z_new.dtype):
+            raise ValueError("spmm_update: Z_old, X, Z_new must share a dtype")
+        self._check(self._fn("clane_spmm_update", Z_old.dtype)(
+            _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
+            _vec(P, acc_dtype(Z_old.dtype), "P"), nrows, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
+            long_threshold, _vec(partials, torch.float64, "partials"), self._stream(Z_old)), "clane_spmm_update")
+
+    def spmm_update_long(self, rowptr, colidx, P, long_rows, row0: int, Z_old, X, gamma: float, Z_new, d: int,
+                         partials):
+        """Long-row pass: one workgroup per listed row; writes long_rows.numel() partials."""
+        zo, ldz = _mat(Z_old, "Z_old")
+        xp, ldx = _mat(X, "X")
+        zn, ldo = _mat(Z_new, "Z_new")
+        if not (Z_old.dtype == X.dtype == Z_new.dtype):
+            raise ValueError("spmm_update_long: Z_old, X, Z_new must share a dtype")
+        self._check(self._fn("clane_spmm_update_long", Z_old.dtype)(
+            _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
+            _vec(P, acc_dtype(Z_old.dtype), "P"), _vec(long_rows, torch.int32, "long_rows"), long_rows.numel(),
+            row0, zo, ldz, xp, ldx, gamma, zn, ldo, d, _vec(partials, torch.float64, "partials"),
+            self._stream(Z_old)), "clane_spmm_update_long")
+
+    def reduce_partials(self, partials, n: int, out):
+        self._check(self.lib.clane_reduce_partials(
+            _vec(partials, torch.float64, "partials"), n, _vec(out, torch.float64, "out"), self._stream(out)),
+            "clane_reduce_partials")
+
+    def l1_distance(self, A, B, d: int, ws, out):
+        ap, lda = _mat(A, "A")
+        bp, ldb = _mat(B, "B")
+        self._check(self._fn("clane_l1_distance", A.dtype)(
+            ap, lda, bp, ldb, A.shape[0], d, _vec(ws, torch.float64, "ws"), _vec(out, torch.float64, "out"),
+            self._stream(A)), "clane_l1_distance")
+
+    # -- CosineSimilarity on explicit pairs ------------------------------------------------
+    def pair_cosine(self, A, B, d: int, out, ws):
+        ap, lda = _mat(A, "A")
+        bp, ldb = _mat(B, "B")
+        self._check(self._fn("clane_pair_cosine", A.dtype)(
+            ap, lda, bp, ldb, A.shape[0], d, _vec(out, acc_dtype(A.dtype), "out"), _vec(ws, torch.float64, "ws"),
+            self._stream(A)), "clane_pair_cosine")
+
+
+_kernels: Optional[HipKernels] = None
+
+
+def kernels() -> HipKernels:
+    """Process-wide HipKernels; raises ClaneHipError when the library is not built."""
+    global _kernels
+    if _kernels is None:
+        _kernels = HipKernels()
+    return _kernels
+
+
+def require_gpu(device=None) -> torch.device:
+    """The device the hot path runs on.  Raises (never falls back) when there is none."""
+    if not torch.cuda.is_available():
+        raise ClaneHipError("clane_amd runs its embedding loop in HIP kernels on an MI355X; no GPU is visible "
+                            "to this process and there is no CPU fallback.")
+    if device is None or torch.device(device).type != "cuda":
+        return torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device(device)
+    return dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())

@@ -1,0 +1,293 @@
+// K0 / K1 / K2 -- the pieces of Graph.build_P (clane/graph.py:118-128) and
+// CosineSimilarity.__call__ (clane/similarity.py:26-37):
+//   K0  row_sqnorm_kernel          sq[v] = |z_v|^2
+//       degree_weighted_kernel     sum_v outdeg_v sq_v , sum_v indeg_v sq_v   (the two GLOBAL
+//                                  Frobenius norms of similarity.py:37, without gathering Z[edges])
+//   K1  edge_score_kernel          score_e = dot(z_src, z_dst) / denominator, CSR order; the source
+//                                  row stays in registers while the wave walks its neighbour list
+//   K2  segment_softmax_kernel     per-row softmax in place (graph.py:122-123)
+// All HBM-bound; K1 has the same gather shape as K3 (spmm_update.h) and the same lane layout.
+#pragma once
+
+#include "device_utils.h"
+
+namespace clane {
+
+constexpr int kScoreReference = 0;
+constexpr int kScorePerEdge = 1;
+constexpr int kScoreRawDot = 2;
+
+// ---- K0 ------------------------------------------------------------------------------------
+// LPR lanes per row; a wave covers 64/LPR rows at once.
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void row_sqnorm_kernel(const T *__restrict__ Z, int64_t nrows, int d, int64_t ldz,
+                                                            typename Elem<T>::acc_t *__restrict__ sq) {
+    using A = typename Elem<T>::acc_t;
+    constexpr int RPW = kWave / LPR;
+    const int lane = lane_id();
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = int64_t(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
+    for (int64_t base = wave * RPW; base < nrows; base += nwaves * RPW) {
+        const int64_t r = base + sub;
+        A s = A(0);
+        if (r < nrows) {
+            for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC) {
+                const Pack<T, VEC> z = load_pack<T, VEC>(Z + r * ldz + c0);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const A v = Elem<T>::to_acc(z.v[k]);
+                    s = fma(v, v, s);
+                }
+            }
+        }
+        s = group_sum<LPR>(s);
+        if (r < nrows && sl == 0) sq[r] = s;
+    }
+}
+
+// ws[b] / ws[G + b] <- block partials of outdeg*sq and indeg*sq  (G = gridDim.x)
+template <typename A>
+__global__ __launch_bounds__(kBlock) void degree_weighted_kernel(const A *__restrict__ sq,
+                                                                 const int64_t *__restrict__ rowptr,
+                                                                 const int32_t *__restrict__ indeg, int64_t nrows,
+                                                                 double *__restrict__ ws) {
+    __shared__ double smem[kWavesPerBlock];
+    double a = 0.0, b = 0.0;
+    for (int64_t v = int64_t(blockIdx.x) * kBlock + threadIdx.x; v < nrows; v += int64_t(gridDim.x) * kBlock) {
+        const double s = double(sq[v]);
+        a += double(rowptr[v + 1] - rowptr[v]) * s;
+        b += double(indeg[v]) * s;
+    }
+    const double ta = block_sum_fixed(a, smem);
+    const double tb = block_sum_fixed(b, smem);
+    if (threadIdx.x == 0) {
+        ws[blockIdx.x] = ta;
+        ws[gridDim.x + blockIdx.x] = tb;
+    }
+}
+
+// out[q] = sum_{i<n} in[q*stride + i], fixed order, for q < nout.  One workgroup.
+__global__ __launch_bounds__(1024) void reduce_fixed_kernel(const double *__restrict__ in, int64_t n, int64_t stride,
+                                                            int nout, double *__restrict__ out) {
+    __shared__ double smem[1024 / kWave];
+    for (int q = 0; q < nout; ++q) {
+        double s = 0.0;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += in[q * stride + i];
+        const double t = block_sum_fixed(s, smem);
+        if (threadIdx.x == 0) out[q] = t;
+    }
+}
+
+// ---- K1 ------------------------------------------------------------------------------------
+template <typename T, int VEC, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void edge_score_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows, int64_t row0,
+    const T *__restrict__ Z, int64_t ldz, int d, int mode, const double *__restrict__ sums2,
+    const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores) {
+    using A = typename Elem<T>::acc_t;
+    constexpr int EPW = kWave / LPR;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
+    const bool single = d <= LPR * VEC;  // whole row in one pack per lane: keep the source row in registers
+
+    A D = A(1);
+    if (mode == kScoreReference) D = sqrt(A(sums2[0])) * sqrt(A(sums2[1]));  // similarity.py:37
+
+    for (int64_t r = int64_t(blockIdx.x) * kWavesPerBlock + wave; r < nrows; r += nwaves) {
+        const int64_t e0 = rowptr[r];
+        const int64_t e1 = rowptr[r + 1];
+        if (e0 == e1) continue;
+        const T *zsrc = Z + (row0 + r) * ldz;
+        const A nsrc = mode == kScorePerEdge ? sqrt(sq[row0 + r]) : A(0);
+        Pack<T, VEC> s0{};
+        if (single && sl * VEC < d) s0 = load_pack<T, VEC>(zsrc + sl * VEC);
+
+        for (int64_t e = e0; e < e1; e += kWave) {
+            const int64_t left = e1 - e;
+            const int n = left < kWave ? int(left) : kWave;
+            const int c = lane < n ? colidx[e + lane] : 0;
+            for (int j = 0; j < n; j += EPW * U) {
+                A part[U];
+                int cj[U];
+                bool act[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = j + u * EPW + sub;
+                    if constexpr (LPR == kWave)
+                        cj[u] = lane_get_uniform(c, idx & (kWave - 1));
+                    else
+                        cj[u] = lane_get(c, idx & (kWave - 1));
+                    act[u] = idx < n;
+                    part[u] = A(0);
+                }
+                for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
+                    const int c0 = t0 + sl * VEC;
+                    const bool ok = c0 < d;
+                    Pack<T, VEC> s = s0;
+                    if (!single) {
+                        s = Pack<T, VEC>{};
+                        if (ok) s = load_pack<T, VEC>(zsrc + c0);
+                    }
+                    Pack<T, VEC> z[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        z[u] = Pack<T, VEC>{};
+                        if (act[u] && ok) z[u] = load_pack<T, VEC>(Z + int64_t(cj[u]) * ldz + c0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k)
+                            part[u] = fma(Elem<T>::to_acc(s.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const A dot = group_sum<LPR>(part[u]);
+                    if (act[u] && sl == 0) {
+                        A score = dot;
+                        if (mode == kScoreReference)
+                            score = dot / D;
+                        else if (mode == kScorePerEdge)
+                            score = dot / (nsrc * sqrt(sq[cj[u]]));
+                        scores[e + j + u * EPW + sub] = score;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- K2 ------------------------------------------------------------------------------------
+template <typename A>
+__device__ __forceinline__ A exp_acc(A v);
+template <>
+__device__ __forceinline__ float exp_acc<float>(float v) {
+    return expf(v);
+}
+template <>
+__device__ __forceinline__ double exp_acc<double>(double v) {
+    return exp(v);
+}
+
+// One wave per row; rows of <= 64 edges stay in registers, longer rows take three passes
+// over their (L2-resident) segment.
+template <typename A>
+__global__ __launch_bounds__(kBlock) void segment_softmax_kernel(const int64_t *__restrict__ rowptr, int64_t nrows,
+                                                                 A *__restrict__ vals) {
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
+    const A neg_inf = -A(INFINITY);
+    for (int64_t r = int64_t(blockIdx.x) * kWavesPerBlock + wave; r < nrows; r += nwaves) {
+        const int64_t e0 = rowptr[r];
+        const int64_t e1 = rowptr[r + 1];
+        const int64_t deg = e1 - e0;
+        if (deg == 0) continue;
+        if (deg <= kWave) {
+            const bool in = lane < deg;
+            const A v = in ? vals[e0 + lane] : neg_inf;
+            const A m = group_max<kWave>(v);
+            const A ex = in ? exp_acc<A>(v - m) : A(0);
+            const A s = group_sum<kWave>(ex);
+            if (in) vals[e0 + lane] = ex / s;
+        } else {
+            A m = neg_inf;
+            for (int64_t e = e0 + lane; e < e1; e += kWave) {
+                const A v = vals[e];
+                m = v > m ? v : m;
+            }
+            m = group_max<kWave>(m);
+            A s = A(0);
+            for (int64_t e = e0 + lane; e < e1; e += kWave) s += exp_acc<A>(vals[e] - m);
+            s = group_sum<kWave>(s);
+            for (int64_t e = e0 + lane; e < e1; e += kWave) vals[e] = exp_acc<A>(vals[e] - m) / s;
+        }
+    }
+}
+
+// ---- sum|A - B| (outer-loop delta, embedder.py:60) -------------------------------------------
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void l1_distance_kernel(const T *__restrict__ Am, int64_t lda,
+                                                             const T *__restrict__ Bm, int64_t ldb, int64_t nrows,
+                                                             int d, double *__restrict__ ws) {
+    using A = typename Elem<T>::acc_t;
+    __shared__ double smem[kWavesPerBlock];
+    constexpr int RPW = kWave / LPR;
+    const int lane = lane_id();
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = int64_t(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
+    double dsum = 0.0;
+    for (int64_t base = wave * RPW; base < nrows; base += nwaves * RPW) {
+        const int64_t r = base + sub;
+        if (r >= nrows) continue;
+        A s = A(0);
+        for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC) {
+            const Pack<T, VEC> a = load_pack<T, VEC>(Am + r * lda + c0);
+            const Pack<T, VEC> b = load_pack<T, VEC>(Bm + r * ldb + c0);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) s += fabs(Elem<T>::to_acc(a.v[k]) - Elem<T>::to_acc(b.v[k]));
+        }
+        dsum += double(s);
+    }
+    const double t = block_sum_fixed(dsum, smem);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+
+// ---- CosineSimilarity on explicit pairs (similarity.py:26-37) --------------------------------
+// out[r] <- dot(A_r, B_r); ws[b], ws[G+b] <- block partials of |A_r|^2, |B_r|^2.
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void pair_dot_kernel(const T *__restrict__ Am, int64_t lda,
+                                                          const T *__restrict__ Bm, int64_t ldb, int64_t nrows, int d,
+                                                          typename Elem<T>::acc_t *__restrict__ out,
+                                                          double *__restrict__ ws) {
+    using A = typename Elem<T>::acc_t;
+    __shared__ double smem[kWavesPerBlock];
+    constexpr int RPW = kWave / LPR;
+    const int lane = lane_id();
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = int64_t(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
+    double qa = 0.0, qb = 0.0;
+    for (int64_t base = wave * RPW; base < nrows; base += nwaves * RPW) {
+        const int64_t r = base + sub;
+        A dot = A(0), sa = A(0), sb = A(0);
+        if (r < nrows) {
+            for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC) {
+                const Pack<T, VEC> a = load_pack<T, VEC>(Am + r * lda + c0);
+                const Pack<T, VEC> b = load_pack<T, VEC>(Bm + r * ldb + c0);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const A x = Elem<T>::to_acc(a.v[k]), y = Elem<T>::to_acc(b.v[k]);
+                    dot = fma(x, y, dot);
+                    sa = fma(x, x, sa);
+                    sb = fma(y, y, sb);
+                }
+            }
+        }
+        dot = group_sum<LPR>(dot);
+        if (r < nrows && sl == 0) out[r] = dot;
+        qa += double(sa);
+        qb += double(sb);
+    }
+    const double ta = block_sum_fixed(qa, smem);
+    const double tb = block_sum_fixed(qb, smem);
+    if (threadIdx.x == 0) {
+        ws[blockIdx.x] = ta;
+        ws[gridDim.x + blockIdx.x] = tb;
+    }
+}
+
+template <typename A>
+__global__ __launch_bounds__(kBlock) void pair_scale_kernel(A *__restrict__ out, int64_t nrows,
+                                                            const double *__restrict__ sums2) {
+    const A D = sqrt(A(sums2[0])) * sqrt(A(sums2[1]));
+    for (int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x; i < nrows; i += int64_t(gridDim.x) * kBlock)
+        out[i] = out[i] / D;
+}
+
+}  // namespace clane

@@ -1,0 +1,343 @@
+// extern "C" surface of libclane_hip.so (see include/clane_hip.h): argument validation,
+// lane-layout selection and kernel launches.  No allocation, no synchronisation, no state.
+#include "../../include/clane_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+
+#include "build_p.h"
+#include "device_utils.h"
+#include "spmm_update.h"
+
+namespace {
+
+using namespace clane;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(CLANE_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return CLANE_OK;
+}
+
+constexpr int kReduceGrid = 1024;              // partial blocks of the two-stage reductions
+constexpr int64_t kReduceWs = 2 * kReduceGrid + 2;  // + the two finished sums
+constexpr int kLongWaves = 16;
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int grid_for_waves(int64_t nwaves_wanted) {
+    int64_t g = ceil_div(nwaves_wanted, kWavesPerBlock);
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g < 1) g = 1;
+    return int(g);
+}
+
+// Lane layout: 16-byte packs when every operand allows it, else one element per lane.
+struct Layout {
+    bool vec;  // 16-byte path
+    int lpr;   // lanes per row (power of two)
+};
+
+template <typename T>
+Layout pick_layout(int d, std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> lds) {
+    constexpr int KV = Elem<T>::kVec;
+    bool vec = true;
+    for (const void *p : ptrs) vec = vec && aligned16(p);
+    for (int64_t ld : lds) vec = vec && (ld % KV == 0);
+    Layout L;
+    L.vec = vec;
+    if (vec) {
+        const int packs = int(ceil_div(d, KV));
+        L.lpr = packs <= 8 ? 8 : packs <= 16 ? 16 : packs <= 32 ? 32 : 64;
+    } else {
+        L.lpr = d <= 4 ? 4 : d <= 16 ? 16 : 64;
+    }
+    return L;
+}
+
+// Calls f.template operator()<VEC, LPR>() for the chosen layout.
+template <typename T, typename F>
+void dispatch_layout(const Layout &L, F &&f) {
+    constexpr int KV = Elem<T>::kVec;
+    if (L.vec) {
+        switch (L.lpr) {
+            case 8: f.template operator()<KV, 8>(); break;
+            case 16: f.template operator()<KV, 16>(); break;
+            case 32: f.template operator()<KV, 32>(); break;
+            default: f.template operator()<KV, 64>(); break;
+        }
+    } else {
+        switch (L.lpr) {
+            case 4: f.template operator()<1, 4>(); break;
+            case 16: f.template operator()<1, 16>(); break;
+            default: f.template operator()<1, 64>(); break;
+        }
+    }
+}
+
+#define REQUIRE(cond, ...) \
+    do {                   \
+        if (!(cond)) return fail(CLANE_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+int row_sqnorm(const T *Z, int64_t nrows, int32_t d, int64_t ldz, typename Elem<T>::acc_t *sq, void *stream) {
+    REQUIRE(nrows >= 0 && d > 0 && ldz >= d, "row_sqnorm: bad shape nrows=%lld d=%d ldz=%lld", (long long)nrows, d,
+            (long long)ldz);
+    if (nrows == 0) return CLANE_OK;
+    REQUIRE(Z && sq, "row_sqnorm: null pointer");
+    const Layout L = pick_layout<T>(d, {Z}, {ldz});
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        const int grid = grid_for_waves(ceil_div(nrows, kWave / LPR));
+        row_sqnorm_kernel<T, VEC, LPR><<<grid, kBlock, 0, (hipStream_t)stream>>>(Z, nrows, d, ldz, sq);
+    });
+    return check_launch("row_sqnorm");
+}
+
+template <typename A>
+int degree_weighted_sums(const A *sq, const int64_t *rowptr, const int32_t *indeg, int64_t nrows, double *ws,
+                         double *out2, void *stream) {
+    REQUIRE(nrows >= 0, "degree_weighted_sums: nrows < 0");
+    REQUIRE(ws && out2, "degree_weighted_sums: null workspace/output");
+    REQUIRE(nrows == 0 || (sq && rowptr && indeg), "degree_weighted_sums: null pointer");
+    int grid = int(ceil_div(nrows > 0 ? nrows : 1, kBlock));
+    if (grid > kReduceGrid) grid = kReduceGrid;
+    degree_weighted_kernel<A><<<grid, kBlock, 0, (hipStream_t)stream>>>(sq, rowptr, indeg, nrows, ws);
+    reduce_fixed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ws, grid, grid, 2, out2);
+    return check_launch("degree_weighted_sums");
+}
+
+template <typename T>
+int edge_score(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const T *Z, int64_t ldz,
+               int32_t d, int32_t mode, const double *sums2, const typename Elem<T>::acc_t *sq,
+               typename Elem<T>::acc_t *scores, void *stream) {
+    REQUIRE(nrows >= 0 && row0 >= 0 && d > 0 && ldz >= d, "edge_score: bad shape");
+    REQUIRE(mode == CLANE_SCORE_REFERENCE || mode == CLANE_SCORE_PER_EDGE || mode == CLANE_SCORE_RAW_DOT,
+            "edge_score: unknown mode %d", mode);
+    if (nrows == 0) return CLANE_OK;
+    REQUIRE(rowptr && colidx && Z && scores, "edge_score: null pointer");
+    REQUIRE(mode != CLANE_SCORE_REFERENCE || sums2, "edge_score: mode REFERENCE needs sums2");
+    REQUIRE(mode != CLANE_SCORE_PER_EDGE || sq, "edge_score: mode PER_EDGE needs sq");
+    const Layout L = pick_layout<T>(d, {Z}, {ldz});
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        constexpr int U = VEC > 1 ? 8 : 4;
+        const int grid = grid_for_waves(nrows);
+        edge_score_kernel<T, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(rowptr, colidx, nrows, row0, Z,
+                                                                                    ldz, d, mode, sums2, sq, scores);
+    });
+    return check_launch("edge_score");
+}
+
+template <typename A>
+int segment_softmax(const int64_t *rowptr, int64_t nrows, A *vals, void *stream) {
+    REQUIRE(nrows >= 0, "segment_softmax: nrows < 0");
+    if (nrows == 0) return CLANE_OK;
+    REQUIRE(rowptr && vals, "segment_softmax: null pointer");
+    segment_softmax_kernel<A><<<grid_for_waves(nrows), kBlock, 0, (hipStream_t)stream>>>(rowptr, nrows, vals);
+    return check_launch("segment_softmax");
+}
+
+inline int64_t spmm_main_grid(int64_t nrows) { return grid_for_waves(nrows); }
+
+template <typename T, typename PT>
+int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows, int64_t row0,
+                const T *Z_old, int64_t ldz, const T *X, int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new,
+                int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials, void *stream) {
+    REQUIRE(nrows >= 0 && row0 >= 0 && d > 0, "spmm_update: bad shape nrows=%lld row0=%lld d=%d", (long long)nrows,
+            (long long)row0, d);
+    REQUIRE(ldz >= d && ldx >= d && ldo >= d, "spmm_update: leading dimension < d");
+    REQUIRE(long_threshold >= 0, "spmm_update: negative long_threshold");
+    REQUIRE(delta_partials, "spmm_update: null delta_partials");
+    if (nrows == 0) return CLANE_OK;
+    REQUIRE(rowptr && colidx && P && Z_old && X && Z_new, "spmm_update: null pointer");
+    REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update: Z_new must not alias Z_old (Jacobi sweep)");
+    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new}, {ldz, ldx, ldo});
+    const int grid = int(spmm_main_grid(nrows));
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        constexpr int U = VEC > 1 ? 8 : 4;
+        spmm_update_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+            rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold, delta_partials);
+    });
+    return check_launch("spmm_update");
+}
+
+template <typename T, typename PT>
+int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, const int32_t *long_rows,
+                     int64_t n_long, int64_t row0, const T *Z_old, int64_t ldz, const T *X, int64_t ldx,
+                     typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d, double *delta_partials,
+                     void *stream) {
+    REQUIRE(n_long >= 0 && n_long <= INT32_MAX && row0 >= 0 && d > 0, "spmm_update_long: bad shape");
+    REQUIRE(ldz >= d && ldx >= d && ldo >= d, "spmm_update_long: leading dimension < d");
+    if (n_long == 0) return CLANE_OK;
+    REQUIRE(rowptr && colidx && P && long_rows && Z_old && X && Z_new && delta_partials,
+            "spmm_update_long: null pointer");
+    REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update_long: Z_new must not alias Z_old");
+    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new}, {ldz, ldx, ldo});
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        constexpr int U = VEC > 1 ? 8 : 4;
+        spmm_long_kernel<T, PT, VEC, LPR, U, kLongWaves><<<int(n_long), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
+            rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, delta_partials);
+    });
+    return check_launch("spmm_update_long");
+}
+
+template <typename T>
+int l1_distance(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows, int32_t d, double *ws, double *out,
+                void *stream) {
+    REQUIRE(nrows >= 0 && d > 0 && lda >= d && ldb >= d, "l1_distance: bad shape");
+    REQUIRE(ws && out, "l1_distance: null workspace/output");
+    REQUIRE(nrows == 0 || (A && B), "l1_distance: null pointer");
+    const Layout L = pick_layout<T>(d, {A, B}, {lda, ldb});
+    int grid = 1;
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        grid = grid_for_waves(ceil_div(nrows > 0 ? nrows : 1, kWave / LPR));
+        if (grid > kReduceGrid) grid = kReduceGrid;
+        l1_distance_kernel<T, VEC, LPR><<<grid, kBlock, 0, (hipStream_t)stream>>>(A, lda, B, ldb, nrows, d, ws);
+    });
+    reduce_fixed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ws, grid, grid, 1, out);
+    return check_launch("l1_distance");
+}
+
+template <typename T>
+int pair_cosine(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows, int32_t d,
+                typename Elem<T>::acc_t *out, double *ws, void *stream) {
+    REQUIRE(nrows >= 0 && d > 0 && lda >= d && ldb >= d, "pair_cosine: bad shape");
+    if (nrows == 0) return CLANE_OK;
+    REQUIRE(A && B && out && ws, "pair_cosine: null pointer");
+    const Layout L = pick_layout<T>(d, {A, B}, {lda, ldb});
+    int grid = 1;
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        grid = grid_for_waves(ceil_div(nrows, kWave / LPR));
+        if (grid > kReduceGrid) grid = kReduceGrid;
+        pair_dot_kernel<T, VEC, LPR><<<grid, kBlock, 0, (hipStream_t)stream>>>(A, lda, B, ldb, nrows, d, out, ws);
+    });
+    double *sums2 = ws + 2 * kReduceGrid;
+    reduce_fixed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ws, grid, grid, 2, sums2);
+    int sgrid = int(ceil_div(nrows, kBlock));
+    if (sgrid > kMaxGrid) sgrid = kMaxGrid;
+    pair_scale_kernel<typename Elem<T>::acc_t><<<sgrid, kBlock, 0, (hipStream_t)stream>>>(out, nrows, sums2);
+    return check_launch("pair_cosine");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int clane_abi_version(void) { return CLANE_ABI_VERSION; }
+const char *clane_last_error(void) { return g_err; }
+
+int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long) {
+    return spmm_main_grid(nrows > 0 ? nrows : 1) + (n_long > 0 ? n_long : 0);
+}
+int64_t clane_reduce_ws_len(void) { return kReduceWs; }
+
+int clane_row_sqnorm_f32(const float *Z, int64_t nrows, int32_t d, int64_t ldz, float *sq, void *stream) {
+    return row_sqnorm<float>(Z, nrows, d, ldz, sq, stream);
+}
+int clane_row_sqnorm_f64(const double *Z, int64_t nrows, int32_t d, int64_t ldz, double *sq, void *stream) {
+    return row_sqnorm<double>(Z, nrows, d, ldz, sq, stream);
+}
+int clane_row_sqnorm_bf16(const uint16_t *Z, int64_t nrows, int32_t d, int64_t ldz, float *sq, void *stream) {
+    return row_sqnorm<bf16_t>(reinterpret_cast<const bf16_t *>(Z), nrows, d, ldz, sq, stream);
+}
+
+int clane_degree_weighted_sums_f32(const float *sq, const int64_t *rowptr, const int32_t *indeg, int64_t nrows,
+                                   double *ws, double *out2, void *stream) {
+    return degree_weighted_sums<float>(sq, rowptr, indeg, nrows, ws, out2, stream);
+}
+int clane_degree_weighted_sums_f64(const double *sq, const int64_t *rowptr, const int32_t *indeg, int64_t nrows,
+                                   double *ws, double *out2, void *stream) {
+    return degree_weighted_sums<double>(sq, rowptr, indeg, nrows, ws, out2, stream);
+}
+
+int clane_edge_score_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const float *Z,
+                         int64_t ldz, int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
+                         void *stream) {
+    return edge_score<float>(rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, stream);
+}
+int clane_edge_score_f64(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const double *Z,
+                         int64_t ldz, int32_t d, int32_t mode, const double *sums2, const double *sq, double *scores,
+                         void *stream) {
+    return edge_score<double>(rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, stream);
+}
+int clane_edge_score_bf16(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
+                          const uint16_t *Z, int64_t ldz, int32_t d, int32_t mode, const double *sums2,
+                          const float *sq, float *scores, void *stream) {
+    return edge_score<bf16_t>(rowptr, colidx, nrows, row0, reinterpret_cast<const bf16_t *>(Z), ldz, d, mode, sums2,
+                              sq, scores, stream);
+}
+
+int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, void *stream) {
+    return segment_softmax<float>(rowptr, nrows, vals, stream);
+}
+int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals, void *stream) {
+    return segment_softmax<double>(rowptr, nrows, vals, stream);
+}
+
+#define CLANE_SPMM_WRAPPERS(SUF, CT, T, PT, GT)                                                                        \
+    int clane_spmm_update_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows,             \
+                                int64_t row0, const CT *Z_old, int64_t ldz, const CT *X, int64_t ldx, GT gamma,       \
+                                CT *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials,    \
+                                void *stream) {                                                                       \
+        return spmm_update<T, PT>(rowptr, colidx, P, nrows, row0, reinterpret_cast<const T *>(Z_old), ldz,            \
+                                  reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new), ldo, d,   \
+                                  long_threshold, delta_partials, stream);                                            \
+    }                                                                                                                 \
+    int clane_spmm_update_long_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P,                       \
+                                     const int32_t *long_rows, int64_t n_long, int64_t row0, const CT *Z_old,         \
+                                     int64_t ldz, const CT *X, int64_t ldx, GT gamma, CT *Z_new, int64_t ldo,         \
+                                     int32_t d, double *delta_partials, void *stream) {                               \
+        return spmm_update_long<T, PT>(rowptr, colidx, P, long_rows, n_long, row0,                                    \
+                                       reinterpret_cast<const T *>(Z_old), ldz, reinterpret_cast<const T *>(X), ldx,  \
+                                       gamma, reinterpret_cast<T *>(Z_new), ldo, d, delta_partials, stream);          \
+    }
+CLANE_SPMM_WRAPPERS(f32, float, float, float, float)
+CLANE_SPMM_WRAPPERS(f64, double, double, double, double)
+CLANE_SPMM_WRAPPERS(bf16, uint16_t, bf16_t, float, float)
+#undef CLANE_SPMM_WRAPPERS
+
+int clane_reduce_partials(const double *partials, int64_t n, double *out, void *stream) {
+    if (n < 0 || !out || (n > 0 && !partials)) return fail(CLANE_ERR_INVALID_ARGUMENT, "reduce_partials: bad arguments");
+    reduce_fixed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partials, n, n, 1, out);
+    return check_launch("reduce_partials");
+}
+
+int clane_l1_distance_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t nrows, int32_t d,
+                          double *ws, double *out, void *stream) {
+    return l1_distance<float>(A, lda, B, ldb, nrows, d, ws, out, stream);
+}
+int clane_l1_distance_f64(const double *A, int64_t lda, const double *B, int64_t ldb, int64_t nrows, int32_t d,
+                          double *ws, double *out, void *stream) {
+    return l1_distance<double>(A, lda, B, ldb, nrows, d, ws, out, stream);
+}
+int clane_l1_distance_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, int64_t nrows, int32_t d,
+                           double *ws, double *out, void *stream) {
+    return l1_distance<bf16_t>(reinterpret_cast<const bf16_t *>(A), lda, reinterpret_cast<const bf16_t *>(B), ldb,
+                               nrows, d, ws, out, stream);
+}
+
+int clane_pair_cosine_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t nrows, int32_t d,
+                          float *out, double *ws, void *stream) {
+    return pair_cosine<float>(A, lda, B, ldb, nrows, d, out, ws, stream);
+}
+int clane_pair_cosine_f64(const double *A, int64_t lda, const double *B, int64_t ldb, int64_t nrows, int32_t d,
+                          double *out, double *ws, void *stream) {
+    return pair_cosine<double>(A, lda, B, ldb, nrows, d, out, ws, stream);
+}
+
+}  // extern "C"

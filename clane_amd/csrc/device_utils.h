@@ -1,0 +1,120 @@
+// Shared device helpers for the CLANE gfx950 kernels: element traits (storage type -> accumulate
+// type, 16-byte packs), wave64 broadcast / reduction primitives, and the block-level
+// fixed-order reduction used for every value that feeds host control flow.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clane {
+
+constexpr int kWave = 64;          // gfx950 wavefront
+constexpr int kBlock = 256;        // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 resident 256-thread workgroups
+
+struct bf16_t {
+    uint16_t bits;
+};
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    using acc_t = float;
+    static constexpr int kVec = 4;
+    static __device__ __forceinline__ float to_acc(float v) { return v; }
+    static __device__ __forceinline__ float from_acc(float v) { return v; }
+};
+template <>
+struct Elem<double> {
+    using acc_t = double;
+    static constexpr int kVec = 2;
+    static __device__ __forceinline__ double to_acc(double v) { return v; }
+    static __device__ __forceinline__ double from_acc(double v) { return v; }
+};
+template <>
+struct Elem<bf16_t> {
+    using acc_t = float;
+    static constexpr int kVec = 8;
+    static __device__ __forceinline__ float to_acc(bf16_t v) { return __uint_as_float(uint32_t(v.bits) << 16); }
+    static __device__ __forceinline__ bf16_t from_acc(float f) {
+        // round-to-nearest-even; NaN stays NaN (quiet bit forced)
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t{uint16_t((u >> 16) | 0x0040u)};
+        return bf16_t{uint16_t((u + 0x7fffu + ((u >> 16) & 1u)) >> 16)};
+    }
+};
+
+// VEC elements moved as one access (16 B when VEC == Elem<T>::kVec, sizeof(T) when VEC == 1).
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) Pack {
+    T v[VEC];
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_pack(const T *p) {
+    return *reinterpret_cast<const Pack<T, VEC> *>(p);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_pack(T *p, const Pack<T, VEC> &v) {
+    *reinterpret_cast<Pack<T, VEC> *>(p) = v;
+}
+
+// ---- wave64 cross-lane -------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// Value of lane `src` (any per-lane index) -- ds_bpermute.
+__device__ __forceinline__ int lane_get(int v, int src) { return __shfl(v, src, kWave); }
+__device__ __forceinline__ float lane_get(float v, int src) { return __shfl(v, src, kWave); }
+__device__ __forceinline__ double lane_get(double v, int src) { return __shfl(v, src, kWave); }
+
+// Value of lane `src` where `src` is wave-uniform -- v_readlane_b32 into an SGPR, so the
+// dependent row address is formed on the scalar unit.
+__device__ __forceinline__ int lane_get_uniform(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float lane_get_uniform(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ double lane_get_uniform(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane(int(b), src);
+    const int hi = __builtin_amdgcn_readlane(int(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// Butterfly sum over aligned groups of WIDTH lanes; every lane of the group gets the total.
+template <int WIDTH, typename A>
+__device__ __forceinline__ A group_sum(A v) {
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+template <int WIDTH, typename A>
+__device__ __forceinline__ A group_max(A v) {
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) {
+        const A o = __shfl_xor(v, m, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// Sum of `v` over the workgroup in a fixed order (lane butterfly, then waves 0..n-1 in turn);
+// valid in thread 0.  `smem` holds one double per wave.
+__device__ __forceinline__ double block_sum_fixed(double v, double *smem) {
+    v = group_sum<kWave>(v);
+    const int wave = threadIdx.x / kWave;
+    if (lane_id() == 0) smem[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x / kWave;
+        for (int w = 0; w < nw; ++w) s += smem[w];
+    }
+    __syncthreads();
+    return s;
+}
+
+__host__ __device__ __forceinline__ int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace clane

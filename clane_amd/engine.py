@@ -1,0 +1,242 @@
+"""SweepEngine -- device-resident state and the launch sequence of the embedding loop.
+
+Replaces, for one rank, what the reference spreads over ``Graph.build_P`` (graph.py:118-128),
+the body of ``Embedder.propagate`` (embedder.py:84-94) and the per-vertex tensors behind
+``Graph.Z`` (graph.py:130-138).  All arithmetic is done by the HIP kernels behind
+``clane_amd._hip.HipKernels`` (C ABI in include/clane_hip.h); torch is used for device memory,
+the D2H copy of one scalar per sweep and ``torch.distributed`` (RCCL).
+
+HBM layout per rank (T = float32 / float64 / bfloat16, ld = d rounded up to a 16-byte pack,
+pad columns zero):
+
+    Zbuf[2]   [V_pad, ld] T    full embedding matrix, ping-pong (read old / write new)
+    X_loc     [n_loc, ld] T    content embeddings of the owned rows
+    rowptr    [n_loc+1] i64, colidx [E_loc] i32 (positions), P [E_loc] acc, indeg [n_loc] i32
+    partials  fixed-order L1-delta partial sums (double)
+
+Multi-GPU: rows are partitioned (partition.py); after the kernel of chunk c, its slice of
+Z_new is all-gathered in place (async, on RCCL's stream) while chunk c+1 computes; the scalar
+delta is all-reduced.  On one GPU no collective is issued.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _hip
+from .partition import HostCSR, LocalCSR, RowPartition, localize
+
+DEFAULT_LONG_THRESHOLD = 1024
+
+
+def _round_up(a: int, b: int) -> int:
+    return -(-a // b) * b
+
+
+class SweepEngine:
+    def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
+                 process_group=None, chunks: Optional[int] = None, long_threshold: int = DEFAULT_LONG_THRESHOLD,
+                 shuffle: Optional[bool] = None, seed: int = 0):
+        if X.dim() != 2 or X.shape[0] != csr.num_vertices:
+            raise ValueError(f"X must be [V, d] with V={csr.num_vertices}, got {tuple(X.shape)}")
+        if cosine_mode not in ("reference", "per_edge"):
+            raise ValueError(f"cosine_mode must be 'reference' or 'per_edge', got {cosine_mode!r}")
+        self.k = kernels if kernels is not None else _hip.kernels()
+        self.device = torch.device(device)
+        self.dtype = X.dtype
+        self.acc_dtype = _hip.acc_dtype(X.dtype)
+        self.cosine_mode = cosine_mode
+        self.pg = process_group
+        self.world = 1
+        rank = 0
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+            rank = dist.get_rank(process_group)
+        if chunks is None:
+            chunks = 1 if self.world == 1 else 4
+        self.V, self.d = csr.num_vertices, int(X.shape[1])
+        self.ld = _round_up(self.d, _hip.VEC_ELEMS[X.dtype])
+        self.part = RowPartition.create(self.V, self.world, rank, chunks, shuffle=shuffle, seed=seed)
+        self.local: LocalCSR = localize(csr, self.part)
+        self.long_threshold = int(long_threshold)
+        dev = self.device
+
+        # ---- graph structure ----------------------------------------------------------
+        self.rowptr = torch.from_numpy(self.local.rowptr).to(dev)
+        self.colidx = torch.from_numpy(self.local.colidx).to(dev)
+        self.indeg = torch.from_numpy(self.local.indeg).to(dev)
+        self.E_loc = int(self.local.colidx.shape[0])
+        self.P = torch.zeros(max(self.E_loc, 1), dtype=self.acc_dtype, device=dev)
+        self.P_valid = False
+        vc = self.part.rows_per_chunk
+        deg = np.diff(self.local.rowptr)
+        self.long_rows: List[Optional[torch.Tensor]] = []
+        self.partial_off = [0]
+        for c in range(self.part.chunks):
+            lr = np.nonzero(deg[c * vc:(c + 1) * vc] > self.long_threshold)[0].astype(np.int32) \
+                if self.long_threshold > 0 else np.empty(0, np.int32)
+            self.long_rows.append(torch.from_numpy(lr).to(dev) if lr.size else None)
+            self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(vc, int(lr.size)))
+        self.partials = torch.zeros(self.partial_off[-1], dtype=torch.float64, device=dev)
+
+        # ---- embeddings ---------------------------------------------------------------
+        self.pos = torch.from_numpy(self.part.position_of_vertex())           # host, int64 [V]
+        self.Zbuf = [torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype, device=dev) for _ in range(2)]
+        self.cur = 0
+        verts = torch.from_numpy(self.local.vertex)
+        Xl = torch.zeros(self.part.n_local, self.ld, dtype=self.dtype)
+        ok = verts >= 0
+        Xl[ok, :self.d] = X[verts[ok]]
+        self.X_loc = Xl.to(dev)
+        self.set_Z(X)
+
+        # ---- scalars / scratch --------------------------------------------------------
+        self.ws = torch.zeros(self.k.reduce_ws_len(), dtype=torch.float64, device=dev)
+        self.sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.delta = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.chunk_out = torch.zeros(self.part.chunks, dtype=torch.float64, device=dev)
+        self.sq_loc = torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev)
+        self.sq_full: Optional[torch.Tensor] = None
+        self.snap: Optional[torch.Tensor] = None
+        self.sweeps_done = 0
+        # optional per-kernel timing with HIP events on the launch stream (bench.py)
+        self.time_kernels = False
+        self.kernel_events = []          # [(chunk, start, after_main, after_long)]
+
+    # ---- Z in / out -------------------------------------------------------------------
+    @property
+    def Zcur(self) -> torch.Tensor:
+        return self.Zbuf[self.cur]
+
+    def set_Z(self, Z: torch.Tensor) -> None:
+        """Load a [V, d] matrix (vertex order) into the current full-Z buffer."""
+        if tuple(Z.shape) != (self.V, self.d):
+            raise ValueError(f"set_Z: expected {(self.V, self.d)}, got {tuple(Z.shape)}")
+        full = torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype)
+        full[self.pos, :self.d] = Z.detach().to("cpu", self.dtype)
+        self.Zcur.copy_(full)
+        self.P_valid = False
+
+    def get_Z(self) -> torch.Tensor:
+        """Current embeddings as a fresh CPU tensor [V, d] in vertex order."""
+        return self.Zcur.to("cpu")[self.pos, :self.d].clone()
+
+    # ---- build_P (graph.py:118-128) -----------------------------------------------------
+    def build_P(self) -> None:
+        k, part, vc = self.k, self.part, self.part.rows_per_chunk
+        Z = self.Zcur
+        mode = _hip.SCORE_MODES[self.cosine_mode]
+        sq = None
+        if self.cosine_mode == "reference":
+            for c in range(part.chunks):
+                r0 = part.chunk_row0(c)
+                k.row_sqnorm(Z[r0:r0 + vc], self.d, self.sq_loc[c * vc:(c + 1) * vc])
+            k.degree_weighted_sums(self.sq_loc, self.rowptr, self.indeg, part.n_local, self.ws, self.sums2)
+            self._all_reduce(self.sums2)
+        else:
+            if self.sq_full is None:
+                self.sq_full = torch.zeros(part.padded_vertices, dtype=self.acc_dtype, device=self.device)
+            k.row_sqnorm(Z, self.d, self.sq_full)
+            sq = self.sq_full
+        if self.E_loc > 0:
+            for c in range(part.chunks):
+                k.edge_score(self.rowptr[c * vc:], self.colidx, vc, part.chunk_row0(c), Z, self.d, mode,
+                             self.sums2, sq, self.P)
+            k.segment_softmax(self.rowptr, part.n_local, self.P)
+        self.P_valid = True
+
+    def P_values_global_order(self) -> torch.Tensor:
+        """Local P values as a CPU tensor plus their index in the global CSR order."""
+        return self.P[:self.E_loc].to("cpu")
+
+    # ---- one sweep (embedder.py:84-94) --------------------------------------------------
+    def sweep(self, gamma: float) -> float:
+        """Z <- X + gamma * P Z on the owned rows, exchange, return sum|Z_new - Z_old| (global)."""
+        if not self.P_valid:
+            raise RuntimeError("sweep() before build_P()")
+        k, part, vc = self.k, self.part, self.part.rows_per_chunk
+        Zold, Znew = self.Zbuf[self.cur], self.Zbuf[1 - self.cur]
+        works = []
+        for c in range(part.chunks):
+            r0 = part.chunk_row0(c)
+            rp, Xc, Zn = self.rowptr[c * vc:], self.X_loc[c * vc:(c + 1) * vc], Znew[r0:r0 + vc]
+            po = self.partial_off[c]
+            ev = self._events(c) if self.time_kernels else None
+            if ev:
+                ev[0].record()
+            k.spmm_update(rp, self.colidx, self.P, vc, r0, Zold, Xc, gamma, Zn, self.d, self.long_threshold,
+                          self.partials[po:])
+            if ev:
+                ev[1].record()
+            if self.long_rows[c] is not None:
+                k.spmm_update_long(rp, self.colidx, self.P, self.long_rows[c], r0, Zold, Xc, gamma, Zn, self.d,
+                                   self.partials[po + self.k.spmm_partials_len(vc, 0):])
+            if ev:
+                ev[2].record()
+            if self.world > 1:
+                import torch.distributed as dist
+                b, e = part.chunk_span(c)
+                works.append(dist.all_gather_into_tensor(Znew[b:e], Znew[r0:r0 + vc], group=self.pg, async_op=True))
+        k.reduce_partials(self.partials, self.partials.numel(), self.delta)
+        self._all_reduce(self.delta)
+        for w in works:
+            w.wait()
+        self.cur = 1 - self.cur
+        self.sweeps_done += 1
+        return float(self.delta.item())
+
+    def _events(self, c: int):
+        ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+        self.kernel_events.append((c,) + ev)
+        return ev
+
+    def kernel_times_ms(self):
+        """(main-pass ms, long-row-pass ms) per recorded launch; call after a synchronize."""
+        out = [(a.elapsed_time(b), b.elapsed_time(e)) for _, a, b, e in self.kernel_events]
+        self.kernel_events = []
+        return out
+
+    def main_pass_bytes(self) -> int:
+        """Algorithmic bytes (section 8d gather model) of the rows the MAIN kernel handles."""
+        s, ps = self.Zcur.element_size(), self.P.element_size()
+        deg = np.diff(self.local.rowptr)
+        keep = deg <= self.long_threshold if self.long_threshold > 0 else np.ones_like(deg, dtype=bool)
+        E, n = int(deg[keep].sum()), self.part.n_local
+        return E * self.d * s + E * (4 + ps) + (n + 1) * 8 + 3 * int(keep.sum()) * self.d * s
+
+    # ---- outer-loop delta (embedder.py:58-60) -------------------------------------------
+    def snapshot(self) -> None:
+        vc = self.part.rows_per_chunk
+        if self.snap is None:
+            self.snap = torch.empty(self.part.n_local, self.ld, dtype=self.dtype, device=self.device)
+        for c in range(self.part.chunks):
+            r0 = self.part.chunk_row0(c)
+            self.snap[c * vc:(c + 1) * vc].copy_(self.Zcur[r0:r0 + vc])
+
+    def distance_from_snapshot(self) -> float:
+        if self.snap is None:
+            raise RuntimeError("distance_from_snapshot() before snapshot()")
+        vc = self.part.rows_per_chunk
+        for c in range(self.part.chunks):
+            r0 = self.part.chunk_row0(c)
+            self.k.l1_distance(self.Zcur[r0:r0 + vc], self.snap[c * vc:(c + 1) * vc], self.d, self.ws,
+                               self.chunk_out[c:c + 1])
+        self.k.reduce_partials(self.chunk_out, self.part.chunks, self.delta)
+        self._all_reduce(self.delta)
+        return float(self.delta.item())
+
+    # ---- collectives ------------------------------------------------------------------
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+    # ---- accounting (bench.py / DESIGN.md) ----------------------------------------------
+    def algorithmic_bytes_per_sweep(self) -> int:
+        """SURVEY.md section 8d gather model, for the rows this rank owns."""
+        s = self.Zcur.element_size()
+        n, E, d = self.part.n_local, self.E_loc, self.d
+        return E * d * s + E * (4 + self.P.element_size()) + (n + 1) * 8 + 3 * n * d * s

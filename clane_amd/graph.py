@@ -1,0 +1,284 @@
+"""Graph -- the reference's ``clane/graph.py`` surface over CSR arrays and GPU-resident state.
+
+Same constructor, attributes and methods as the reference (``Graph(data_root, embedding_dim)``,
+``d, vertex_ids, X, V, E, dispense_pair, A, get_nbrs, build_P, Z, set_Z, len()``), same files
+(``V``: ids one per line; ``E``: ``src\\tdst`` per line; optional ``C.npy`` / ``C.pt``), same
+exceptions.  What differs is the representation: one O(|E|) parse into CSR instead of a Python
+``Edge`` object per line and an O(|V|) ``list.index`` per endpoint (graph.py:79-89), and the
+embeddings live in HBM inside a ``SweepEngine`` instead of one tensor per ``Vertex``.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _hip
+from .partition import HostCSR
+
+
+# ---- file parsing (graph.py:43-47, 72-81) ---------------------------------------------------
+def read_vertex_ids(data_root: Path) -> List[str]:
+    with open(Path(data_root).joinpath("V"), "r") as io:          # FileNotFoundError propagates
+        return io.read().strip().split("\n")
+
+
+def read_edge_indices(data_root: Path, vertex_ids: Sequence[str]):
+    """-> (src, dst) int64 arrays, one entry per line of ``E`` (duplicates kept).
+
+    An id resolves to the index of its FIRST occurrence in ``V`` (``list.index``,
+    graph.py:81); an unknown id or a line without exactly one tab raises ValueError.
+    """
+    with open(Path(data_root).joinpath("E"), "r") as io:
+        lines = io.read().strip().split("\n")
+    first = {}
+    for i, vid in enumerate(vertex_ids):
+        first.setdefault(vid, i)
+    src = np.empty(len(lines), dtype=np.int64)
+    dst = np.empty(len(lines), dtype=np.int64)
+    for k, line in enumerate(lines):
+        parts = line.split("\t")
+        if len(parts) != 2:
+            raise ValueError(f"E line {k + 1}: expected 'src\\tdst', got {line!r}")
+        try:
+            src[k], dst[k] = first[parts[0]], first[parts[1]]
+        except KeyError as exc:
+            raise ValueError(f"{exc.args[0]!r} is not in list") from None
+    return src, dst
+
+
+def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray) -> HostCSR:
+    """Coalesced adjacency (graph.py:104-110): sorted by (src, dst), duplicates merged, self-loops kept."""
+    key = np.unique(src.astype(np.int64) * np.int64(num_vertices) + dst.astype(np.int64))
+    rows = key // num_vertices
+    rowptr = np.zeros(num_vertices + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=num_vertices), out=rowptr[1:])
+    return HostCSR(num_vertices, rowptr, (key % num_vertices).astype(np.int32))
+
+
+# ---- object-model facade ----------------------------------------------------------------------
+class Vertex(object):
+    """View of one vertex (reference graph.py:9-21).  ``x`` / ``z`` are rows of the graph's matrices."""
+    __slots__ = ("_g", "idx", "id_")
+
+    def __init__(self, graph: "Graph", idx: int, id_) -> None:
+        self._g, self.idx, self.id_ = graph, idx, id_
+
+    @property
+    def x(self) -> torch.Tensor:
+        return self._g.X[self.idx]
+
+    @property
+    def z(self) -> torch.Tensor:
+        return self._g._host_Z()[self.idx]
+
+    @z.setter
+    def z(self, value: torch.Tensor) -> None:
+        self._g._set_row(self.idx, value)
+
+    @property
+    def outgoing_indices(self) -> List[int]:
+        return self._g._raw_neighbours(self.idx, out=True)
+
+    @property
+    def incoming_indices(self) -> List[int]:
+        return self._g._raw_neighbours(self.idx, out=False)
+
+
+class Edge(object):
+    """reference graph.py:24-30."""
+    __slots__ = ("src", "dst")
+
+    def __init__(self, src: Vertex, dst: Vertex) -> None:
+        self.src, self.dst = src, dst
+
+
+class _LazySeq:
+    """len()/index/iterate without materialising one Python object per element."""
+
+    def __init__(self, n: int, make):
+        self._n, self._make = n, make
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._make(j) for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        return self._make(i)
+
+    def __iter__(self):
+        return (self._make(i) for i in range(self._n))
+
+
+class Graph(torch.utils.data.Dataset):
+    def __init__(self, data_root: Path, embedding_dim: int = 128) -> None:
+        super().__init__()
+        data_root = Path(data_root)
+        self.d = embedding_dim
+        self.vertex_ids = read_vertex_ids(data_root)
+
+        # Content embeddings C: C.npy -> C.pt -> N(0,1) (graph.py:50-58).  dtype is preserved.
+        try:
+            self.X = torch.from_numpy(np.load(data_root.joinpath("C.npy")))
+        except FileNotFoundError:
+            try:
+                self.X = torch.load(data_root.joinpath("C.pt"))
+            except FileNotFoundError:
+                self.X = torch.normal(0, 1, [len(self.vertex_ids), self.d])
+        if self.X.dim() != 2 or self.X.shape[0] != len(self.vertex_ids):
+            raise ValueError(f"content embeddings have shape {tuple(self.X.shape)}, expected "
+                             f"[{len(self.vertex_ids)}, d]")
+
+        self._raw_src, self._raw_dst = read_edge_indices(data_root, self.vertex_ids)
+        self.csr = csr_from_edges(len(self.vertex_ids), self._raw_src, self._raw_dst)
+
+        self.V = _LazySeq(len(self.vertex_ids), lambda i: Vertex(self, i, self.vertex_ids[i]))
+        self.E = _LazySeq(len(self._raw_src),
+                          lambda k: Edge(self.V[int(self._raw_src[k])], self.V[int(self._raw_dst[k])]))
+        self.dispense_pair = False
+
+        self._Z_host: Optional[torch.Tensor] = None   # authoritative only while no engine exists / when dirty
+        self._dirty = False
+        self._engine = None
+        self._raw_order = {}
+
+    # ---- Dataset protocol ---------------------------------------------------------------
+    def __len__(self):
+        return len(self.vertex_ids)
+
+    def __getitem__(self, idx):
+        if self.dispense_pair:
+            raise NotImplementedError("negative-pair sampling serves only the reference's trainable-similarity "
+                                      "path (IterativeEmbedder), which is outside this package's scope")
+        return idx
+
+    # ---- adjacency (graph.py:104-116) -----------------------------------------------------
+    def _edge_index(self) -> torch.Tensor:
+        rows = np.repeat(np.arange(len(self), dtype=np.int64), self.csr.outdeg())
+        return torch.from_numpy(np.stack([rows, self.csr.colidx.astype(np.int64)]))
+
+    @property
+    def A(self) -> torch.Tensor:
+        idx = self._edge_index()
+        return torch.sparse_coo_tensor(idx, torch.ones(idx.shape[1]), size=(len(self), len(self)),
+                                       is_coalesced=True)
+
+    def get_nbrs(self, idx: int) -> torch.LongTensor:
+        a, b = self.csr.rowptr[idx], self.csr.rowptr[idx + 1]
+        return torch.from_numpy(self.csr.colidx[a:b].astype(np.int64))
+
+    def _raw_neighbours(self, idx: int, out: bool) -> List[int]:
+        key, val = (self._raw_src, self._raw_dst) if out else (self._raw_dst, self._raw_src)
+        if out not in self._raw_order:
+            order = np.argsort(key, kind="stable")
+            ptr = np.zeros(len(self) + 1, dtype=np.int64)
+            np.cumsum(np.bincount(key, minlength=len(self)), out=ptr[1:])
+            self._raw_order[out] = (order, ptr)
+        order, ptr = self._raw_order[out]
+        return val[order[ptr[idx]:ptr[idx + 1]]].tolist()
+
+    # ---- GPU engine ---------------------------------------------------------------------
+    def engine(self, device=None, cosine_mode: str = "reference", **engine_kwargs):
+        """The SweepEngine holding this graph's state in HBM (created on first use).
+
+        Raises ``ClaneHipError`` when no GPU / HIP library is available: there is no CPU path.
+        """
+        from .engine import SweepEngine
+        if self._engine is None:
+            dev = _hip.require_gpu(device)
+            pg = engine_kwargs.pop("process_group", None)
+            if pg is None:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    pg = dist.group.WORLD
+            with torch.cuda.device(dev):
+                self._engine = SweepEngine(self.csr, self.X, dev, cosine_mode=cosine_mode, process_group=pg,
+                                           **engine_kwargs)
+        eng = self._engine
+        if self._dirty:
+            eng.set_Z(self._Z_host)
+            self._dirty = False
+        if eng.cosine_mode != cosine_mode:
+            eng.cosine_mode, eng.P_valid = cosine_mode, False
+        return eng
+
+    def _attach_engine(self, engine) -> None:
+        """Use an already-built engine (tests inject one with substitute kernels)."""
+        self._engine = engine
+        if self._dirty:
+            engine.set_Z(self._Z_host)
+            self._dirty = False
+
+    # ---- embeddings (graph.py:130-138) ----------------------------------------------------
+    def _host_Z(self) -> torch.Tensor:
+        if self._engine is not None and not self._dirty:
+            return self._engine.get_Z()
+        if self._Z_host is None:
+            self._Z_host = self.X.clone()      # Vertex.z starts as x (graph.py:19)
+        return self._Z_host
+
+    @property
+    def Z(self) -> torch.Tensor:
+        """Fresh [V, d] tensor; callers may mutate it freely (like the reference's torch.stack)."""
+        z = self._host_Z()
+        return z if (self._engine is not None and not self._dirty) else z.clone()
+
+    def set_Z(self, Z: torch.Tensor) -> None:
+        if tuple(Z.shape) != tuple(self.X.shape):
+            raise ValueError(f"set_Z: expected {tuple(self.X.shape)}, got {tuple(Z.shape)}")
+        self._Z_host = Z.detach().to("cpu", self.X.dtype).clone()
+        self._dirty = True
+
+    def _set_row(self, idx: int, value: torch.Tensor) -> None:
+        z = self._host_Z().clone() if not self._dirty else self._Z_host
+        z[idx] = value.detach().to("cpu", z.dtype)
+        self._Z_host, self._dirty = z, True
+
+    # ---- P (graph.py:118-128) -------------------------------------------------------------
+    def build_P(self, similarity) -> torch.Tensor:
+        """Row-softmax of per-edge similarity as a coalesced sparse [V, V] tensor (CPU).
+
+        ``CosineSimilarity`` takes the fused HIP path (K0 + K1 + K2, nothing materialised).
+        Any other callable follows the plugin protocol literally: it is called ONCE with the
+        gathered ``Z[src]``, ``Z[dst]`` batches (GPU tensors) and its scores are normalised by
+        the HIP segmented softmax.
+        """
+        from .similarity import CosineSimilarity
+        if isinstance(similarity, CosineSimilarity):
+            eng = self.engine(cosine_mode=similarity.mode)
+            eng.build_P()
+        else:
+            eng = self.engine()
+            if eng.world > 1:
+                raise NotImplementedError("custom similarity callables are supported on a single GPU only")
+            rows = torch.repeat_interleave(torch.arange(eng.part.n_local, device=eng.device),
+                                           eng.rowptr[1:] - eng.rowptr[:-1])
+            Zd = eng.Zcur[:, :eng.d]
+            src_Z = Zd[torch.from_numpy(eng.part.local_positions()).to(eng.device)[rows]]
+            dst_Z = Zd[eng.colidx.long()]
+            scores = similarity(src_Z, dst_Z).detach().to(eng.acc_dtype).reshape(-1)
+            eng.P[:eng.E_loc].copy_(scores)
+            eng.k.segment_softmax(eng.rowptr, eng.part.n_local, eng.P)
+            eng.P_valid = True
+        values = self._gather_P(eng)
+        return torch.sparse_coo_tensor(self._edge_index(), values, size=(len(self), len(self)), is_coalesced=True)
+
+    def _gather_P(self, eng) -> torch.Tensor:
+        """P values of every rank, put back into the global (row, col)-sorted edge order."""
+        out = torch.empty(self.csr.num_edges, dtype=eng.acc_dtype)
+        local = (torch.from_numpy(eng.local.edge_origin), eng.P[:eng.E_loc].to("cpu"))
+        pieces = [local]
+        if eng.world > 1:
+            import torch.distributed as dist
+            pieces = [None] * eng.world
+            dist.all_gather_object(pieces, local, group=eng.pg)
+        for origin, vals in pieces:
+            out[origin] = vals
+        return out

@@ -1,0 +1,153 @@
+/*
+ * clane_hip.h -- C ABI of libclane_hip.so: CLANE's iterative embedding loop on MI355X (gfx950).
+ *
+ * The reference (helloybz/CLANE @ v2) is pure Python on PyTorch-CPU and has no FFI.  This
+ * header is the boundary a maintainer would bind (ctypes) underneath
+ * the reference's own Python surface.  Each entry point names the reference code it
+ * replaces (paths are relative to the reference checkout).
+ *
+ * Conventions
+ *  - Every function returns 0 on success, <0 on error (CLANE_ERR_*); the text of the last
+ *    error on the calling thread is clane_last_error().
+ *  - All array arguments are DEVICE pointers to caller-owned memory.  The library never
+ *    allocates, frees or retains them, keeps no global mutable state, and never
+ *    synchronises: work is enqueued on `stream` (a hipStream_t, NULL = default stream).
+ *  - Matrices are row-major with a leading dimension in ELEMENTS (ldz, ldx, ldo >= d).
+ *    FAST PATH: when every matrix base pointer is 16-byte aligned and every leading
+ *    dimension is a multiple of 16/sizeof(T), rows are moved with 16-byte accesses and the
+ *    columns [d, roundup(d, 16/sizeof(T))) of each row are read AND written: they must be
+ *    zero on entry (they stay zero).  Otherwise a 1-element-per-lane path is taken.
+ *  - CSR: rowptr int64 [nrows+1], offsets into colidx / P; colidx int32, GLOBAL column ids
+ *    (rows of the full Z), sorted and unique within a row (reference: graph.py:104-110,
+ *    sparse_coo_tensor(...).coalesce(): row = source, col = destination).
+ *  - `row0` is the global row id of local row 0 (row-partitioned multi-GPU runs hand each
+ *    rank a contiguous block of rows; on one GPU row0 = 0).
+ *  - Suffix _f32: T = float,  accumulate float,  P/scores float.
+ *    Suffix _f64: T = double, accumulate double, P/scores double (C.npy may be float64 and
+ *                 the reference keeps that dtype: graph.py:51).
+ *    Suffix _bf16: T = bf16 storage for Z/X, accumulate float, P/scores float.
+ *  - Reductions that feed control flow (the L1 delta) are deterministic: fixed grid,
+ *    fixed-order partials, no float atomics.
+ */
+#ifndef CLANE_HIP_H_
+#define CLANE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLANE_ABI_VERSION 1
+
+#define CLANE_OK 0
+#define CLANE_ERR_INVALID_ARGUMENT (-1)
+#define CLANE_ERR_LAUNCH (-2)
+
+/* score modes of clane_edge_score_* */
+#define CLANE_SCORE_REFERENCE 0 /* dot / (||Z[src_all]||_F * ||Z[dst_all]||_F)  -- what similarity.py:37 computes */
+#define CLANE_SCORE_PER_EDGE 1  /* dot / (||z_src|| * ||z_dst||)                 -- what its docstring describes  */
+#define CLANE_SCORE_RAW_DOT 2   /* dot                                           -- stage test                     */
+
+int clane_abi_version(void);
+const char *clane_last_error(void);
+
+/* Doubles written by clane_spmm_update_*(nrows) plus clane_spmm_update_long_*(n_long). */
+int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long);
+/* Doubles of scratch needed by clane_degree_weighted_sums_* / clane_pair_cosine_*. */
+int64_t clane_reduce_ws_len(void);
+
+/* ---- K0: sq[v] = sum_k Z[v,k]^2.  Replaces the two `pow(2).sum()` of similarity.py:37
+ * (together with clane_degree_weighted_sums_*). */
+int clane_row_sqnorm_f32(const float *Z, int64_t nrows, int32_t d, int64_t ldz, float *sq, void *stream);
+int clane_row_sqnorm_f64(const double *Z, int64_t nrows, int32_t d, int64_t ldz, double *sq, void *stream);
+int clane_row_sqnorm_bf16(const uint16_t *Z, int64_t nrows, int32_t d, int64_t ldz, float *sq, void *stream);
+
+/* out2[0] = sum_v outdeg_v*sq_v, out2[1] = sum_v indeg_v*sq_v over the local rows, in double
+ * (= ||Z[src_all]||_F^2 and ||Z[dst_all]||_F^2 of similarity.py:37 for the edges built at
+ * graph.py:119-120).  outdeg_v = rowptr[v+1]-rowptr[v]; indeg is caller-provided [nrows].
+ * ws: clane_reduce_ws_len() doubles.  Multi-GPU: all-reduce out2 (sum) afterwards. */
+int clane_degree_weighted_sums_f32(const float *sq, const int64_t *rowptr, const int32_t *indeg, int64_t nrows,
+                                   double *ws, double *out2, void *stream);
+int clane_degree_weighted_sums_f64(const double *sq, const int64_t *rowptr, const int32_t *indeg, int64_t nrows,
+                                   double *ws, double *out2, void *stream);
+
+/* ---- K1: per-edge similarity score in CSR order.  Replaces the gather + similarity call
+ * of graph.py:119-121 and CosineSimilarity.__call__ (similarity.py:26-37) without
+ * materialising Z[edges].  Source row of local row i is Z[row0+i].
+ *   mode REFERENCE: sums2 = the (all-reduced) pair from clane_degree_weighted_sums_*; sq unused.
+ *   mode PER_EDGE : sq = squared norms of ALL rows of Z; sums2 unused.
+ *   mode RAW_DOT  : both unused. */
+int clane_edge_score_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const float *Z,
+                         int64_t ldz, int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
+                         void *stream);
+int clane_edge_score_f64(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const double *Z,
+                         int64_t ldz, int32_t d, int32_t mode, const double *sums2, const double *sq, double *scores,
+                         void *stream);
+int clane_edge_score_bf16(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
+                          const uint16_t *Z, int64_t ldz, int32_t d, int32_t mode, const double *sums2,
+                          const float *sq, float *scores, void *stream);
+
+/* ---- K2: in-place softmax of vals within each CSR row.  Replaces the per-row boolean-mask
+ * loop of graph.py:122-123.  Empty rows are skipped. */
+int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, void *stream);
+int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals, void *stream);
+
+/* ---- K3: one Jacobi sweep over the local rows, fused with the L1 delta.  Replaces the
+ * per-vertex loop embedder.py:84-92 and the reduction embedder.py:94:
+ *     Z_new[i,:] = X[i,:] + gamma * sum_e P[e] * Z_old[colidx[e],:]     rowptr[i] <= e < rowptr[i+1]
+ *     Z_new[i,:] = Z_old[row0+i,:]                                       if the row has no out-edge (embedder.py:88-89)
+ *     delta_partials[b] = partial sums of |Z_new[i,:] - Z_old[row0+i,:]| (fixed order; reduce with clane_reduce_partials)
+ * Z_new must not alias Z_old.
+ *  clane_spmm_update_*      : one wave per row over a fixed grid; rows with more than `long_threshold`
+ *                             edges (0 = never) are skipped.  Writes clane_spmm_partials_len(nrows, 0) doubles.
+ *  clane_spmm_update_long_* : the skipped rows, one 16-wave workgroup per row; `long_rows` holds their
+ *                             local row ids (the caller builds the list once per graph).  Writes n_long doubles.
+ * The two touch disjoint rows of Z_new and may run on different streams. */
+int clane_spmm_update_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
+                          const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
+                          int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials, void *stream);
+int clane_spmm_update_f64(const int64_t *rowptr, const int32_t *colidx, const double *P, int64_t nrows, int64_t row0,
+                          const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma, double *Z_new,
+                          int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials, void *stream);
+int clane_spmm_update_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
+                           const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
+                           uint16_t *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials,
+                           void *stream);
+int clane_spmm_update_long_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, const int32_t *long_rows,
+                               int64_t n_long, int64_t row0, const float *Z_old, int64_t ldz, const float *X,
+                               int64_t ldx, float gamma, float *Z_new, int64_t ldo, int32_t d, double *delta_partials,
+                               void *stream);
+int clane_spmm_update_long_f64(const int64_t *rowptr, const int32_t *colidx, const double *P,
+                               const int32_t *long_rows, int64_t n_long, int64_t row0, const double *Z_old,
+                               int64_t ldz, const double *X, int64_t ldx, double gamma, double *Z_new, int64_t ldo,
+                               int32_t d, double *delta_partials, void *stream);
+int clane_spmm_update_long_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P,
+                                const int32_t *long_rows, int64_t n_long, int64_t row0, const uint16_t *Z_old,
+                                int64_t ldz, const uint16_t *X, int64_t ldx, float gamma, uint16_t *Z_new,
+                                int64_t ldo, int32_t d, double *delta_partials, void *stream);
+
+/* out[0] = sum of partials[0..n) in a fixed order (one workgroup).  Finishes embedder.py:94 / :60. */
+int clane_reduce_partials(const double *partials, int64_t n, double *out, void *stream);
+
+/* sum|A - B| over an [nrows, d] matrix pair -> out[0] (outer-loop delta, embedder.py:60).
+ * ws: clane_reduce_ws_len() doubles. */
+int clane_l1_distance_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t nrows, int32_t d,
+                          double *ws, double *out, void *stream);
+int clane_l1_distance_f64(const double *A, int64_t lda, const double *B, int64_t ldb, int64_t nrows, int32_t d,
+                          double *ws, double *out, void *stream);
+int clane_l1_distance_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, int64_t nrows, int32_t d,
+                           double *ws, double *out, void *stream);
+
+/* ---- CosineSimilarity.__call__ on explicit pairs (similarity.py:26-37):
+ *   out[i] = dot(A[i,:], B[i,:]) / (||A||_F * ||B||_F)      -- global denominators.
+ * ws: clane_reduce_ws_len() doubles. */
+int clane_pair_cosine_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t nrows, int32_t d,
+                          float *out, double *ws, void *stream);
+int clane_pair_cosine_f64(const double *A, int64_t lda, const double *B, int64_t ldb, int64_t nrows, int32_t d,
+                          double *out, double *ws, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLANE_HIP_H_ */

@@ -1,0 +1,90 @@
+"""TEST DOUBLE for ``clane_amd._hip.HipKernels`` backed by the CPU oracle.
+
+Lives under tests/ on purpose: it lets the CPU suite drive the *host* logic of clane_amd
+(SweepEngine launch sequence, row partition, all-gather layout, Embedder control flow, CLI)
+without a GPU.  It is never importable from the product package, and the product never
+substitutes it: ``SweepEngine`` only gets it when a test passes it in explicitly.
+"""
+import numpy as np
+import torch
+
+from oracle import clane_oracle as O
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class OracleKernels:
+    def spmm_partials_len(self, nrows, n_long):
+        return 3 + n_long
+
+    def reduce_ws_len(self):
+        return 8
+
+    def row_sqnorm(self, Z, d, sq):
+        sq.copy_(Z[:, :d].to(sq.dtype).pow(2).sum(1))
+
+    def degree_weighted_sums(self, sq, rowptr, indeg, nrows, ws, out2):
+        outdeg = (rowptr[1:nrows + 1] - rowptr[:nrows]).double()
+        out2[0] = (outdeg * sq[:nrows].double()).sum()
+        out2[1] = (indeg[:nrows].double() * sq[:nrows].double()).sum()
+
+    def edge_score(self, rowptr, colidx, nrows, row0, Z, d, mode, sums2, sq, scores):
+        rp = _np(rowptr[:nrows + 1])
+        if rp[-1] == rp[0]:
+            return
+        rows = torch.from_numpy(np.repeat(np.arange(nrows), np.diff(rp))) + row0
+        cols = colidx[rp[0]:rp[-1]].long()
+        Zf = Z[:, :d].to(scores.dtype)
+        dots = (Zf[rows] * Zf[cols]).sum(1)
+        if mode == 0:
+            dots = dots / (sums2[0].to(scores.dtype).sqrt() * sums2[1].to(scores.dtype).sqrt())
+        elif mode == 1:
+            dots = dots / (sq[rows].sqrt() * sq[cols].sqrt())
+        scores[rp[0]:rp[-1]] = dots
+
+    def segment_softmax(self, rowptr, nrows, vals):
+        rp = _np(rowptr[:nrows + 1])
+        if rp[-1] == rp[0]:
+            return
+        seg = vals[rp[0]:rp[-1]]
+        seg.copy_(O.segment_softmax(rp - rp[0], seg.clone()))
+
+    def _spmm_rows(self, rowptr, colidx, P, rows_sel, row0, Z_old, X, gamma, Z_new, d):
+        rp = _np(rowptr)
+        acc = P.dtype
+        total = 0.0
+        for r in rows_sel:
+            a, b = int(rp[r]), int(rp[r + 1])
+            own = Z_old[row0 + r, :d]
+            if b > a:
+                agg = (P[a:b].unsqueeze(1) * Z_old[colidx[a:b].long(), :d].to(acc)).sum(0)
+                new = (X[r, :d].to(acc) + gamma * agg).to(Z_new.dtype)
+            else:
+                new = own.clone()
+            Z_new[r, :d] = new
+            total += float((new.to(acc) - own.to(acc)).abs().sum())
+        return total
+
+    def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials):
+        rp = _np(rowptr[:nrows + 1])
+        deg = np.diff(rp)
+        sel = [r for r in range(nrows) if not (long_threshold > 0 and deg[r] > long_threshold)]
+        n = self.spmm_partials_len(nrows, 0)
+        partials[:n] = 0
+        partials[0] = self._spmm_rows(rowptr, colidx, P, sel, row0, Z_old, X, gamma, Z_new, d)
+
+    def spmm_update_long(self, rowptr, colidx, P, long_rows, row0, Z_old, X, gamma, Z_new, d, partials):
+        for i, r in enumerate(long_rows.tolist()):
+            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d)
+
+    def reduce_partials(self, partials, n, out):
+        out[0] = partials[:n].sum()
+
+    def l1_distance(self, A, B, d, ws, out):
+        acc = torch.float64 if A.dtype == torch.float64 else torch.float32
+        out[0] = (A[:, :d].to(acc) - B[:, :d].to(acc)).abs().sum().double()
+
+    def pair_cosine(self, A, B, d, out, ws):
+        out.copy_(O.cosine_similarity(A[:, :d], B[:, :d]))

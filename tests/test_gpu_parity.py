@@ -1,0 +1,373 @@
+"""GPU parity: the HIP path, called through the C ABI (clane_amd._hip.HipKernels), against the CPU
+oracle on the same seeded inputs and against the committed golden vectors from the reference.
+
+Tolerances (north_star: embeddings within 1e-4 relative L2 of the CPU reference):
+  * fp32 stage outputs  rel-L2 <= 2e-6  (only summation order differs)
+  * fp64 stage outputs  rel-L2 <= 1e-13
+  * bf16 storage        rel-L2 <= 8e-3  (2^-8 rounding of the stored values)
+  * final embeddings    rel-L2 <= 1e-5 fp32 (bar is 1e-4)
+"""
+import contextlib
+import io
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from clane_amd import _hip
+from clane_amd.embedder import Embedder
+from clane_amd.engine import SweepEngine
+from clane_amd.graph import Graph
+from clane_amd.partition import HostCSR
+from clane_amd.similarity import CosineSimilarity
+from clane_amd import synth
+from oracle import clane_oracle as O
+
+from .conftest import load_golden, write_data_root
+from .test_host_logic import KARATE_LIKE, graph_from_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-6, torch.float64: 1e-13, torch.bfloat16: 8e-3}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return _hip.require_gpu("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def k():
+    return _hip.kernels()
+
+
+def ragged_csr(V, seed, max_deg=40, hubs=(), empty_frac=0.2):
+    """Random CSR with empty rows, ragged rows and a few very long rows (hubs: list of degrees)."""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, max_deg + 1, size=V)
+    deg[rng.random(V) < empty_frac] = 0
+    for i, h in enumerate(hubs):
+        deg[(7 * i + 3) % V] = min(h, V)
+    rowptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    colidx = np.concatenate([np.sort(rng.choice(V, size=dg, replace=False)) for dg in deg] + [np.empty(0, int)])
+    return HostCSR(V, rowptr, colidx.astype(np.int32))
+
+
+def padded(t, dtype, dev, pad_to=None):
+    """[V, d] CPU -> [V, ld] device tensor with zero pad columns (the ABI's fast-path contract)."""
+    V, d = t.shape
+    ld = -(-d // _hip.VEC_ELEMS[dtype]) * _hip.VEC_ELEMS[dtype] if pad_to is None else pad_to
+    out = torch.zeros(V, ld, dtype=dtype, device=dev)
+    out[:, :d] = t.to(dtype)
+    return out
+
+
+def rel(a, b):
+    return O.rel_l2(a.detach().cpu().double(), b.detach().cpu().double())
+
+
+# ---- reference tests/test_similarity.py re-expressed on the HIP path ------------------------------
+def test_cosine_known_answers(dev):
+    cs = CosineSimilarity()
+    g = load_golden("g1_cosine.npz")
+    v = torch.tensor([1.0, 2.0, 3.0])
+    assert cs(v, v).item() == pytest.approx(1.0, abs=1e-4)
+    assert cs(torch.tensor([0.0, 1.0]), torch.tensor([1.0, 0.0])).item() == pytest.approx(0.0, abs=1e-4)
+    assert cs(v, -v).item() == pytest.approx(-1.0, abs=1e-4)
+    a, b = torch.from_numpy(g["a4"]), torch.from_numpy(g["b4"])
+    out = cs(a, b)
+    assert out.shape == torch.Size([4]) and out.device == a.device
+    np.testing.assert_allclose(out.numpy(), g["out4"], rtol=1e-6)
+    assert torch.allclose(cs(a[0], b[0]), cs(b[0], a[0]))
+    out64 = cs(torch.from_numpy(g["a64"]), torch.from_numpy(g["b64"]))
+    assert out64.dtype == torch.float64
+    np.testing.assert_allclose(out64.numpy(), g["out64"], rtol=1e-14)
+    assert torch.isnan(cs(torch.zeros(3), torch.ones(3))).all()             # D = 0 -> nan, like the reference
+    big_a, big_b = torch.rand(5000, 1433), torch.rand(5000, 1433)
+    np.testing.assert_allclose(cs(big_a, big_b).numpy(), O.cosine_similarity(big_a, big_b).numpy(), rtol=2e-5)
+    assert cs(a.to(dev), b.to(dev)).is_cuda
+
+
+# ---- stage kernels ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+@pytest.mark.parametrize("d,pad", [(2, True), (16, True), (100, True), (128, True), (256, True), (1433, True),
+                                   (1433, False), (3, False), (70, False)])
+def test_row_sqnorm(dev, k, dtype, d, pad):
+    V = 777
+    Z = synth.gaussian_X(V, d, seed=d).to(dtype)
+    Zd = padded(Z, dtype, dev) if pad else Z.to(dev).contiguous()
+    sq = torch.empty(V, dtype=_hip.acc_dtype(dtype), device=dev)
+    k.row_sqnorm(Zd, d, sq)
+    ref = Z.double().pow(2).sum(1)                    # Z is already rounded to the storage dtype
+    assert rel(sq, ref) < (1e-13 if dtype == torch.float64 else 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+@pytest.mark.parametrize("d,pad", [(2, True), (16, True), (128, True), (256, True), (300, True), (1433, True),
+                                   (37, False)])
+def test_edge_score_and_softmax_stages(dev, k, dtype, d, pad):
+    csr = ragged_csr(500, seed=d, hubs=(64, 65, 130, 400))
+    V = csr.num_vertices
+    acc = _hip.acc_dtype(dtype)
+    Zc = synth.gaussian_X(V, d, seed=3).to(dtype)
+    Zf = Zc.to(acc)                                                    # what the kernel sees after widening
+    Zd = padded(Zc, dtype, dev) if pad else Zc.to(dev).contiguous()
+    rowptr, colidx = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    scores = torch.full((csr.num_edges,), float("nan"), dtype=acc, device=dev)
+    tol = 5e-6 if dtype == torch.bfloat16 else TOL[dtype]
+
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, scores)
+    dots = O.edge_dots(csr.rowptr, csr.colidx, Zf.double())
+    assert rel(scores, dots) < tol
+
+    # reference mode: denominators from K0 + degree-weighted reduction
+    sq = torch.empty(V, dtype=acc, device=dev)
+    k.row_sqnorm(Zd, d, sq)
+    ws = torch.zeros(k.reduce_ws_len(), dtype=torch.float64, device=dev)
+    sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    indeg = torch.from_numpy(csr.indeg()).to(dev)
+    k.degree_weighted_sums(sq, rowptr, indeg, V, ws, sums2)
+    D = O.global_denominator(csr.rowptr, csr.colidx, Zf.double())
+    assert float(sums2[0].sqrt() * sums2[1].sqrt()) == pytest.approx(D, rel=1e-6)
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_REFERENCE, sums2, None, scores)
+    assert rel(scores, dots / D) < max(tol, 3e-7)
+    k.segment_softmax(rowptr, V, scores)
+    P_ref = O.build_P_values(csr.rowptr, csr.colidx, Zf.double())
+    assert rel(scores, P_ref) < max(tol, 3e-7)
+
+    # per-edge (true cosine) mode
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_PER_EDGE, None, sq, scores)
+    k.segment_softmax(rowptr, V, scores)
+    assert rel(scores, O.build_P_values(csr.rowptr, csr.colidx, Zf.double(), mode="per_edge")) < max(tol, 1e-6)
+
+
+def test_segment_softmax_edge_cases(dev, k):
+    deg = np.array([0, 1, 2, 63, 64, 65, 0, 0, 5000, 1, 129], dtype=np.int64)
+    rowptr = np.zeros(len(deg) + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    for dtype in (torch.float32, torch.float64):
+        vals = torch.randn(int(rowptr[-1]), dtype=dtype, generator=torch.Generator().manual_seed(1)) * 30
+        vals[3] = 88.0                                         # large spread: max-subtraction matters
+        ref = O.segment_softmax(rowptr, vals.double())
+        out = vals.to(dev)
+        k.segment_softmax(torch.from_numpy(rowptr).to(dev), len(deg), out)
+        assert rel(out, ref) < (1e-6 if dtype == torch.float32 else 1e-14)
+        sums = torch.zeros(len(deg), dtype=torch.float64).index_add_(
+            0, torch.from_numpy(np.repeat(np.arange(len(deg)), deg)), out.cpu().double())
+        assert torch.allclose(sums[deg > 0], torch.ones(int((deg > 0).sum()), dtype=torch.float64), atol=1e-5)
+
+
+def run_sweep(k, rowptr, colidx, P, V, Zo, X, gamma, Zn, d, long_threshold, long_rows, partials):
+    k.spmm_update(rowptr, colidx, P, V, 0, Zo, X, gamma, Zn, d, long_threshold, partials)
+    if long_rows is not None and long_rows.numel():
+        k.spmm_update_long(rowptr, colidx, P, long_rows, 0, Zo, X, gamma, Zn, d,
+                           partials[k.spmm_partials_len(V, 0):])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+@pytest.mark.parametrize("d,pad", [(2, True), (16, True), (64, True), (128, True), (256, True), (300, True),
+                                   (1433, True), (1433, False), (5, False)])
+@pytest.mark.parametrize("long_threshold", [0, 48])
+def test_spmm_update_vs_oracle(dev, k, dtype, d, pad, long_threshold):
+    csr = ragged_csr(600, seed=d + 1, hubs=(64, 65, 200, 600, 1))
+    V = csr.num_vertices
+    acc = _hip.acc_dtype(dtype)
+    gamma = 0.76
+    X = synth.gaussian_X(V, d, seed=4).to(dtype)
+    Zold = (synth.gaussian_X(V, d, seed=5) * 0.5).to(dtype)
+    P = O.build_P_values(csr.rowptr, csr.colidx, synth.gaussian_X(V, 8, seed=6).double()).to(acc)
+    mk = (lambda t: padded(t, dtype, dev)) if pad else (lambda t: t.to(dev).contiguous())
+    Xd, Zo = mk(X), mk(Zold)
+    Zn = torch.full_like(Zo, float("nan"))
+    if pad:
+        Zn[:, d:] = 0
+    rowptr, colidx = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    deg = np.diff(csr.rowptr)
+    long_rows = torch.from_numpy(np.nonzero(deg > long_threshold)[0].astype(np.int32)).to(dev) \
+        if long_threshold else None
+    n_long = 0 if long_rows is None else long_rows.numel()
+    partials = torch.full((k.spmm_partials_len(V, n_long),), float("nan"), dtype=torch.float64, device=dev)
+    out = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    run_sweep(k, rowptr, colidx, P.to(dev), V, Zo, Xd, gamma, Zn, d, long_threshold, long_rows, partials)
+    k.reduce_partials(partials, partials.numel(), out)
+    Z_ref, _ = O.sweep(csr.rowptr, csr.colidx, P.double(), X.double(), Zold.double(), gamma)
+    got = Zn[:, :d].cpu()
+    assert not torch.isnan(got.float()).any()
+    assert rel(got, Z_ref) < TOL[dtype]
+    sink = torch.from_numpy(deg == 0)
+    assert torch.equal(got[sink], Zold[sink])                              # embedder.py:88-89: untouched rows
+    if pad:
+        assert float(Zn[:, d:].abs().sum()) == 0.0                         # pad columns stay zero
+    delta_ref = (got.double() - Zold.double()).abs().sum()
+    assert float(out) == pytest.approx(float(delta_ref), rel=1e-6 if dtype != torch.float64 else 1e-12)
+
+    # bitwise reproducible: fixed-order partials, no atomics
+    Zn2 = torch.zeros_like(Zn)
+    partials2 = torch.zeros_like(partials)
+    run_sweep(k, rowptr, colidx, P.to(dev), V, Zo, Xd, gamma, Zn2, d, long_threshold, long_rows, partials2)
+    assert torch.equal(Zn2[:, :d], Zn[:, :d]) and torch.equal(partials, partials2)
+
+
+def test_spmm_row_block_with_row0_offset(dev, k):
+    """A rank's row block: local rowptr/X/Z_new, global columns, row0 != 0."""
+    csr = ragged_csr(400, seed=9, hubs=(300,))
+    V, d, gamma, r0, n = 400, 128, 0.5, 150, 200
+    X, Zold = synth.gaussian_X(V, d, seed=1), synth.gaussian_X(V, d, seed=2)
+    P = O.build_P_values(csr.rowptr, csr.colidx, X.double()).float()
+    Z_ref, _ = O.sweep(csr.rowptr, csr.colidx, P.double(), X.double(), Zold.double(), gamma)
+    rp = torch.from_numpy(csr.rowptr).to(dev)
+    Zn = torch.zeros(n, d, device=dev)
+    partials = torch.zeros(k.spmm_partials_len(n, 0), dtype=torch.float64, device=dev)
+    k.spmm_update(rp[r0:], torch.from_numpy(csr.colidx).to(dev), P.to(dev), n, r0, Zold.to(dev),
+                  X[r0:r0 + n].to(dev), gamma, Zn, d, 0, partials)
+    assert rel(Zn, Z_ref[r0:r0 + n]) < 2e-6
+    with pytest.raises(_hip.ClaneHipError, match="alias"):
+        Zo = Zold.to(dev)
+        k.spmm_update(rp, torch.from_numpy(csr.colidx).to(dev), P.to(dev), V, 0, Zo, X.to(dev), gamma, Zo, d, 0,
+                      torch.zeros(k.spmm_partials_len(V, 0), dtype=torch.float64, device=dev))
+
+
+def test_l1_distance(dev, k):
+    for dtype, d in [(torch.float32, 256), (torch.float64, 7), (torch.bfloat16, 128), (torch.float32, 1433)]:
+        A, B = synth.gaussian_X(321, d, seed=1).to(dtype), synth.gaussian_X(321, d, seed=2).to(dtype)
+        ws = torch.zeros(k.reduce_ws_len(), dtype=torch.float64, device=dev)
+        out = torch.zeros(1, dtype=torch.float64, device=dev)
+        k.l1_distance(A.to(dev), B.to(dev), d, ws, out)
+        assert float(out) == pytest.approx(float((A.double() - B.double()).abs().sum()), rel=1e-6)
+
+
+# ---- end to end through the reference surface, against the goldens ------------------------------------
+@pytest.mark.parametrize("name", KARATE_LIKE)
+def test_graph_build_P_matches_reference(tmp_path, name):
+    gold, g = graph_from_golden(tmp_path, name)
+    P = g.build_P(CosineSimilarity())
+    assert P.is_coalesced() and P.dtype == g.X.dtype
+    np.testing.assert_array_equal(P.indices().numpy(), gold["A_indices"])
+    np.testing.assert_allclose(P.values().numpy(), gold["P0_values"], rtol=1e-5, atol=1e-7)
+    dense = P.to_dense()
+    assert dense.shape == (len(g), len(g))
+    assert dense.sum(1).max().item() == pytest.approx(1, abs=1e-3)          # reference test_graph.py:47-48
+    if (np.diff(g.csr.rowptr) == 0).any():
+        assert dense.sum(1).min().item() == pytest.approx(0, abs=1e-3)
+
+
+@pytest.mark.parametrize("name", KARATE_LIKE)
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_embedder_iterate_matches_reference(tmp_path, name, chunks):
+    gold, g = graph_from_golden(tmp_path, name)
+    g.engine(chunks=chunks, shuffle=chunks > 1)
+    emb = Embedder(g, CosineSimilarity(), torch.device("cpu"), gamma=float(gold["gamma"]),
+                   tolerence=int(gold["tolerence"]), save_history=True, verbose=False)
+    emb.iterate()
+    Z = g.Z
+    assert Z.dtype == g.X.dtype and not Z.is_cuda
+    tol = 1e-12 if g.X.dtype == torch.float64 else 1e-5
+    assert O.rel_l2(Z, torch.from_numpy(gold["Z_final"])) < tol
+    assert O.rel_l2(emb.history["Z"][0][0], torch.from_numpy(gold["Z_sweep1"])) < tol
+    assert O.rel_l2(emb.history["Z"][0][-1], torch.from_numpy(gold["Z_prop1"])) < tol
+    assert (g.Z - g.X).abs().sum() != 0                                     # reference test_embedder.py:29
+    sink = np.diff(g.csr.rowptr) == 0
+    np.testing.assert_array_equal(Z.numpy()[sink], gold["X"][sink])
+
+
+def test_corashape_literal_sweep_golden(dev):
+    g = load_golden("g8_corashape.npz")
+    V, d = int(g["V"]), int(g["d"])
+    X = torch.zeros(V, d)
+    X[torch.from_numpy(g["X_nz_row"].astype(np.int64)), torch.from_numpy(g["X_nz_col"].astype(np.int64))] = 1.0
+    rowptr, colidx = O.build_csr(V, g["src"], g["dst"])
+    eng = SweepEngine(HostCSR(V, rowptr, colidx), X, dev)
+    eng.build_P()
+    np.testing.assert_allclose(eng.P[:eng.E_loc].cpu().numpy(), g["P_values"], rtol=1e-5)
+    delta = eng.sweep(0.76)
+    Z1 = eng.get_Z()
+    np.testing.assert_allclose(Z1[:24].numpy(), g["Z1_head"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(Z1.norm(dim=1).numpy(), g["Z1_rownorm"], rtol=1e-5)
+    assert delta == pytest.approx(float(g["delta1"]), rel=1e-5)
+
+
+def test_corashape_converged_embeddings_config1(tmp_path):
+    """BASELINE config 1: Cora-shaped graph (2708 / 5429 / d=1433 BoW) to convergence, within 1e-4."""
+    g = load_golden("g8_corashape.npz")
+    V, d = int(g["V"]), int(g["d"])
+    X = torch.zeros(V, d)
+    X[torch.from_numpy(g["X_nz_row"].astype(np.int64)), torch.from_numpy(g["X_nz_col"].astype(np.int64))] = 1.0
+    root = write_data_root(tmp_path / "cora", range(V), g["src"], g["dst"], X.numpy())
+    graph = Graph(root)
+    assert graph.csr.num_edges == 5429
+    emb = Embedder(graph, CosineSimilarity(), torch.device("cuda"), gamma=0.76, tolerence=10, verbose=False)
+    emb.iterate()
+    orc = O.OracleEmbedder(graph.csr.rowptr, graph.csr.colidx, X, gamma=0.76, tolerence=10)
+    assert O.rel_l2(graph.Z, orc.iterate()) < 1e-5
+
+
+def test_cli_end_to_end(tmp_path, karate_root, monkeypatch):
+    from clane_amd.__main__ import embedding, get_parser
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text("graph:\n  embedding_dim: 2\n\nsimilarity:\n  method: \"CosineSimilarity\"\n  kwargs:\n"
+                   "    foo: \"bar\"\n\nembedder:\n  gamma: 0.76\n  tolerence: 10\n")
+    out = tmp_path / "test_output"
+    for argv in (["--data_root", str(karate_root)], ["embedding", "--data_root", str(karate_root)]):
+        args = get_parser().parse_args(argv + ["--output_root", str(out), "--config_file", str(cfg),
+                                               "--save_history"])
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            embedding(args)
+        gold = load_golden("g9_cli.npz")
+        Z = np.load(out / "Z.npy")
+        assert Z.shape == (34, 2) and np.load(out / "0" / "Z_0.npy").shape == (34, 2)   # reference test_cli.py:31-36
+        listing = sorted(str(p.relative_to(out)) for p in out.rglob("*.npy"))
+        assert "Z.npy" in listing and "0/Z_0.npy" in listing
+        text = buf.getvalue()
+        for line in ("[Embedding]", "Graph Loaded.", " - 34 vertices", " - 78 edges", "Saving the results."):
+            assert line in text
+        assert set(gold["parser_dests"]) <= {a.dest for a in get_parser()._actions}
+    with pytest.raises(FileNotFoundError):
+        embedding(get_parser().parse_args(["--data_root", str(karate_root), "--output_root", str(out),
+                                           "--config_file", str(tmp_path / "missing.yaml")]))
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("graph:\n  embedding_dim: 2\nsimilarity:\n  method: \"Nope\"\n  kwargs: {}\nembedder: {}\n")
+    with pytest.raises(AttributeError, match="not found"):
+        embedding(get_parser().parse_args(["--data_root", str(karate_root), "--output_root", str(out),
+                                           "--config_file", str(bad)]))
+
+
+# ---- scale: config 2 shape (R-MAT 200k / 4M / d=128) directly against the oracle ------------------------
+def test_rmat_200k_parity_and_properties(dev):
+    V, E, d, gamma = 200_000, 4_000_000, 128, 0.76
+    csr = synth.rmat_csr(V, E, seed=1)
+    assert csr.num_edges == E and int(np.diff(csr.rowptr).max()) > 1024       # has hub rows -> long-row pass
+    X = synth.gaussian_X(V, d, seed=2)
+    eng = SweepEngine(csr, X, dev)
+    assert any(lr is not None for lr in eng.long_rows)
+    eng.build_P()
+    P_or = O.build_P_values(csr.rowptr, csr.colidx, X)
+    assert rel(eng.P[:E], P_or) < 1e-5
+    # property: every non-empty row of P sums to 1
+    rows = torch.from_numpy(np.repeat(np.arange(V), np.diff(csr.rowptr))).to(dev)
+    rs = torch.zeros(V, dtype=torch.float64, device=dev).index_add_(0, rows, eng.P[:E].double())
+    nz = torch.from_numpy(np.diff(csr.rowptr) > 0).to(dev)
+    assert float((rs[nz] - 1).abs().max()) < 1e-5 and float(rs[~nz].abs().max()) == 0
+    Z = X.clone()
+    Ps = O.as_sparse(csr.rowptr, csr.colidx, P_or)
+    for _ in range(3):
+        delta = eng.sweep(gamma)
+        Z, d_or = O.sweep(csr.rowptr, csr.colidx, P_or, X, Z, gamma, Ps)
+        assert delta == pytest.approx(float(d_or), rel=1e-4)
+    assert O.rel_l2(eng.get_Z(), Z) < 1e-5
+    # property (size-independent): the sweep is affine in Z -> S(a) - S(b) = gamma * P (a - b)
+    a = eng.get_Z()
+    eng.set_Z(a * 0.5)
+    eng.P_valid = True
+    eng.sweep(gamma)
+    half = eng.get_Z()
+    eng.set_Z(a)
+    eng.P_valid = True
+    eng.sweep(gamma)
+    full = eng.get_Z()
+    lin = (full - X) - 2 * (half - X)
+    nzc = torch.from_numpy(np.diff(csr.rowptr) > 0)
+    assert float(lin[nzc].abs().max()) < 1e-4 * float(full.abs().max())

@@ -1,0 +1,255 @@
+"""Host-side logic of clane_amd on CPU: file loader, CSR, object-model facade, row partition,
+SweepEngine launch sequence and Embedder control flow.  The kernels are replaced by the
+oracle-backed test double (tests/oracle_kernels.py) -- only here, only by injection."""
+import io
+import contextlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from clane_amd import _hip
+from clane_amd.embedder import Embedder, IterativeEmbedder
+from clane_amd.engine import SweepEngine
+from clane_amd.graph import Graph
+from clane_amd.partition import HostCSR, RowPartition, localize
+from clane_amd.similarity import AsymmertricSimilarity, CosineSimilarity, Similarity
+from oracle import clane_oracle as O
+
+from .conftest import load_golden, write_data_root
+from .oracle_kernels import OracleKernels
+
+KARATE_LIKE = ["g4_karate_d2.npz", "g4_karate_d16.npz", "g5_symkarate_d16_g0.5.npz",
+               "g5_symkarate_d16_g0.76.npz", "g5_symkarate_d2_g0.76.npz", "g7_readme5.npz", "g6_tiny_f64.npz"]
+
+
+def graph_from_golden(tmp_path, name):
+    g = load_golden(name)
+    if "edge_src" in g.files:
+        vids = g["vertex_ids"] if "vertex_ids" in g.files else load_golden("g2_karate_csr.npz")["vertex_ids"]
+        src, dst = g["edge_src"], g["edge_dst"]
+    else:
+        k = load_golden("g2_karate_csr.npz")
+        vids, src, dst = k["vertex_ids"], k["edge_src"], k["edge_dst"]
+    root = write_data_root(tmp_path / name, vids, src, dst, g["X"])
+    return g, Graph(root)
+
+
+def attach_cpu_engine(graph, **kw):
+    eng = SweepEngine(graph.csr, graph.X, "cpu", OracleKernels(), **kw)
+    graph._attach_engine(eng)
+    return eng
+
+
+# ---- reference tests/test_graph.py, re-expressed ----------------------------------------------
+def test_load_zachary(karate_root):
+    g = Graph(data_root=karate_root, embedding_dim=16)
+    assert len(g.vertex_ids) == 34 and len(g.V) == 34 and len(g.E) == 78 and len(g) == 34
+    for v in g.V:
+        assert isinstance(v.x, torch.Tensor) and v.x.shape[-1] == 16
+    assert g.d == 16 and g.dispense_pair is False and g[5] == 5
+
+
+def test_build_A_and_get_nbrs(karate_root):
+    g = Graph(data_root=karate_root, embedding_dim=16)
+    A = g.A
+    assert A.shape == (34, 34) and A.is_coalesced()
+    np.testing.assert_array_equal(A.indices().numpy(), load_golden("g2_karate_csr.npz")["A_indices"])
+    assert g.get_nbrs(33).tolist() == [8, 9, 13, 14, 15, 18, 19, 20, 22, 23, 26, 27, 28, 29, 30, 31, 32]
+    for v in g.V:
+        nb = g.get_nbrs(v.idx)
+        assert nb.dim() == 1 and nb.dtype == torch.int64
+    # object-model facade: per-line adjacency lists, edge endpoints
+    e0 = g.E[0]
+    assert (e0.src.id_, e0.dst.id_) == ("2", "1") and e0.src.idx == 1
+    assert g.V[33].outgoing_indices == g.get_nbrs(33).tolist()
+    assert 33 in g.V[8].incoming_indices
+
+
+def test_duplicates_selfloop_string_ids_f64(tmp_path):
+    gold, g = graph_from_golden(tmp_path, "g6_tiny_f64.npz")
+    assert len(g.E) == int(gold["num_E"]) == 5 and g.csr.num_edges == 4
+    assert g.X.dtype == torch.float64 and g.d == 128 and g.X.shape == (4, 3)   # embedding_dim kept, shape from C.npy
+    assert g.get_nbrs(0).tolist() == [1, 2] and g.get_nbrs(2).tolist() == [] and g.get_nbrs(3).tolist() == [3]
+    assert g.V[0].outgoing_indices == [1, 2, 1]          # per-line list keeps the duplicate (graph.py:82)
+
+
+def test_loader_errors(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        Graph(tmp_path / "nope")
+    root = write_data_root(tmp_path / "noE", ["1", "2"], ["1"], ["2"])
+    (root / "E").unlink()
+    with pytest.raises(FileNotFoundError):
+        Graph(root)
+    with pytest.raises(ValueError):
+        Graph(write_data_root(tmp_path / "unk", ["1", "2"], ["1"], ["3"]))
+    bad = write_data_root(tmp_path / "bad", ["1", "2"], ["1"], ["2"])
+    (bad / "E").write_text("1 2\n")
+    with pytest.raises(ValueError):
+        Graph(bad)
+
+
+def test_first_occurrence_wins_for_duplicate_ids(tmp_path):
+    g = Graph(write_data_root(tmp_path / "dup", ["a", "b", "a"], ["b"], ["a"]), embedding_dim=2)
+    assert g.get_nbrs(1).tolist() == [0]
+
+
+def test_Z_is_fresh_and_set_Z_roundtrip(karate_root):
+    g = Graph(karate_root, embedding_dim=4)
+    z = g.Z
+    assert torch.equal(z, g.X) and z.data_ptr() != g.X.data_ptr()
+    z.zero_()
+    assert torch.equal(g.Z, g.X)
+    new = torch.arange(34 * 4, dtype=torch.float32).reshape(34, 4)
+    g.set_Z(new)
+    assert torch.equal(g.Z, new) and torch.equal(g.V[3].z, new[3])
+    g.V[3].z = torch.ones(4)
+    assert torch.equal(g.Z[3], torch.ones(4)) and torch.equal(g.Z[4], new[4])
+    eng = attach_cpu_engine(g)
+    assert torch.equal(eng.get_Z(), g.Z) and torch.equal(g.Z[3], torch.ones(4))
+
+
+# ---- no GPU => loud failure, never a fallback ---------------------------------------------------
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_path_refuses_to_run_without_gpu(karate_root):
+    g = Graph(karate_root, embedding_dim=4)
+    with pytest.raises(_hip.ClaneHipError, match="no CPU fallback"):
+        g.build_P(CosineSimilarity())
+    with pytest.raises(_hip.ClaneHipError):
+        Embedder(g, CosineSimilarity(), torch.device("cpu")).iterate()
+    with pytest.raises(_hip.ClaneHipError):
+        CosineSimilarity()(torch.ones(3), torch.ones(3))
+    with pytest.raises(_hip.ClaneHipError, match="GPU memory"):
+        _hip.kernels().row_sqnorm(torch.ones(2, 4), 4, torch.zeros(2))
+
+
+# ---- plugin surface -------------------------------------------------------------------------
+def test_similarity_plugin_surface():
+    import clane_amd.similarity as S
+    assert getattr(S, "CosineSimilarity")(foo="bar").is_trainable() is False
+    assert isinstance(CosineSimilarity(), Similarity) and CosineSimilarity(mode="per_edge").mode == "per_edge"
+    with pytest.raises(ValueError):
+        CosineSimilarity(mode="nope")
+    a = AsymmertricSimilarity(n_dim=4)
+    assert a.is_trainable() and hasattr(a, "parameters")
+    x, y = torch.rand(3, 4), torch.rand(3, 4)
+    assert a(x, y).shape == (3,) and not torch.allclose(a(x, y), a(y, x))
+    with pytest.raises(NotImplementedError):
+        IterativeEmbedder()
+
+
+# ---- partition ------------------------------------------------------------------------------
+@pytest.mark.parametrize("V,W,C", [(34, 1, 1), (34, 2, 1), (34, 2, 3), (5, 4, 2), (1000, 8, 4)])
+def test_partition_is_a_bijection_with_contiguous_chunk_spans(V, W, C):
+    parts = [RowPartition.create(V, W, r, C, seed=3) for r in range(W)]
+    p0 = parts[0]
+    pos = p0.position_of_vertex()
+    assert len(np.unique(pos)) == V and pos.max() < p0.padded_vertices
+    owned = np.concatenate([p.local_positions() for p in parts])
+    assert sorted(owned.tolist()) == list(range(p0.padded_vertices))
+    vc = p0.rows_per_chunk
+    for r, p in enumerate(parts):
+        lp = p.local_positions()
+        for c in range(C):
+            b, e = p.chunk_span(c)
+            r0 = p.chunk_row0(c)
+            assert r0 == b + r * vc and e - b == W * vc          # in-place all-gather form
+            np.testing.assert_array_equal(lp[c * vc:(c + 1) * vc], np.arange(r0, r0 + vc))
+
+
+def test_localize_relabels_and_keeps_every_edge():
+    gold = load_golden("g5_symkarate_d16_g0.76.npz")
+    idx = gold["A_indices"]
+    rowptr, colidx = O.build_csr(34, idx[0], idx[1])
+    csr = HostCSR(34, rowptr, colidx)
+    seen = np.zeros(csr.num_edges, dtype=int)
+    for r in range(3):
+        part = RowPartition.create(34, 3, r, 2, seed=1)
+        loc = localize(csr, part)
+        pos = part.position_of_vertex()
+        seen[loc.edge_origin] += 1
+        for l in range(part.n_local):
+            v = loc.vertex[l]
+            cols = loc.colidx[loc.rowptr[l]:loc.rowptr[l + 1]]
+            if v < 0:
+                assert len(cols) == 0
+                continue
+            assert sorted(cols.tolist()) == cols.tolist()
+            assert sorted(cols.tolist()) == sorted(pos[colidx[rowptr[v]:rowptr[v + 1]]].tolist())
+            assert loc.indeg[l] == np.sum(colidx == v)
+    assert (seen == 1).all()
+
+
+# ---- engine launch sequence vs goldens ----------------------------------------------------------
+@pytest.mark.parametrize("name", KARATE_LIKE)
+@pytest.mark.parametrize("chunks,shuffle", [(1, False), (3, True)])
+def test_engine_build_P_and_first_sweep(tmp_path, name, chunks, shuffle):
+    gold, g = graph_from_golden(tmp_path, name)
+    attach_cpu_engine(g, chunks=chunks, shuffle=shuffle, seed=5)
+    P = g.build_P(CosineSimilarity())
+    assert P.is_coalesced() and P.shape == (len(g), len(g)) and P.dtype == g.X.dtype
+    np.testing.assert_array_equal(P.indices().numpy(), gold["A_indices"])
+    np.testing.assert_allclose(P.values().numpy(), gold["P0_values"], rtol=3e-6, atol=1e-7)
+    dense = P.to_dense().sum(1)
+    sink = np.diff(g.csr.rowptr) == 0
+    assert torch.allclose(dense[~torch.from_numpy(sink)], torch.ones((~sink).sum(), dtype=dense.dtype), atol=1e-5)
+    assert float(dense[torch.from_numpy(sink)].abs().sum()) == 0.0
+    eng = g._engine
+    delta = eng.sweep(float(gold["gamma"]))
+    Z1 = torch.from_numpy(gold["Z_sweep1"])
+    assert O.rel_l2(g.Z, Z1) < 1e-6
+    assert delta == pytest.approx(float((Z1 - torch.from_numpy(gold["X"])).abs().sum()), rel=1e-5)
+
+
+@pytest.mark.parametrize("name", KARATE_LIKE)
+def test_embedder_iterate_matches_reference_final_Z(tmp_path, name):
+    gold, g = graph_from_golden(tmp_path, name)
+    attach_cpu_engine(g)
+    emb = Embedder(g, CosineSimilarity(), torch.device("cpu"), gamma=float(gold["gamma"]),
+                   tolerence=int(gold["tolerence"]), save_history=True, verbose=False)
+    emb.iterate()
+    assert O.rel_l2(g.Z, torch.from_numpy(gold["Z_final"])) < 1e-6
+    assert emb.tolerences["global"].value == 0 and emb.tolerences["propagation"].value == 0
+    assert len(emb.history["Z"]) == len(emb.sweep_counts) == len(emb.outer_deltas)
+    assert [len(h) for h in emb.history["Z"]] == emb.sweep_counts
+    # sweep counts depend on last-ulp noise near the fixed point: bounded, never pinned
+    assert abs(emb.sweep_counts[0] - gold["sweep_counts"][0]) <= max(3, 0.15 * gold["sweep_counts"][0])
+    assert O.rel_l2(emb.history["Z"][0][0], torch.from_numpy(gold["Z_sweep1"])) < 1e-6
+    assert O.rel_l2(emb.history["Z"][0][-1], torch.from_numpy(gold["Z_prop1"])) < 1e-6
+    assert emb.minimum_amount_updated_Z == min(emb.outer_deltas)
+
+
+def test_embedder_prints_delta_and_tolerance_per_sweep(tmp_path):
+    gold, g = graph_from_golden(tmp_path, "g7_readme5.npz")
+    attach_cpu_engine(g)
+    emb = Embedder(g, CosineSimilarity(), torch.device("cpu"), tolerence=2)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        emb.propagate()
+    lines = buf.getvalue().strip().splitlines()
+    assert len(lines) == emb.sweep_counts[0] and lines[-1].endswith(" 0") and lines[0].endswith(" 2")
+
+
+def test_per_edge_mode_is_true_cosine(tmp_path):
+    gold, g = graph_from_golden(tmp_path, "g5_symkarate_d16_g0.76.npz")
+    attach_cpu_engine(g)
+    P = g.build_P(CosineSimilarity(mode="per_edge"))
+    rowptr, colidx = g.csr.rowptr, g.csr.colidx
+    ref = O.build_P_values(rowptr, colidx, g.X, mode="per_edge")
+    np.testing.assert_allclose(P.values().numpy(), ref.numpy(), rtol=1e-5)
+    assert not np.allclose(P.values().numpy(), gold["P0_values"], rtol=1e-3)
+
+
+def test_custom_similarity_callable_goes_through_plugin_protocol(tmp_path):
+    gold, g = graph_from_golden(tmp_path, "g5_symkarate_d2_g0.76.npz")
+    attach_cpu_engine(g)
+    calls = []
+
+    def sim(a, b):
+        calls.append((tuple(a.shape), tuple(b.shape)))
+        return O.cosine_similarity(a, b)
+
+    P = g.build_P(sim)
+    assert calls == [((156, 2), (156, 2))]                 # ONE batched call with all edges (graph.py:121)
+    np.testing.assert_allclose(P.values().numpy(), gold["P0_values"], rtol=3e-6, atol=1e-7)
