@@ -34,7 +34,8 @@ SIGNATURES = {
 }
 for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_row_sqnorm_{_s}"] = (C.c_int, [_p, _i64, _i32, _i64, _p, _p])
-    SIGNATURES[f"clane_edge_score_{_s}"] = (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _p])
+    SIGNATURES[f"clane_edge_score_{_s}"] = (
+        C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _i64, _p])
     _g = C.c_double if _s == "f64" else C.c_float
     SIGNATURES[f"clane_spmm_update_{_s}"] = (
         C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _p, _p])
@@ -140,11 +141,15 @@ class HipKernels:
             "clane_degree_weighted_sums")
 
     # -- K1 / K2 ------------------------------------------------------------------------
-    def edge_score(self, rowptr, colidx, nrows: int, row0: int, Z, d: int, mode: int, sums2, sq, scores):
+    def edge_score(self, rowptr, colidx, nrows: int, row0: int, Z, d: int, mode: int, sums2, sq, scores,
+                   long_threshold: int = 0, long_rows=None, max_long_degree: int = 0):
         zp, ldz = _mat(Z, "Z")
+        n_long = 0 if long_rows is None else long_rows.numel()
         self._check(self._fn("clane_edge_score", Z.dtype)(
             _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"), nrows, row0, zp, ldz, d, mode,
-            _ptr(sums2), _ptr(sq), _vec(scores, acc_dtype(Z.dtype), "scores"), self._stream(Z)), "clane_edge_score")
+            _ptr(sums2), _ptr(sq), _vec(scores, acc_dtype(Z.dtype), "scores"), long_threshold,
+            None if n_long == 0 else _vec(long_rows, torch.int32, "long_rows"), n_long, max_long_degree,
+            self._stream(Z)), "clane_edge_score")
 
     def segment_softmax(self, rowptr, nrows: int, vals):
         self._check(self._fn("clane_segment_softmax", vals.dtype)(

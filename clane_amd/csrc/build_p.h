@@ -3,8 +3,7 @@
 //   K0  row_sqnorm_kernel          sq[v] = |z_v|^2
 //       degree_weighted_kernel     sum_v outdeg_v sq_v , sum_v indeg_v sq_v   (the two GLOBAL
 //                                  Frobenius norms of similarity.py:37, without gathering Z[edges])
-//   K1  edge_score_kernel          score_e = dot(z_src, z_dst) / denominator, CSR order; the source
-//                                  row stays in registers while the wave walks its neighbour list
+//   K1  (edge_score.h)
 //   K2  segment_softmax_kernel     per-row softmax in place (graph.py:122-123)
 // All HBM-bound; K1 has the same gather shape as K3 (spmm_update.h) and the same lane layout.
 #pragma once
@@ -13,9 +12,6 @@
 
 namespace clane {
 
-constexpr int kScoreReference = 0;
-constexpr int kScorePerEdge = 1;
-constexpr int kScoreRawDot = 2;
 
 // ---- K0 ------------------------------------------------------------------------------------
 // LPR lanes per row; a wave covers 64/LPR rows at once.
@@ -79,88 +75,6 @@ __global__ __launch_bounds__(1024) void reduce_fixed_kernel(const double *__rest
     }
 }
 
-// ---- K1 ------------------------------------------------------------------------------------
-template <typename T, int VEC, int LPR, int U>
-__global__ __launch_bounds__(kBlock) void edge_score_kernel(
-    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows, int64_t row0,
-    const T *__restrict__ Z, int64_t ldz, int d, int mode, const double *__restrict__ sums2,
-    const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores) {
-    using A = typename Elem<T>::acc_t;
-    constexpr int EPW = kWave / LPR;
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int sub = lane / LPR, sl = lane % LPR;
-    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
-    const bool single = d <= LPR * VEC;  // whole row in one pack per lane: keep the source row in registers
-
-    A D = A(1);
-    if (mode == kScoreReference) D = sqrt(A(sums2[0])) * sqrt(A(sums2[1]));  // similarity.py:37
-
-    for (int64_t r = int64_t(blockIdx.x) * kWavesPerBlock + wave; r < nrows; r += nwaves) {
-        const int64_t e0 = rowptr[r];
-        const int64_t e1 = rowptr[r + 1];
-        if (e0 == e1) continue;
-        const T *zsrc = Z + (row0 + r) * ldz;
-        const A nsrc = mode == kScorePerEdge ? sqrt(sq[row0 + r]) : A(0);
-        Pack<T, VEC> s0{};
-        if (single && sl * VEC < d) s0 = load_pack<T, VEC>(zsrc + sl * VEC);
-
-        for (int64_t e = e0; e < e1; e += kWave) {
-            const int64_t left = e1 - e;
-            const int n = left < kWave ? int(left) : kWave;
-            const int c = lane < n ? colidx[e + lane] : 0;
-            for (int j = 0; j < n; j += EPW * U) {
-                A part[U];
-                int cj[U];
-                bool act[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = j + u * EPW + sub;
-                    if constexpr (LPR == kWave)
-                        cj[u] = lane_get_uniform(c, idx & (kWave - 1));
-                    else
-                        cj[u] = lane_get(c, idx & (kWave - 1));
-                    act[u] = idx < n;
-                    part[u] = A(0);
-                }
-                for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
-                    const int c0 = t0 + sl * VEC;
-                    const bool ok = c0 < d;
-                    Pack<T, VEC> s = s0;
-                    if (!single) {
-                        s = Pack<T, VEC>{};
-                        if (ok) s = load_pack<T, VEC>(zsrc + c0);
-                    }
-                    Pack<T, VEC> z[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        z[u] = Pack<T, VEC>{};
-                        if (act[u] && ok) z[u] = load_pack<T, VEC>(Z + int64_t(cj[u]) * ldz + c0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k)
-                            part[u] = fma(Elem<T>::to_acc(s.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const A dot = group_sum<LPR>(part[u]);
-                    if (act[u] && sl == 0) {
-                        A score = dot;
-                        if (mode == kScoreReference)
-                            score = dot / D;
-                        else if (mode == kScorePerEdge)
-                            score = dot / (nsrc * sqrt(sq[cj[u]]));
-                        scores[e + j + u * EPW + sub] = score;
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---- K2 ------------------------------------------------------------------------------------
 template <typename A>
 __device__ __forceinline__ A exp_acc(A v);
@@ -177,12 +91,13 @@ __device__ __forceinline__ double exp_acc<double>(double v) {
 // over their (L2-resident) segment.
 template <typename A>
 __global__ __launch_bounds__(kBlock) void segment_softmax_kernel(const int64_t *__restrict__ rowptr, int64_t nrows,
-                                                                 A *__restrict__ vals) {
+                                                                 A *__restrict__ vals, int rows_per_block) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
+    const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
+    const int64_t row_end = row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows;
     const A neg_inf = -A(INFINITY);
-    for (int64_t r = int64_t(blockIdx.x) * kWavesPerBlock + wave; r < nrows; r += nwaves) {
+    for (int64_t r = row_begin + wave; r < row_end; r += kWavesPerBlock) {
         const int64_t e0 = rowptr[r];
         const int64_t e1 = rowptr[r + 1];
         const int64_t deg = e1 - e0;

@@ -9,6 +9,7 @@
 #include <cstdio>
 
 #include "build_p.h"
+#include "edge_score.h"
 #include "device_utils.h"
 #include "spmm_update.h"
 
@@ -37,6 +38,14 @@ constexpr int64_t kReduceWs = 2 * kReduceGrid + 2;  // + the two finished sums
 constexpr int kLongWaves = 16;
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Row kernels (K1, K2, K3): a workgroup owns `rows_per_block` consecutive rows; the grid is kept
+// <= 65536 workgroups and >> the 2048 resident ones, so the dispatcher load-balances skewed rows.
+inline int rows_per_block(int64_t nrows) {
+    const int64_t r = ceil_div(ceil_div(nrows, 65536), kWavesPerBlock) * kWavesPerBlock;
+    return int(r < 32 ? 32 : r);
+}
+inline int row_grid(int64_t nrows) { return int(ceil_div(nrows > 0 ? nrows : 1, rows_per_block(nrows))); }
 
 inline int grid_for_waves(int64_t nwaves_wanted) {
     int64_t g = ceil_div(nwaves_wanted, kWavesPerBlock);
@@ -124,10 +133,14 @@ int degree_weighted_sums(const A *sq, const int64_t *rowptr, const int32_t *inde
 template <typename T>
 int edge_score(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const T *Z, int64_t ldz,
                int32_t d, int32_t mode, const double *sums2, const typename Elem<T>::acc_t *sq,
-               typename Elem<T>::acc_t *scores, void *stream) {
+               typename Elem<T>::acc_t *scores, int64_t long_threshold, const int32_t *long_rows, int64_t n_long,
+               int64_t max_long_degree, void *stream) {
     REQUIRE(nrows >= 0 && row0 >= 0 && d > 0 && ldz >= d, "edge_score: bad shape");
     REQUIRE(mode == CLANE_SCORE_REFERENCE || mode == CLANE_SCORE_PER_EDGE || mode == CLANE_SCORE_RAW_DOT,
             "edge_score: unknown mode %d", mode);
+    REQUIRE(long_threshold >= 0 && n_long >= 0 && n_long <= INT32_MAX, "edge_score: bad long-row parameters");
+    REQUIRE(n_long == 0 || (long_rows && long_threshold > 0 && max_long_degree > long_threshold),
+            "edge_score: long_rows needs a list, a threshold and max_long_degree > threshold");
     if (nrows == 0) return CLANE_OK;
     REQUIRE(rowptr && colidx && Z && scores, "edge_score: null pointer");
     REQUIRE(mode != CLANE_SCORE_REFERENCE || sums2, "edge_score: mode REFERENCE needs sums2");
@@ -135,9 +148,15 @@ int edge_score(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int6
     const Layout L = pick_layout<T>(d, {Z}, {ldz});
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? 8 : 4;
-        const int grid = grid_for_waves(nrows);
-        edge_score_kernel<T, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(rowptr, colidx, nrows, row0, Z,
-                                                                                    ldz, d, mode, sums2, sq, scores);
+        edge_score_kernel<T, VEC, LPR, U><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(
+            rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, long_threshold, rows_per_block(nrows));
+        if (n_long > 0) {
+            constexpr int kEdgesPerWave = 256;
+            const int64_t slices = ceil_div(max_long_degree, int64_t(kLongWaves) * kEdgesPerWave);
+            edge_score_long_kernel<T, VEC, LPR, U, kLongWaves>
+                <<<dim3(unsigned(n_long), unsigned(slices)), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
+                    rowptr, colidx, long_rows, row0, Z, ldz, d, mode, sums2, sq, scores, kEdgesPerWave);
+        }
     });
     return check_launch("edge_score");
 }
@@ -147,11 +166,12 @@ int segment_softmax(const int64_t *rowptr, int64_t nrows, A *vals, void *stream)
     REQUIRE(nrows >= 0, "segment_softmax: nrows < 0");
     if (nrows == 0) return CLANE_OK;
     REQUIRE(rowptr && vals, "segment_softmax: null pointer");
-    segment_softmax_kernel<A><<<grid_for_waves(nrows), kBlock, 0, (hipStream_t)stream>>>(rowptr, nrows, vals);
+    segment_softmax_kernel<A><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(rowptr, nrows, vals,
+                                                                                  rows_per_block(nrows));
     return check_launch("segment_softmax");
 }
 
-inline int64_t spmm_main_grid(int64_t nrows) { return grid_for_waves(nrows); }
+inline int64_t spmm_main_grid(int64_t nrows) { return row_grid(nrows); }
 
 template <typename T, typename PT>
 int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows, int64_t row0,
@@ -170,7 +190,8 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? 8 : 4;
         spmm_update_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-            rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold, delta_partials);
+            rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
+            rows_per_block(nrows), delta_partials);
     });
     return check_launch("spmm_update");
 }
@@ -265,22 +286,18 @@ int clane_degree_weighted_sums_f64(const double *sq, const int64_t *rowptr, cons
     return degree_weighted_sums<double>(sq, rowptr, indeg, nrows, ws, out2, stream);
 }
 
-int clane_edge_score_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const float *Z,
-                         int64_t ldz, int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
-                         void *stream) {
-    return edge_score<float>(rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, stream);
-}
-int clane_edge_score_f64(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const double *Z,
-                         int64_t ldz, int32_t d, int32_t mode, const double *sums2, const double *sq, double *scores,
-                         void *stream) {
-    return edge_score<double>(rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, stream);
-}
-int clane_edge_score_bf16(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
-                          const uint16_t *Z, int64_t ldz, int32_t d, int32_t mode, const double *sums2,
-                          const float *sq, float *scores, void *stream) {
-    return edge_score<bf16_t>(rowptr, colidx, nrows, row0, reinterpret_cast<const bf16_t *>(Z), ldz, d, mode, sums2,
-                              sq, scores, stream);
-}
+#define CLANE_EDGE_SCORE_WRAPPER(SUF, CT, T, AT)                                                                      \
+    int clane_edge_score_##SUF(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,             \
+                               const CT *Z, int64_t ldz, int32_t d, int32_t mode, const double *sums2, const AT *sq,  \
+                               AT *scores, int64_t long_threshold, const int32_t *long_rows, int64_t n_long,          \
+                               int64_t max_long_degree, void *stream) {                                               \
+        return edge_score<T>(rowptr, colidx, nrows, row0, reinterpret_cast<const T *>(Z), ldz, d, mode, sums2, sq,    \
+                             scores, long_threshold, long_rows, n_long, max_long_degree, stream);                     \
+    }
+CLANE_EDGE_SCORE_WRAPPER(f32, float, float, float)
+CLANE_EDGE_SCORE_WRAPPER(f64, double, double, double)
+CLANE_EDGE_SCORE_WRAPPER(bf16, uint16_t, bf16_t, float)
+#undef CLANE_EDGE_SCORE_WRAPPER
 
 int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, void *stream) {
     return segment_softmax<float>(rowptr, nrows, vals, stream);

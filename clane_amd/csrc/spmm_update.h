@@ -15,8 +15,11 @@
 //  * U row loads are issued back-to-back before the first FMA consumes one, so every wave
 //    keeps U KiB of gathers in flight; edges past the end of a row are exec-masked loads
 //    (no traffic), never branches.
-//  * rows are dealt round-robin to a fixed grid (grid-stride), so the number of delta
-//    partials is bounded and their order is fixed: no float atomics anywhere.
+//  * a workgroup owns `rows_per_block` CONSECUTIVE rows (its 4 waves interleave over them) and
+//    there are many more workgroups than CUs, so the hardware dispatcher balances skewed rows
+//    dynamically.  (A fixed grid striding rows by a power of two is pathological on R-MAT:
+//    stride 2^13 hands one wave every id with 13 trailing zero bits, i.e. the heaviest hubs.)
+//    One delta partial per workgroup, reduced later in index order: no float atomics anywhere.
 //  * rows longer than `long_threshold` edges are skipped here and done by spmm_long_kernel
 //    (one 16-wave workgroup per row, per-wave edge segments, fixed-order LDS fold).
 #pragma once
@@ -88,17 +91,18 @@ __global__ __launch_bounds__(kBlock) void spmm_update_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    double *__restrict__ partials) {
+    int rows_per_block, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ double smem[kWavesPerBlock];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sub = lane / LPR;
     const int sl = lane % LPR;
-    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
+    const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
+    const int64_t row_end = row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows;
     double dsum = 0.0;
 
-    for (int64_t r = int64_t(blockIdx.x) * kWavesPerBlock + wave; r < nrows; r += nwaves) {
+    for (int64_t r = row_begin + wave; r < row_end; r += kWavesPerBlock) {
         const int64_t e0 = rowptr[r];
         const int64_t e1 = rowptr[r + 1];
         if (long_threshold > 0 && e1 - e0 > long_threshold) continue;

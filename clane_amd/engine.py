@@ -73,6 +73,7 @@ class SweepEngine:
         self.P_valid = False
         vc = self.part.rows_per_chunk
         deg = np.diff(self.local.rowptr)
+        self.max_degree = int(deg.max()) if deg.size else 0
         self.long_rows: List[Optional[torch.Tensor]] = []
         self.partial_off = [0]
         for c in range(self.part.chunks):
@@ -144,7 +145,7 @@ class SweepEngine:
         if self.E_loc > 0:
             for c in range(part.chunks):
                 k.edge_score(self.rowptr[c * vc:], self.colidx, vc, part.chunk_row0(c), Z, self.d, mode,
-                             self.sums2, sq, self.P)
+                             self.sums2, sq, self.P, self.long_threshold, self.long_rows[c], self.max_degree)
             k.segment_softmax(self.rowptr, part.n_local, self.P)
         self.P_valid = True
 

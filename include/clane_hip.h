@@ -77,16 +77,22 @@ int clane_degree_weighted_sums_f64(const double *sq, const int64_t *rowptr, cons
  * materialising Z[edges].  Source row of local row i is Z[row0+i].
  *   mode REFERENCE: sums2 = the (all-reduced) pair from clane_degree_weighted_sums_*; sq unused.
  *   mode PER_EDGE : sq = squared norms of ALL rows of Z; sums2 unused.
- *   mode RAW_DOT  : both unused. */
+ *   mode RAW_DOT  : both unused.
+ * Rows with more than `long_threshold` edges (0 = never) are cut into per-wave slices by a
+ * second launch over `long_rows` (local row ids, n_long of them, none longer than
+ * `max_long_degree`); pass n_long = 0 to have every row walked by a single wave. */
 int clane_edge_score_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const float *Z,
                          int64_t ldz, int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
+                         int64_t long_threshold, const int32_t *long_rows, int64_t n_long, int64_t max_long_degree,
                          void *stream);
 int clane_edge_score_f64(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const double *Z,
                          int64_t ldz, int32_t d, int32_t mode, const double *sums2, const double *sq, double *scores,
+                         int64_t long_threshold, const int32_t *long_rows, int64_t n_long, int64_t max_long_degree,
                          void *stream);
 int clane_edge_score_bf16(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
                           const uint16_t *Z, int64_t ldz, int32_t d, int32_t mode, const double *sums2,
-                          const float *sq, float *scores, void *stream);
+                          const float *sq, float *scores, int64_t long_threshold, const int32_t *long_rows,
+                          int64_t n_long, int64_t max_long_degree, void *stream);
 
 /* ---- K2: in-place softmax of vals within each CSR row.  Replaces the per-row boolean-mask
  * loop of graph.py:122-123.  Empty rows are skipped. */

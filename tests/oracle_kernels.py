@@ -17,7 +17,7 @@ def _np(t):
 
 class OracleKernels:
     def spmm_partials_len(self, nrows, n_long):
-        return 3 + n_long
+        return -(-max(nrows, 1) // 32) + n_long
 
     def reduce_ws_len(self):
         return 8
@@ -30,7 +30,8 @@ class OracleKernels:
         out2[0] = (outdeg * sq[:nrows].double()).sum()
         out2[1] = (indeg[:nrows].double() * sq[:nrows].double()).sum()
 
-    def edge_score(self, rowptr, colidx, nrows, row0, Z, d, mode, sums2, sq, scores):
+    def edge_score(self, rowptr, colidx, nrows, row0, Z, d, mode, sums2, sq, scores, long_threshold=0,
+                   long_rows=None, max_long_degree=0):
         rp = _np(rowptr[:nrows + 1])
         if rp[-1] == rp[0]:
             return

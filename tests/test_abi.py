@@ -29,8 +29,9 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.clane_abi_version() == _hip.ABI_VERSION
-    assert lib.clane_spmm_partials_len(10, 0) == 3          # ceil(10 rows / 4 waves per workgroup)
-    assert lib.clane_spmm_partials_len(10_000_000, 7) == 2048 + 7
+    assert lib.clane_spmm_partials_len(10, 0) == 1          # 32 consecutive rows per workgroup
+    assert lib.clane_spmm_partials_len(2_000_000, 7) == 62500 + 7
+    assert lib.clane_spmm_partials_len(10_000_000, 0) <= 65536
     assert lib.clane_reduce_ws_len() >= 2 * 1024 + 2
 
 
@@ -46,5 +47,5 @@ def test_argument_validation_reaches_last_error():
     assert rc == -1 and b"delta_partials" in lib.clane_last_error()
     rc = lib.clane_row_sqnorm_f32(None, 4, 0, 0, None, None)
     assert rc == -1 and b"bad shape" in lib.clane_last_error()
-    rc = lib.clane_edge_score_f32(None, None, 4, 0, None, 8, 8, 7, None, None, None, None)
+    rc = lib.clane_edge_score_f32(None, None, 4, 0, None, 8, 8, 7, None, None, None, 0, None, 0, 0, None)
     assert rc == -1 and b"unknown mode" in lib.clane_last_error()

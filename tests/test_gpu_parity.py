@@ -121,6 +121,12 @@ def test_edge_score_and_softmax_stages(dev, k, dtype, d, pad):
     k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, scores)
     dots = O.edge_dots(csr.rowptr, csr.colidx, Zf.double())
     assert rel(scores, dots) < tol
+    # long rows cut into per-wave slices by the second launch: identical scores
+    deg = np.diff(csr.rowptr)
+    long_rows = torch.from_numpy(np.nonzero(deg > 48)[0].astype(np.int32)).to(dev)
+    sliced = torch.full_like(scores, float("nan"))
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, sliced, 48, long_rows, int(deg.max()))
+    assert torch.equal(sliced, scores)
 
     # reference mode: denominators from K0 + degree-weighted reduction
     sq = torch.empty(V, dtype=acc, device=dev)
