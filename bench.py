@@ -68,12 +68,15 @@ def main():
     ap.add_argument("--gamma", type=float, default=0.76)
     ap.add_argument("--chunks", type=int, default=None)
     ap.add_argument("--long-threshold", type=int, default=None)
+    ap.add_argument("--hub-threshold", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="also launch l1_distance over two [V,d] matrices (known bytes) -- PMC calibration")
     args = ap.parse_args()
 
     import torch.distributed as dist
     from clane_amd import _hip, synth
-    from clane_amd.engine import SweepEngine, DEFAULT_LONG_THRESHOLD
+    from clane_amd.engine import SweepEngine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -95,11 +98,13 @@ def main():
         f"generated in {time.perf_counter() - t0:.1f}s")
 
     t0 = time.perf_counter()
-    eng = SweepEngine(csr, X, dev, process_group=pg, chunks=args.chunks,
-                      long_threshold=DEFAULT_LONG_THRESHOLD if args.long_threshold is None else args.long_threshold)
+    eng = SweepEngine(csr, X, dev, process_group=pg, chunks=args.chunks, long_threshold=args.long_threshold,
+                      hub_threshold=args.hub_threshold)
     torch.cuda.synchronize()
     log(f"engine up in {time.perf_counter() - t0:.1f}s; rank rows={eng.part.n_local} edges={eng.E_loc} "
-        f"long rows={sum(0 if l is None else l.numel() for l in eng.long_rows)}")
+        f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
+        f"hub(16 waves)={sum(0 if l is None else l.numel() for l in eng.hub_rows)} "
+        f"thresholds {eng.long_threshold}/{eng.hub_threshold}")
 
     # build_P once (timed separately, not part of a step), P frozen afterwards
     torch.cuda.synchronize()
@@ -108,6 +113,9 @@ def main():
     torch.cuda.synchronize()
     build_p_ms = (time.perf_counter() - t0) * 1e3
 
+    if args.calibrate:      # known-size streaming read in this library's own 16 B/lane access pattern
+        eng.snapshot()
+        eng.distance_from_snapshot()
     Z1 = None
     for i in range(args.warmup):
         eng.sweep(args.gamma)
@@ -136,19 +144,26 @@ def main():
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
 
-    # roofline of the dominant kernel (spmm_update_kernel, the main pass), HIP events on its stream;
-    # one launch per chunk, so per-launch bytes = main-pass bytes / chunks.
-    main_ms = float(np.mean([a for a, _ in ktimes]))
-    long_ms = float(np.mean([b for _, b in ktimes]))
+    # Roofline of the DOMINANT K3 kernel (largest share of the sweep), from HIP events recorded on the
+    # launch stream inside the timed region.  One launch of each kernel per chunk, so per-launch
+    # bytes = that kernel's algorithmic bytes per sweep / chunks (SURVEY.md section 8d gather model).
     chunks = eng.part.chunks
-    bytes_main_launch = eng.main_pass_bytes() / chunks
-    achieved = bytes_main_launch / (main_ms * 1e-3) / 1e9
-    pass_bytes = eng.algorithmic_bytes_per_sweep()
-    pass_gbps = pass_bytes / ((main_ms + long_ms) * chunks * 1e-3) / 1e9
+    kbytes = eng.kernel_bytes()
+    names = {"main": "spmm_update_kernel", "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>"}
+    per_kernel = {}
+    for key, ms in ktimes.items():
+        if kbytes[key] > 0 and ms > 0:
+            gbps = kbytes[key] / chunks / (ms * 1e-3) / 1e9
+            per_kernel[names[key]] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": kbytes[key] / chunks,
+                                      "GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
+    dom = max(per_kernel, key=lambda n: per_kernel[n]["avg_launch_ms"])
+    pass_ms = sum(ktimes.values()) * chunks
+    pass_bytes = sum(kbytes.values())
+    pass_gbps = pass_bytes / (pass_ms * 1e-3) / 1e9
     traffic = None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
-        traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}", {}).get("bytes_per_launch")
+        traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}", {}).get(dom, {}).get("bytes_per_launch")
 
     result = {
         "metric": "embedding-update iters/sec (Jacobi sweeps of Z <- X + gamma*P*Z, P frozen)",
@@ -159,11 +174,11 @@ def main():
                                f"(reference mode), seeds {gseed}/{xseed}",
                    "parallelism": f"row-partition x{world}, {chunks} chunk(s)/sweep"
                                   + (", in-place RCCL all-gather per chunk + scalar all-reduce" if world > 1 else "")},
-        "roofline": {"bound": "hbm", "kernel": "spmm_update_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": bytes_main_launch, "avg_launch_ms": main_ms,
-                     "k3_pass": {"kernels": "spmm_update_kernel + spmm_long_kernel", "bytes": pass_bytes,
-                                 "ms": (main_ms + long_ms) * chunks, "GBps": pass_gbps,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic,
+                     "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],
+                     "avg_launch_ms": per_kernel[dom]["avg_launch_ms"], "kernels": per_kernel,
+                     "k3_pass": {"bytes": pass_bytes, "ms": pass_ms, "GBps": pass_gbps,
                                  "frac": pass_gbps / HBM_PEAK_GBPS}},
         "build_P_ms": build_p_ms, "last_delta": delta,
     }

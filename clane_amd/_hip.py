@@ -10,6 +10,7 @@ from the tensor dtype.  Work is enqueued on torch's current HIP stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Optional
 
@@ -40,7 +41,7 @@ for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_spmm_update_{_s}"] = (
         C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _p, _p])
     SIGNATURES[f"clane_spmm_update_long_{_s}"] = (
-        C.c_int, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p])
+        C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p])
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 for _s in ("f32", "f64"):
     SIGNATURES[f"clane_degree_weighted_sums_{_s}"] = (C.c_int, [_p, _p, _p, _i64, _p, _p, _p])
@@ -58,6 +59,8 @@ class ClaneHipError(RuntimeError):
 
 def load_library(path: Optional[Path] = None) -> C.CDLL:
     """dlopen the library and bind every declared symbol.  Raises if anything is missing."""
+    if path is None and os.environ.get("CLANE_HIP_LIB"):      # A/B builds of the same ABI (tools/ab_variants.py)
+        path = os.environ["CLANE_HIP_LIB"]
     path = Path(path) if path is not None else LIB_PATH
     if not path.exists():
         raise ClaneHipError(
@@ -170,9 +173,10 @@ class HipKernels:
             _vec(P, acc_dtype(Z_old.dtype), "P"), nrows, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
             long_threshold, _vec(partials, torch.float64, "partials"), self._stream(Z_old)), "clane_spmm_update")
 
-    def spmm_update_long(self, rowptr, colidx, P, long_rows, row0: int, Z_old, X, gamma: float, Z_new, d: int,
-                         partials):
-        """Long-row pass: one workgroup per listed row; writes long_rows.numel() partials."""
+    def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row: int, row0: int, Z_old, X, gamma: float,
+                         Z_new, d: int, partials):
+        """Row-split pass: one workgroup of `waves_per_row` (4 | 16) waves per listed row; writes
+        long_rows.numel() partials."""
         zo, ldz = _mat(Z_old, "Z_old")
         xp, ldx = _mat(X, "X")
         zn, ldo = _mat(Z_new, "Z_new")
@@ -181,7 +185,7 @@ class HipKernels:
         self._check(self._fn("clane_spmm_update_long", Z_old.dtype)(
             _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
             _vec(P, acc_dtype(Z_old.dtype), "P"), _vec(long_rows, torch.int32, "long_rows"), long_rows.numel(),
-            row0, zo, ldz, xp, ldx, gamma, zn, ldo, d, _vec(partials, torch.float64, "partials"),
+            waves_per_row, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d, _vec(partials, torch.float64, "partials"),
             self._stream(Z_old)), "clane_spmm_update_long")
 
     def reduce_partials(self, partials, n: int, out):

@@ -36,6 +36,9 @@ int check_launch(const char *what) {
 constexpr int kReduceGrid = 1024;              // partial blocks of the two-stage reductions
 constexpr int64_t kReduceWs = 2 * kReduceGrid + 2;  // + the two finished sums
 constexpr int kLongWaves = 16;
+#ifndef CLANE_ROWS_PER_BLOCK
+#define CLANE_ROWS_PER_BLOCK 32   // minimum consecutive rows per workgroup of the row kernels
+#endif
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -43,7 +46,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // <= 65536 workgroups and >> the 2048 resident ones, so the dispatcher load-balances skewed rows.
 inline int rows_per_block(int64_t nrows) {
     const int64_t r = ceil_div(ceil_div(nrows, 65536), kWavesPerBlock) * kWavesPerBlock;
-    return int(r < 32 ? 32 : r);
+    return int(r < CLANE_ROWS_PER_BLOCK ? CLANE_ROWS_PER_BLOCK : r > kMaxRowsPerBlock ? kMaxRowsPerBlock : r);
 }
 inline int row_grid(int64_t nrows) { return int(ceil_div(nrows > 0 ? nrows : 1, rows_per_block(nrows))); }
 
@@ -188,7 +191,7 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
     const Layout L = pick_layout<T>(d, {Z_old, X, Z_new}, {ldz, ldx, ldo});
     const int grid = int(spmm_main_grid(nrows));
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
-        constexpr int U = VEC > 1 ? 8 : 4;
+        constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
         spmm_update_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
             rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
             rows_per_block(nrows), delta_partials);
@@ -198,7 +201,7 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
 
 template <typename T, typename PT>
 int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, const int32_t *long_rows,
-                     int64_t n_long, int64_t row0, const T *Z_old, int64_t ldz, const T *X, int64_t ldx,
+                     int64_t n_long, int32_t waves_per_row, int64_t row0, const T *Z_old, int64_t ldz, const T *X, int64_t ldx,
                      typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d, double *delta_partials,
                      void *stream) {
     REQUIRE(n_long >= 0 && n_long <= INT32_MAX && row0 >= 0 && d > 0, "spmm_update_long: bad shape");
@@ -208,10 +211,16 @@ int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, 
             "spmm_update_long: null pointer");
     REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update_long: Z_new must not alias Z_old");
     const Layout L = pick_layout<T>(d, {Z_old, X, Z_new}, {ldz, ldx, ldo});
+    REQUIRE(waves_per_row == 4 || waves_per_row == kLongWaves, "spmm_update_long: waves_per_row must be 4 or 16");
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
-        constexpr int U = VEC > 1 ? 8 : 4;
-        spmm_long_kernel<T, PT, VEC, LPR, U, kLongWaves><<<int(n_long), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
-            rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, delta_partials);
+        constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
+        if (waves_per_row == 4)
+            spmm_long_kernel<T, PT, VEC, LPR, U, 4><<<int(n_long), 4 * kWave, 0, (hipStream_t)stream>>>(
+                rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, delta_partials);
+        else
+            spmm_long_kernel<T, PT, VEC, LPR, U, kLongWaves>
+                <<<int(n_long), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
+                    rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, delta_partials);
     });
     return check_launch("spmm_update_long");
 }
@@ -316,10 +325,10 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
                                   long_threshold, delta_partials, stream);                                            \
     }                                                                                                                 \
     int clane_spmm_update_long_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P,                       \
-                                     const int32_t *long_rows, int64_t n_long, int64_t row0, const CT *Z_old,         \
+                                     const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const CT *Z_old,         \
                                      int64_t ldz, const CT *X, int64_t ldx, GT gamma, CT *Z_new, int64_t ldo,         \
                                      int32_t d, double *delta_partials, void *stream) {                               \
-        return spmm_update_long<T, PT>(rowptr, colidx, P, long_rows, n_long, row0,                                    \
+        return spmm_update_long<T, PT>(rowptr, colidx, P, long_rows, n_long, waves_per_row, row0,                     \
                                        reinterpret_cast<const T *>(Z_old), ldz, reinterpret_cast<const T *>(X), ldx,  \
                                        gamma, reinterpret_cast<T *>(Z_new), ldo, d, delta_partials, stream);          \
     }

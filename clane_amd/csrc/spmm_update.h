@@ -15,64 +15,108 @@
 //  * U row loads are issued back-to-back before the first FMA consumes one, so every wave
 //    keeps U KiB of gathers in flight; edges past the end of a row are exec-masked loads
 //    (no traffic), never branches.
-//  * a workgroup owns `rows_per_block` CONSECUTIVE rows (its 4 waves interleave over them) and
-//    there are many more workgroups than CUs, so the hardware dispatcher balances skewed rows
-//    dynamically.  (A fixed grid striding rows by a power of two is pathological on R-MAT:
-//    stride 2^13 hands one wave every id with 13 trailing zero bits, i.e. the heaviest hubs.)
-//    One delta partial per workgroup, reduced later in index order: no float atomics anywhere.
+//  * a workgroup owns `rows_per_block` CONSECUTIVE rows and there are many more workgroups
+//    than CUs, so the hardware dispatcher balances skewed rows dynamically.  (A fixed grid
+//    striding rows by a power of two is pathological on R-MAT: stride 2^13 hands one wave
+//    every id with 13 trailing zero bits, i.e. the heaviest hubs.)
+//  * inside a workgroup: the block's rowptr slice is staged in LDS once; waves CLAIM rows from
+//    an LDS counter (a wave stuck on a 1000-edge row does not hold the others back), and the
+//    colidx / P of the next claimed row are requested before the current row's gathers, so a
+//    row costs one dependent memory round trip (its gathers), not three.
+//  * the L1 delta is kept per ROW in LDS and summed in row order at the end of the block, so
+//    the result does not depend on which wave claimed which row: one partial per workgroup,
+//    reduced later in index order -- bitwise reproducible, no float atomics anywhere.
 //  * rows longer than `long_threshold` edges are skipped here and done by spmm_long_kernel
 //    (one 16-wave workgroup per row, per-wave edge segments, fixed-order LDS fold).
 #pragma once
 
 #include "device_utils.h"
 
+#ifndef CLANE_SPMM_U
+#define CLANE_SPMM_U 8            // neighbour-row loads in flight per wave (16-byte path)
+#endif
+#ifndef CLANE_SPMM_DYNAMIC
+#define CLANE_SPMM_DYNAMIC 1      // waves claim rows from an LDS counter (0: static interleave)
+#endif
+#ifndef CLANE_SPMM_PREFETCH
+#define CLANE_SPMM_PREFETCH 1     // request the next row's colidx/P before gathering the current row
+#endif
+#ifndef CLANE_SPMM_MIN_WAVES
+#define CLANE_SPMM_MIN_WAVES 0    // __launch_bounds__ 2nd argument (waves per SIMD), 0 = unconstrained
+#endif
+
 namespace clane {
 
-// acc[k] += sum over edges e in [e0, e1) of P[e] * Z[colidx[e], col + k]  for this lane's pack.
-// `zcol` already includes the lane's column offset.  Must be called by all 64 lanes.
+constexpr int kMaxRowsPerBlock = 256;
+
+// First (<= 64-edge) chunk of a row's colidx / P, one edge per lane.
+template <typename A>
+struct EdgeChunk {
+    int c;
+    A p;
+};
+
+template <typename A, typename PT>
+__device__ __forceinline__ EdgeChunk<A> load_chunk(const int32_t *__restrict__ colidx, const PT *__restrict__ P,
+                                                   int64_t e, int64_t e1) {
+    EdgeChunk<A> ch{0, A(0)};
+    if (e + lane_id() < e1) {
+        ch.c = colidx[e + lane_id()];
+        ch.p = A(P[e + lane_id()]);
+    }
+    return ch;
+}
+
+// acc[k] += sum over the n (<= 64) edges held in `ch` of p * Z[c, col + k] for this lane's pack.
+template <typename T, int VEC, int LPR, int U>
+__device__ __forceinline__ void accumulate_chunk(const EdgeChunk<typename Elem<T>::acc_t> &ch, int n,
+                                                 const T *__restrict__ zcol, int64_t ldz, bool col_ok,
+                                                 typename Elem<T>::acc_t (&acc)[VEC]) {
+    using A = typename Elem<T>::acc_t;
+    constexpr int EPW = kWave / LPR;  // neighbour rows fetched by one wave-instruction
+    const int sub = lane_id() / LPR;
+    for (int j = 0; j < n; j += EPW * U) {
+        Pack<T, VEC> z[U];
+        A pj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = j + u * EPW + sub;
+            int cj;
+            A pv;
+            if constexpr (LPR == kWave) {
+                cj = lane_get_uniform(ch.c, idx & (kWave - 1));
+                pv = lane_get_uniform(ch.p, idx & (kWave - 1));
+            } else {
+                cj = lane_get(ch.c, idx & (kWave - 1));
+                pv = lane_get(ch.p, idx & (kWave - 1));
+            }
+            const bool in_row = idx < n;
+            pj[u] = in_row ? pv : A(0);
+            z[u] = Pack<T, VEC>{};
+            if (in_row && col_ok) z[u] = load_pack<T, VEC>(zcol + int64_t(cj) * ldz);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = fma(pj[u], Elem<T>::to_acc(z[u].v[k]), acc[k]);
+        }
+    }
+}
+
+// acc[k] += sum over edges e in [e0, e1) of P[e] * Z[colidx[e], col + k].  `first` holds the
+// chunk starting at e0 if `have_first` (prefetched by the caller).  Called by all 64 lanes.
 template <typename T, typename PT, int VEC, int LPR, int U>
 __device__ __forceinline__ void gather_accumulate(const int32_t *__restrict__ colidx, const PT *__restrict__ P,
                                                   int64_t e0, int64_t e1, const T *__restrict__ zcol, int64_t ldz,
-                                                  bool col_ok, typename Elem<T>::acc_t (&acc)[VEC]) {
+                                                  bool col_ok, typename Elem<T>::acc_t (&acc)[VEC],
+                                                  const EdgeChunk<typename Elem<T>::acc_t> &first, bool have_first) {
     using A = typename Elem<T>::acc_t;
-    constexpr int EPW = kWave / LPR;  // neighbour rows fetched by one wave-instruction
-    const int lane = lane_id();
-    const int sub = lane / LPR;
     for (int64_t e = e0; e < e1; e += kWave) {
         const int64_t left = e1 - e;
         const int n = left < kWave ? int(left) : kWave;
-        int c = 0;
-        A p = A(0);
-        if (lane < n) {
-            c = colidx[e + lane];
-            p = A(P[e + lane]);
-        }
-        for (int j = 0; j < n; j += EPW * U) {
-            Pack<T, VEC> z[U];
-            A pj[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = j + u * EPW + sub;
-                int cj;
-                A pv;
-                if constexpr (LPR == kWave) {
-                    cj = lane_get_uniform(c, idx & (kWave - 1));
-                    pv = lane_get_uniform(p, idx & (kWave - 1));
-                } else {
-                    cj = lane_get(c, idx & (kWave - 1));
-                    pv = lane_get(p, idx & (kWave - 1));
-                }
-                const bool in_row = idx < n;
-                pj[u] = in_row ? pv : A(0);
-                z[u] = Pack<T, VEC>{};
-                if (in_row && col_ok) z[u] = load_pack<T, VEC>(zcol + int64_t(cj) * ldz);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] = fma(pj[u], Elem<T>::to_acc(z[u].v[k]), acc[k]);
-            }
-        }
+        EdgeChunk<A> ch = first;
+        if (!(have_first && e == e0)) ch = load_chunk<A, PT>(colidx, P, e, e1);
+        accumulate_chunk<T, VEC, LPR, U>(ch, n, zcol, ldz, col_ok, acc);
     }
 }
 
@@ -86,61 +130,139 @@ __device__ __forceinline__ void fold_subwaves(A (&acc)[VEC]) {
     }
 }
 
+// Epilogue of one row's column tile; returns this lane's share of sum|z_new - z_old|.
+template <typename T, int VEC>
+__device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC> &x, const Pack<T, VEC> &zo,
+                                                               const typename Elem<T>::acc_t (&acc)[VEC],
+                                                               typename Elem<T>::acc_t gamma, bool has_edges,
+                                                               T *__restrict__ dst) {
+    using A = typename Elem<T>::acc_t;
+    Pack<T, VEC> out;
+    A rsum = A(0);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const A zold = Elem<T>::to_acc(zo.v[k]);
+        const A znew = has_edges ? Elem<T>::to_acc(x.v[k]) + gamma * acc[k] : zold;  // embedder.py:88-92
+        out.v[k] = Elem<T>::from_acc(znew);
+        rsum += fabs(Elem<T>::to_acc(out.v[k]) - zold);
+    }
+    store_pack<T, VEC>(dst, out);
+    return rsum;
+}
+
+#if CLANE_SPMM_MIN_WAVES > 0
+#define CLANE_SPMM_BOUNDS __launch_bounds__(kBlock, CLANE_SPMM_MIN_WAVES)
+#else
+#define CLANE_SPMM_BOUNDS __launch_bounds__(kBlock)
+#endif
+
 template <typename T, typename PT, int VEC, int LPR, int U>
-__global__ __launch_bounds__(kBlock) void spmm_update_kernel(
+__global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
     int rows_per_block, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
-    __shared__ double smem[kWavesPerBlock];
+    __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
+    __shared__ double s_rowsum[kMaxRowsPerBlock];
+    __shared__ int s_next;
+    __shared__ int s_done;
+
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sub = lane / LPR;
     const int sl = lane % LPR;
     const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
-    const int64_t row_end = row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows;
-    double dsum = 0.0;
+    const int nb = int((row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows) - row_begin);
 
-    for (int64_t r = row_begin + wave; r < row_end; r += kWavesPerBlock) {
-        const int64_t e0 = rowptr[r];
-        const int64_t e1 = rowptr[r + 1];
-        if (long_threshold > 0 && e1 - e0 > long_threshold) continue;
-        A rsum = A(0);
-        for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
-            const int c0 = t0 + sl * VEC;
-            const bool col_ok = c0 < d;
-            const bool writer = col_ok && sub == 0;
-            Pack<T, VEC> x{}, zo{};
-            if (writer) {
-                x = load_pack<T, VEC>(X + r * ldx + c0);
-                zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
-            }
-            A acc[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = A(0);
-            gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + c0, ldz, col_ok, acc);
-            fold_subwaves<LPR>(acc);
-            if (writer) {
-                Pack<T, VEC> out;
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    const A zold = Elem<T>::to_acc(zo.v[k]);
-                    const A znew = e1 > e0 ? Elem<T>::to_acc(x.v[k]) + gamma * acc[k] : zold;
-                    out.v[k] = Elem<T>::from_acc(znew);
-                    rsum += fabs(Elem<T>::to_acc(out.v[k]) - zold);
-                }
-                store_pack<T, VEC>(Znew + r * ldo + c0, out);
-            }
-        }
-        dsum += double(rsum);
+    for (int i = threadIdx.x; i <= nb; i += kBlock) s_rowptr[i] = rowptr[row_begin + i];
+    for (int i = threadIdx.x; i < nb; i += kBlock) s_rowsum[i] = 0.0;
+    if (threadIdx.x == 0) {
+        s_next = kWavesPerBlock;
+        s_done = 0;
     }
-    const double total = block_sum_fixed(dsum, smem);
-    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+    __syncthreads();
+
+    // next row of this block for the calling wave (wave-uniform)
+    auto claim = [&](int prev) -> int {
+#if CLANE_SPMM_DYNAMIC
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&s_next, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+#else
+        return prev + kWavesPerBlock;
+#endif
+    };
+
+    int cur = wave;
+    int64_t e0 = 0, e1 = 0;
+    EdgeChunk<A> ch{0, A(0)};
+    if (cur < nb) {
+        e0 = s_rowptr[cur];
+        e1 = s_rowptr[cur + 1];
+        ch = load_chunk<A, PT>(colidx, P, e0, e1);
+    }
+    while (cur < nb) {
+        const int nxt = claim(cur);
+        int64_t n0 = 0, n1 = 0;
+        EdgeChunk<A> chn{0, A(0)};
+        if (nxt < nb) {
+            n0 = s_rowptr[nxt];
+            n1 = s_rowptr[nxt + 1];
+#if CLANE_SPMM_PREFETCH
+            chn = load_chunk<A, PT>(colidx, P, n0, n1);
+#endif
+        }
+        if (!(long_threshold > 0 && e1 - e0 > long_threshold)) {
+            const int64_t r = row_begin + cur;
+            A rsum = A(0);
+            for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
+                const int c0 = t0 + sl * VEC;
+                const bool col_ok = c0 < d;
+                const bool writer = col_ok && sub == 0;
+                Pack<T, VEC> x{}, zo{};
+                if (writer) {
+                    x = load_pack<T, VEC>(X + r * ldx + c0);
+                    zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
+                }
+                A acc[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+                gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + c0, ldz, col_ok, acc, ch, true);
+                fold_subwaves<LPR>(acc);
+                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0);
+            }
+            rsum = group_sum<kWave>(rsum);
+            if (lane == 0) s_rowsum[cur] = double(rsum);
+        }
+        cur = nxt;
+        e0 = n0;
+        e1 = n1;
+#if CLANE_SPMM_PREFETCH
+        ch = chn;
+#else
+        if (cur < nb) ch = load_chunk<A, PT>(colidx, P, e0, e1);
+#endif
+    }
+    // No closing barrier: a wave that runs out of rows leaves (its slot goes to another workgroup);
+    // the LAST wave to arrive sums the per-row deltas in row order.  LDS is one in-order memory per
+    // CU, so every s_rowsum store issued before a wave's ticket is visible to the last ticket holder.
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's s_rowsum stores have landed
+    int ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&s_done, 1);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != kWavesPerBlock - 1) return;
+    double dsum = 0.0;
+    for (int i = lane; i < nb; i += kWave) dsum += s_rowsum[i];
+    dsum = group_sum<kWave>(dsum);
+    if (lane == 0) partials[blockIdx.x] = dsum;
 }
 
-// One workgroup of WAVES waves per long row: wave w gathers edge segment w, the segment sums
-// are folded through LDS in wave order (fixed order => reproducible), wave 0 writes the row.
+// One workgroup of WAVES waves per long row.  Wave w gathers the 64-aligned edge slice w; slices are
+// folded through LDS in wave order (fixed order => reproducible) and wave 0 writes the row.  A wave
+// whose slice is empty leaves at once: on AMD hardware s_barrier waits only for the waves of the
+// workgroup that have not terminated, so a 100-edge row costs two working waves, not sixteen
+// parked ones -- the same kernel serves 65-edge rows and 70k-edge hubs.
 template <typename T, typename PT, int VEC, int LPR, int U, int WAVES>
 __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P,
@@ -149,7 +271,6 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ A red[WAVES][kWave][VEC];
-    __shared__ double smem[WAVES];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sub = lane / LPR;
@@ -158,42 +279,45 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     const int64_t e0 = rowptr[r];
     const int64_t e1 = rowptr[r + 1];
     const int64_t seg = ceil_div(ceil_div(e1 - e0, WAVES), kWave) * kWave;
+    const int active = e1 > e0 ? int(ceil_div(e1 - e0, seg)) : 1;  // waves with a non-empty slice (wave 0 always stays)
+    if (wave >= active) return;
     const int64_t a = e0 + wave * seg;
     const int64_t b = a + seg < e1 ? a + seg : e1;
-    double dsum = 0.0;
+    const EdgeChunk<A> none{0, A(0)};
+    A rsum = A(0);
 
     for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
         const int c0 = t0 + sl * VEC;
         const bool col_ok = c0 < d;
+        const bool writer = wave == 0 && col_ok && sub == 0;
+        Pack<T, VEC> x{}, zo{};
+        if (writer) {  // requested before the gathers, consumed after the fold
+            x = load_pack<T, VEC>(X + r * ldx + c0);
+            zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
+        }
         A acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = A(0);
-        gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, a, b, Zold + c0, ldz, col_ok, acc);
+        gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, a, b, Zold + c0, ldz, col_ok, acc, none, false);
         fold_subwaves<LPR>(acc);
+        if (wave > 0) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) red[wave][lane][k] = acc[k];
-        __syncthreads();
-        if (wave == 0 && col_ok && sub == 0) {
-            const Pack<T, VEC> x = load_pack<T, VEC>(X + r * ldx + c0);
-            const Pack<T, VEC> zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
-            Pack<T, VEC> out;
-            A rsum = A(0);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                A tot = A(0);
-                for (int w = 0; w < WAVES; ++w) tot += red[w][lane][k];
-                const A zold = Elem<T>::to_acc(zo.v[k]);
-                const A znew = Elem<T>::to_acc(x.v[k]) + gamma * tot;
-                out.v[k] = Elem<T>::from_acc(znew);
-                rsum += fabs(Elem<T>::to_acc(out.v[k]) - zold);
-            }
-            store_pack<T, VEC>(Znew + r * ldo + c0, out);
-            dsum += double(rsum);
+            for (int k = 0; k < VEC; ++k) red[wave][lane][k] = acc[k];
         }
         __syncthreads();
+        if (writer) {
+            for (int w = 1; w < active; ++w) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
+            }
+            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0);
+        }
+        if (t0 + LPR * VEC < d) __syncthreads();  // red[] is reused by the next column tile
     }
-    const double total = block_sum_fixed(dsum, smem);
-    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+    if (wave == 0) {
+        rsum = group_sum<kWave>(rsum);
+        if (lane == 0) partials[blockIdx.x] = double(rsum);
+    }
 }
 
 }  // namespace clane

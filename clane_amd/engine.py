@@ -28,7 +28,22 @@ import torch
 from . import _hip
 from .partition import HostCSR, LocalCSR, RowPartition, localize
 
-DEFAULT_LONG_THRESHOLD = 1024
+# Rows are binned by out-degree once per graph.  Measured on R-MAT 2M/40M/d256 (MI355X): a single
+# wave walking a 65..1024-edge row streams at a fraction of what a multi-wave workgroup reaches,
+# and the 16-wave row-split kernel (idle waves exit at once) is the best streaming engine for
+# every row above ~32 gather steps (profiles/r01_threshold_sweep.md):
+#   deg <= T   one wave per row, rows claimed dynamically inside a workgroup  (spmm_update_kernel)
+#   deg >  T   16-wave workgroup per row, 64-aligned slices                    (spmm_long_kernel)
+# with T = 32 gather steps = 32 * (64 / lanes-per-row) edges.  A 4-wave bin (T < deg <= hub_threshold)
+# exists in the ABI and can be enabled with hub_threshold > long_threshold; it did not pay.
+DEFAULT_STEPS_PER_WAVE = 32
+HUB_FACTOR = 1
+
+
+def lanes_per_row(d: int, dtype: torch.dtype) -> int:
+    """Lanes that cover one row with 16-byte packs (mirrors pick_layout in csrc/clane_abi.hip)."""
+    packs = -(-d // _hip.VEC_ELEMS[dtype])
+    return 8 if packs <= 8 else 16 if packs <= 16 else 32 if packs <= 32 else 64
 
 
 def _round_up(a: int, b: int) -> int:
@@ -37,8 +52,8 @@ def _round_up(a: int, b: int) -> int:
 
 class SweepEngine:
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
-                 process_group=None, chunks: Optional[int] = None, long_threshold: int = DEFAULT_LONG_THRESHOLD,
-                 shuffle: Optional[bool] = None, seed: int = 0):
+                 process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
+                 hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0):
         if X.dim() != 2 or X.shape[0] != csr.num_vertices:
             raise ValueError(f"X must be [V, d] with V={csr.num_vertices}, got {tuple(X.shape)}")
         if cosine_mode not in ("reference", "per_edge"):
@@ -61,7 +76,10 @@ class SweepEngine:
         self.ld = _round_up(self.d, _hip.VEC_ELEMS[X.dtype])
         self.part = RowPartition.create(self.V, self.world, rank, chunks, shuffle=shuffle, seed=seed)
         self.local: LocalCSR = localize(csr, self.part)
+        if long_threshold is None:
+            long_threshold = DEFAULT_STEPS_PER_WAVE * (64 // lanes_per_row(self.d, X.dtype))
         self.long_threshold = int(long_threshold)
+        self.hub_threshold = int(hub_threshold) if hub_threshold is not None else HUB_FACTOR * self.long_threshold
         dev = self.device
 
         # ---- graph structure ----------------------------------------------------------
@@ -74,13 +92,19 @@ class SweepEngine:
         vc = self.part.rows_per_chunk
         deg = np.diff(self.local.rowptr)
         self.max_degree = int(deg.max()) if deg.size else 0
-        self.long_rows: List[Optional[torch.Tensor]] = []
+        self.long_rows: List[Optional[torch.Tensor]] = []     # every row above long_threshold (K1 slices these)
+        self.mid_rows: List[Optional[torch.Tensor]] = []      # long_threshold < deg <= hub_threshold: 4 waves/row
+        self.hub_rows: List[Optional[torch.Tensor]] = []      # deg > hub_threshold: 16 waves/row
         self.partial_off = [0]
+        to_dev = lambda a: torch.from_numpy(a.astype(np.int32)).to(dev) if a.size else None  # noqa: E731
         for c in range(self.part.chunks):
-            lr = np.nonzero(deg[c * vc:(c + 1) * vc] > self.long_threshold)[0].astype(np.int32) \
-                if self.long_threshold > 0 else np.empty(0, np.int32)
-            self.long_rows.append(torch.from_numpy(lr).to(dev) if lr.size else None)
-            self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(vc, int(lr.size)))
+            dc = deg[c * vc:(c + 1) * vc]
+            is_long = dc > self.long_threshold if self.long_threshold > 0 else np.zeros_like(dc, dtype=bool)
+            is_hub = is_long & (dc > self.hub_threshold)
+            self.long_rows.append(to_dev(np.nonzero(is_long)[0]))
+            self.mid_rows.append(to_dev(np.nonzero(is_long & ~is_hub)[0]))
+            self.hub_rows.append(to_dev(np.nonzero(is_hub)[0]))
+            self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(vc, int(is_long.sum())))
         self.partials = torch.zeros(self.partial_off[-1], dtype=torch.float64, device=dev)
 
         # ---- embeddings ---------------------------------------------------------------
@@ -166,17 +190,25 @@ class SweepEngine:
             rp, Xc, Zn = self.rowptr[c * vc:], self.X_loc[c * vc:(c + 1) * vc], Znew[r0:r0 + vc]
             po = self.partial_off[c]
             ev = self._events(c) if self.time_kernels else None
+            # hubs first (longest tail), then mid rows, then the one-wave-per-row pass
+            po_mid = po + k.spmm_partials_len(vc, 0)
+            po_hub = po_mid + (0 if self.mid_rows[c] is None else self.mid_rows[c].numel())
             if ev:
                 ev[0].record()
+            if self.hub_rows[c] is not None:
+                k.spmm_update_long(rp, self.colidx, self.P, self.hub_rows[c], 16, r0, Zold, Xc, gamma, Zn, self.d,
+                                   self.partials[po_hub:])
+            if ev:
+                ev[1].record()
+            if self.mid_rows[c] is not None:
+                k.spmm_update_long(rp, self.colidx, self.P, self.mid_rows[c], 4, r0, Zold, Xc, gamma, Zn, self.d,
+                                   self.partials[po_mid:])
+            if ev:
+                ev[2].record()
             k.spmm_update(rp, self.colidx, self.P, vc, r0, Zold, Xc, gamma, Zn, self.d, self.long_threshold,
                           self.partials[po:])
             if ev:
-                ev[1].record()
-            if self.long_rows[c] is not None:
-                k.spmm_update_long(rp, self.colidx, self.P, self.long_rows[c], r0, Zold, Xc, gamma, Zn, self.d,
-                                   self.partials[po + self.k.spmm_partials_len(vc, 0):])
-            if ev:
-                ev[2].record()
+                ev[3].record()
             if self.world > 1:
                 import torch.distributed as dist
                 b, e = part.chunk_span(c)
@@ -190,23 +222,27 @@ class SweepEngine:
         return float(self.delta.item())
 
     def _events(self, c: int):
-        ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+        ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
         self.kernel_events.append((c,) + ev)
         return ev
 
     def kernel_times_ms(self):
-        """(main-pass ms, long-row-pass ms) per recorded launch; call after a synchronize."""
-        out = [(a.elapsed_time(b), b.elapsed_time(e)) for _, a, b, e in self.kernel_events]
+        """{'hub','mid','main'} -> mean ms per launch over the recorded sweeps; call after a synchronize."""
+        t = np.array([(a.elapsed_time(b), b.elapsed_time(m), m.elapsed_time(e))
+                      for _, a, b, m, e in self.kernel_events]).reshape(-1, 3)
         self.kernel_events = []
-        return out
+        return dict(zip(("hub", "mid", "main"), t.mean(0).tolist())) if len(t) else {}
 
-    def main_pass_bytes(self) -> int:
-        """Algorithmic bytes (section 8d gather model) of the rows the MAIN kernel handles."""
+    def kernel_bytes(self):
+        """Algorithmic bytes per SWEEP of each K3 kernel (SURVEY.md section 8d gather model, split by the
+        rows each kernel owns): per row  deg*(d*s + 4 + sizeof P) + 3*d*s + 8."""
         s, ps = self.Zcur.element_size(), self.P.element_size()
         deg = np.diff(self.local.rowptr)
-        keep = deg <= self.long_threshold if self.long_threshold > 0 else np.ones_like(deg, dtype=bool)
-        E, n = int(deg[keep].sum()), self.part.n_local
-        return E * self.d * s + E * (4 + ps) + (n + 1) * 8 + 3 * int(keep.sum()) * self.d * s
+        per_row = deg * (self.d * s + 4 + ps) + 3 * self.d * s + 8
+        is_long = deg > self.long_threshold if self.long_threshold > 0 else np.zeros_like(deg, dtype=bool)
+        is_hub = is_long & (deg > self.hub_threshold)
+        return {"main": int(per_row[~is_long].sum()) + 8, "mid": int(per_row[is_long & ~is_hub].sum()),
+                "hub": int(per_row[is_hub].sum())}
 
     # ---- outer-loop delta (embedder.py:58-60) -------------------------------------------
     def snapshot(self) -> None:

@@ -107,9 +107,12 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
  * Z_new must not alias Z_old.
  *  clane_spmm_update_*      : one wave per row over a fixed grid; rows with more than `long_threshold`
  *                             edges (0 = never) are skipped.  Writes clane_spmm_partials_len(nrows, 0) doubles.
- *  clane_spmm_update_long_* : the skipped rows, one 16-wave workgroup per row; `long_rows` holds their
- *                             local row ids (the caller builds the list once per graph).  Writes n_long doubles.
- * The two touch disjoint rows of Z_new and may run on different streams. */
+ *  clane_spmm_update_long_* : the skipped rows, one workgroup of `waves_per_row` (4 or 16) waves per row,
+ *                             each wave gathering a 64-aligned slice of the row, slices folded in wave
+ *                             order; `long_rows` holds the local row ids (the caller bins rows by degree
+ *                             once per graph: 4 waves suit rows of up to a few hundred edges, 16 the
+ *                             hubs).  Writes n_long doubles.
+ * Calls touch disjoint rows of Z_new and may run on different streams. */
 int clane_spmm_update_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
                           const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
                           int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials, void *stream);
@@ -121,15 +124,15 @@ int clane_spmm_update_bf16(const int64_t *rowptr, const int32_t *colidx, const f
                            uint16_t *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials,
                            void *stream);
 int clane_spmm_update_long_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, const int32_t *long_rows,
-                               int64_t n_long, int64_t row0, const float *Z_old, int64_t ldz, const float *X,
+                               int64_t n_long, int32_t waves_per_row, int64_t row0, const float *Z_old, int64_t ldz, const float *X,
                                int64_t ldx, float gamma, float *Z_new, int64_t ldo, int32_t d, double *delta_partials,
                                void *stream);
 int clane_spmm_update_long_f64(const int64_t *rowptr, const int32_t *colidx, const double *P,
-                               const int32_t *long_rows, int64_t n_long, int64_t row0, const double *Z_old,
+                               const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const double *Z_old,
                                int64_t ldz, const double *X, int64_t ldx, double gamma, double *Z_new, int64_t ldo,
                                int32_t d, double *delta_partials, void *stream);
 int clane_spmm_update_long_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P,
-                                const int32_t *long_rows, int64_t n_long, int64_t row0, const uint16_t *Z_old,
+                                const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const uint16_t *Z_old,
                                 int64_t ldz, const uint16_t *X, int64_t ldx, float gamma, uint16_t *Z_new,
                                 int64_t ldo, int32_t d, double *delta_partials, void *stream);
 

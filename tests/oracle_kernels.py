@@ -76,7 +76,9 @@ class OracleKernels:
         partials[:n] = 0
         partials[0] = self._spmm_rows(rowptr, colidx, P, sel, row0, Z_old, X, gamma, Z_new, d)
 
-    def spmm_update_long(self, rowptr, colidx, P, long_rows, row0, Z_old, X, gamma, Z_new, d, partials):
+    def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row, row0, Z_old, X, gamma, Z_new, d,
+                         partials):
+        assert waves_per_row in (4, 16)
         for i, r in enumerate(long_rows.tolist()):
             partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d)
 

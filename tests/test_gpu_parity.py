@@ -165,18 +165,18 @@ def test_segment_softmax_edge_cases(dev, k):
         assert torch.allclose(sums[deg > 0], torch.ones(int((deg > 0).sum()), dtype=torch.float64), atol=1e-5)
 
 
-def run_sweep(k, rowptr, colidx, P, V, Zo, X, gamma, Zn, d, long_threshold, long_rows, partials):
+def run_sweep(k, rowptr, colidx, P, V, Zo, X, gamma, Zn, d, long_threshold, long_rows, partials, waves=16):
     k.spmm_update(rowptr, colidx, P, V, 0, Zo, X, gamma, Zn, d, long_threshold, partials)
     if long_rows is not None and long_rows.numel():
-        k.spmm_update_long(rowptr, colidx, P, long_rows, 0, Zo, X, gamma, Zn, d,
+        k.spmm_update_long(rowptr, colidx, P, long_rows, waves, 0, Zo, X, gamma, Zn, d,
                            partials[k.spmm_partials_len(V, 0):])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
 @pytest.mark.parametrize("d,pad", [(2, True), (16, True), (64, True), (128, True), (256, True), (300, True),
                                    (1433, True), (1433, False), (5, False)])
-@pytest.mark.parametrize("long_threshold", [0, 48])
-def test_spmm_update_vs_oracle(dev, k, dtype, d, pad, long_threshold):
+@pytest.mark.parametrize("long_threshold,waves", [(0, 16), (48, 16), (48, 4)])
+def test_spmm_update_vs_oracle(dev, k, dtype, d, pad, long_threshold, waves):
     csr = ragged_csr(600, seed=d + 1, hubs=(64, 65, 200, 600, 1))
     V = csr.num_vertices
     acc = _hip.acc_dtype(dtype)
@@ -197,7 +197,7 @@ def test_spmm_update_vs_oracle(dev, k, dtype, d, pad, long_threshold):
     partials = torch.full((k.spmm_partials_len(V, n_long),), float("nan"), dtype=torch.float64, device=dev)
     out = torch.zeros(1, dtype=torch.float64, device=dev)
 
-    run_sweep(k, rowptr, colidx, P.to(dev), V, Zo, Xd, gamma, Zn, d, long_threshold, long_rows, partials)
+    run_sweep(k, rowptr, colidx, P.to(dev), V, Zo, Xd, gamma, Zn, d, long_threshold, long_rows, partials, waves)
     k.reduce_partials(partials, partials.numel(), out)
     Z_ref, _ = O.sweep(csr.rowptr, csr.colidx, P.double(), X.double(), Zold.double(), gamma)
     got = Zn[:, :d].cpu()
@@ -213,7 +213,7 @@ def test_spmm_update_vs_oracle(dev, k, dtype, d, pad, long_threshold):
     # bitwise reproducible: fixed-order partials, no atomics
     Zn2 = torch.zeros_like(Zn)
     partials2 = torch.zeros_like(partials)
-    run_sweep(k, rowptr, colidx, P.to(dev), V, Zo, Xd, gamma, Zn2, d, long_threshold, long_rows, partials2)
+    run_sweep(k, rowptr, colidx, P.to(dev), V, Zo, Xd, gamma, Zn2, d, long_threshold, long_rows, partials2, waves)
     assert torch.equal(Zn2[:, :d], Zn[:, :d]) and torch.equal(partials, partials2)
 
 
@@ -348,7 +348,7 @@ def test_rmat_200k_parity_and_properties(dev):
     assert csr.num_edges == E and int(np.diff(csr.rowptr).max()) > 1024       # has hub rows -> long-row pass
     X = synth.gaussian_X(V, d, seed=2)
     eng = SweepEngine(csr, X, dev)
-    assert any(lr is not None for lr in eng.long_rows)
+    assert eng.hub_rows[0] is not None and eng.mid_rows[0] is not None
     eng.build_P()
     P_or = O.build_P_values(csr.rowptr, csr.colidx, X)
     assert rel(eng.P[:E], P_or) < 1e-5

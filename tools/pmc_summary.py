@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs into profiles/: per-kernel time (kernel-trace stats) and HBM-side
+traffic from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in SEPARATE runs, KiB units).
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of a
+16-B-per-lane coalesced read.  The factor is calibrated, not assumed: bench.py --calibrate
+launches l1_distance_kernel over two [V, ld] matrices whose byte count is known.
+
+    python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE \
+        --known-bytes 4096000000 --tag r01 --workload rmat2m_n1 [--stats gpurun_out/prof1]
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+from pathlib import Path
+
+
+def per_kernel(dirname):
+    f = glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "clane::" in r["Kernel_Name"]:
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[name].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    return {k: (sum(a for a, _ in v) / len(v), sum(t for _, t in v) / len(v) / 1e3, len(v)) for k, v in agg.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir")
+    ap.add_argument("write_dir")
+    ap.add_argument("--known-bytes", type=float, required=True, help="bytes read by l1_distance_kernel")
+    ap.add_argument("--tag", default="r01")
+    ap.add_argument("--workload", default="rmat2m_n1")
+    ap.add_argument("--stats", default=None)
+    args = ap.parse_args()
+    out = Path(__file__).resolve().parent.parent / "profiles"
+    out.mkdir(exist_ok=True)
+    fetch, write = per_kernel(args.fetch_dir), per_kernel(args.write_dir)
+    cal = [k for k in fetch if "l1_distance_kernel" in k][0]
+    factor = args.known_bytes / (fetch[cal][0] * 1024)
+    lines = [f"# HBM-side traffic per launch, {args.workload} ({args.tag})", "",
+             f"FETCH_SIZE calibration on `{cal}`: known {args.known_bytes:.4g} B / counted "
+             f"{fetch[cal][0] * 1024:.4g} B = **x{factor:.4f}** (guide: exactly 2 for 16 B/lane reads). "
+             "WRITE_SIZE is taken as exact.", "",
+             "| kernel | launches | avg us (under PMC) | fetch GB (corrected) | write GB | total GB | GB/s |",
+             "|---|---|---|---|---|---|---|"]
+    summary = {}
+    for k in fetch:
+        fb = fetch[k][0] * 1024 * factor
+        wb = write.get(k, (0, 0, 0))[0] * 1024
+        us = fetch[k][1]
+        lines.append(f"| `{k}` | {fetch[k][2]} | {us:.1f} | {fb / 1e9:.3f} | {wb / 1e9:.3f} | {(fb + wb) / 1e9:.3f} | "
+                     f"{(fb + wb) / us / 1e3:.0f} |")
+        summary[k] = {"fetch_bytes": fb, "write_bytes": wb, "avg_us_under_pmc": us}
+    (out / f"{args.tag}_pmc_traffic_{args.workload}.md").write_text("\n".join(lines) + "\n")
+    main_k = [k for k in fetch if "spmm_update_kernel" in k][0]
+    tfile = out / "traffic.json"
+    data = json.loads(tfile.read_text()) if tfile.exists() else {}
+    data[args.workload] = {"kernel": main_k, "bytes_per_launch": summary[main_k]["fetch_bytes"] + summary[main_k]["write_bytes"],
+                           "fetch_correction": factor, "source": f"profiles/{args.tag}_pmc_traffic_{args.workload}.md"}
+    tfile.write_text(json.dumps(data, indent=1) + "\n")
+    if args.stats:
+        f = glob.glob(f"{args.stats}/**/*kernel_stats.csv", recursive=True)[0]
+        rows = list(csv.DictReader(open(f)))
+        sl = [f"# rocprofv3 --kernel-trace --stats, {args.workload} ({args.tag})", "",
+              "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+        for r in rows[:12]:
+            sl.append(f"| `{r['Name'].split('(')[0][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | "
+                      f"{float(r['TotalDurationNs']) / 1e6:.2f} | {r['Percentage']} |")
+        (out / f"{args.tag}_kernel_stats_{args.workload}.md").write_text("\n".join(sl) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
