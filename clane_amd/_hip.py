@@ -21,6 +21,7 @@ LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
 ABI_VERSION = 1
 
 SCORE_REFERENCE, SCORE_PER_EDGE, SCORE_RAW_DOT = 0, 1, 2
+SPMM_SINKS_UNTOUCHED = 1
 SCORE_MODES = {"reference": SCORE_REFERENCE, "per_edge": SCORE_PER_EDGE, "raw_dot": SCORE_RAW_DOT}
 
 _p, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
@@ -39,7 +40,7 @@ for _s in ("f32", "f64", "bf16"):
         C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _i64, _p])
     _g = C.c_double if _s == "f64" else C.c_float
     SIGNATURES[f"clane_spmm_update_{_s}"] = (
-        C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _p, _p])
+        C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _i32, _p, _p])
     SIGNATURES[f"clane_spmm_update_long_{_s}"] = (
         C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p])
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
@@ -161,8 +162,9 @@ class HipKernels:
 
     # -- K3 -----------------------------------------------------------------------------
     def spmm_update(self, rowptr, colidx, P, nrows: int, row0: int, Z_old, X, gamma: float, Z_new, d: int,
-                    long_threshold: int, partials):
-        """Main pass: every row of <= long_threshold edges (0 = all rows)."""
+                    long_threshold: int, partials, sinks_untouched: bool = False):
+        """Main pass: every row of <= long_threshold edges (0 = all rows).  With `sinks_untouched` rows
+        without out-edges are neither read nor written (caller keeps Z_new == Z_old there)."""
         zo, ldz = _mat(Z_old, "Z_old")
         xp, ldx = _mat(X, "X")
         zn, ldo = _mat(Z_new, "Z_new")
@@ -171,7 +173,8 @@ class HipKernels:
         self._check(self._fn("clane_spmm_update", Z_old.dtype)(
             _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
             _vec(P, acc_dtype(Z_old.dtype), "P"), nrows, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
-            long_threshold, _vec(partials, torch.float64, "partials"), self._stream(Z_old)), "clane_spmm_update")
+            long_threshold, SPMM_SINKS_UNTOUCHED if sinks_untouched else 0, _vec(partials, torch.float64, "partials"),
+            self._stream(Z_old)), "clane_spmm_update")
 
     def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row: int, row0: int, Z_old, X, gamma: float,
                          Z_new, d: int, partials):

@@ -179,7 +179,7 @@ inline int64_t spmm_main_grid(int64_t nrows) { return row_grid(nrows); }
 template <typename T, typename PT>
 int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows, int64_t row0,
                 const T *Z_old, int64_t ldz, const T *X, int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new,
-                int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials, void *stream) {
+                int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, double *delta_partials, void *stream) {
     REQUIRE(nrows >= 0 && row0 >= 0 && d > 0, "spmm_update: bad shape nrows=%lld row0=%lld d=%d", (long long)nrows,
             (long long)row0, d);
     REQUIRE(ldz >= d && ldx >= d && ldo >= d, "spmm_update: leading dimension < d");
@@ -194,7 +194,7 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
         constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
         spmm_update_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
             rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-            rows_per_block(nrows), delta_partials);
+            (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), delta_partials);
     });
     return check_launch("spmm_update");
 }
@@ -318,11 +318,12 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
 #define CLANE_SPMM_WRAPPERS(SUF, CT, T, PT, GT)                                                                        \
     int clane_spmm_update_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows,             \
                                 int64_t row0, const CT *Z_old, int64_t ldz, const CT *X, int64_t ldx, GT gamma,       \
-                                CT *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials,    \
+                                CT *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags,             \
+                                double *delta_partials,                                                               \
                                 void *stream) {                                                                       \
         return spmm_update<T, PT>(rowptr, colidx, P, nrows, row0, reinterpret_cast<const T *>(Z_old), ldz,            \
                                   reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new), ldo, d,   \
-                                  long_threshold, delta_partials, stream);                                            \
+                                  long_threshold, flags, delta_partials, stream);                                     \
     }                                                                                                                 \
     int clane_spmm_update_long_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P,                       \
                                      const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const CT *Z_old,         \

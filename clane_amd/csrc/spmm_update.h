@@ -161,7 +161,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    int rows_per_block, double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
     __shared__ double s_rowsum[kMaxRowsPerBlock];
@@ -213,7 +213,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
             chn = load_chunk<A, PT>(colidx, P, n0, n1);
 #endif
         }
-        if (!(long_threshold > 0 && e1 - e0 > long_threshold)) {
+        if (!(long_threshold > 0 && e1 - e0 > long_threshold) && !(skip_sinks && e1 == e0)) {
             const int64_t r = row_begin + cur;
             A rsum = A(0);
             for (int t0 = 0; t0 < d; t0 += LPR * VEC) {

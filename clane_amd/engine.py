@@ -142,7 +142,10 @@ class SweepEngine:
             raise ValueError(f"set_Z: expected {(self.V, self.d)}, got {tuple(Z.shape)}")
         full = torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype)
         full[self.pos, :self.d] = Z.detach().to("cpu", self.dtype)
-        self.Zcur.copy_(full)
+        # BOTH ping-pong buffers: rows without out-edges never change (embedder.py:88-89), so the sweep
+        # kernel leaves them alone (CLANE_SPMM_SINKS_UNTOUCHED) and relies on the two copies agreeing.
+        for buf in self.Zbuf:
+            buf.copy_(full)
         self.P_valid = False
 
     def get_Z(self) -> torch.Tensor:
@@ -206,7 +209,7 @@ class SweepEngine:
             if ev:
                 ev[2].record()
             k.spmm_update(rp, self.colidx, self.P, vc, r0, Zold, Xc, gamma, Zn, self.d, self.long_threshold,
-                          self.partials[po:])
+                          self.partials[po:], sinks_untouched=True)
             if ev:
                 ev[3].record()
             if self.world > 1:
@@ -238,7 +241,7 @@ class SweepEngine:
         rows each kernel owns): per row  deg*(d*s + 4 + sizeof P) + 3*d*s + 8."""
         s, ps = self.Zcur.element_size(), self.P.element_size()
         deg = np.diff(self.local.rowptr)
-        per_row = deg * (self.d * s + 4 + ps) + 3 * self.d * s + 8
+        per_row = deg * (self.d * s + 4 + ps) + np.where(deg > 0, 3 * self.d * s, 0) + 8   # sinks: rowptr only
         is_long = deg > self.long_threshold if self.long_threshold > 0 else np.zeros_like(deg, dtype=bool)
         is_hub = is_long & (deg > self.hub_threshold)
         return {"main": int(per_row[~is_long].sum()) + 8, "mid": int(per_row[is_long & ~is_hub].sum()),

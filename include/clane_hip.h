@@ -49,6 +49,9 @@ extern "C" {
 #define CLANE_SCORE_PER_EDGE 1  /* dot / (||z_src|| * ||z_dst||)                 -- what its docstring describes  */
 #define CLANE_SCORE_RAW_DOT 2   /* dot                                           -- stage test                     */
 
+/* flags of clane_spmm_update_* */
+#define CLANE_SPMM_SINKS_UNTOUCHED 1
+
 int clane_abi_version(void);
 const char *clane_last_error(void);
 
@@ -105,8 +108,11 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
  *     Z_new[i,:] = Z_old[row0+i,:]                                       if the row has no out-edge (embedder.py:88-89)
  *     delta_partials[b] = partial sums of |Z_new[i,:] - Z_old[row0+i,:]| (fixed order; reduce with clane_reduce_partials)
  * Z_new must not alias Z_old.
- *  clane_spmm_update_*      : one wave per row over a fixed grid; rows with more than `long_threshold`
- *                             edges (0 = never) are skipped.  Writes clane_spmm_partials_len(nrows, 0) doubles.
+ *  clane_spmm_update_*      : one wave per row; rows with more than `long_threshold` edges (0 = never)
+ *                             are skipped.  Writes clane_spmm_partials_len(nrows, 0) doubles.
+ *                             flags & CLANE_SPMM_SINKS_UNTOUCHED: rows without out-edges are neither read
+ *                             nor written -- the caller guarantees Z_new already equals Z_old there (they
+ *                             never change, so two ping-pong buffers initialised alike stay alike).
  *  clane_spmm_update_long_* : the skipped rows, one workgroup of `waves_per_row` (4 or 16) waves per row,
  *                             each wave gathering a 64-aligned slice of the row, slices folded in wave
  *                             order; `long_rows` holds the local row ids (the caller bins rows by degree
@@ -115,13 +121,13 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
  * Calls touch disjoint rows of Z_new and may run on different streams. */
 int clane_spmm_update_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
                           const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
-                          int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials, void *stream);
+                          int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, double *delta_partials, void *stream);
 int clane_spmm_update_f64(const int64_t *rowptr, const int32_t *colidx, const double *P, int64_t nrows, int64_t row0,
                           const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma, double *Z_new,
-                          int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials, void *stream);
+                          int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, double *delta_partials, void *stream);
 int clane_spmm_update_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
                            const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
-                           uint16_t *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, double *delta_partials,
+                           uint16_t *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, double *delta_partials,
                            void *stream);
 int clane_spmm_update_long_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, const int32_t *long_rows,
                                int64_t n_long, int32_t waves_per_row, int64_t row0, const float *Z_old, int64_t ldz, const float *X,

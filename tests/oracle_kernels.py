@@ -68,10 +68,12 @@ class OracleKernels:
             total += float((new.to(acc) - own.to(acc)).abs().sum())
         return total
 
-    def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials):
+    def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials,
+                    sinks_untouched=False):
         rp = _np(rowptr[:nrows + 1])
         deg = np.diff(rp)
-        sel = [r for r in range(nrows) if not (long_threshold > 0 and deg[r] > long_threshold)]
+        sel = [r for r in range(nrows) if not (long_threshold > 0 and deg[r] > long_threshold)
+               and not (sinks_untouched and deg[r] == 0)]
         n = self.spmm_partials_len(nrows, 0)
         partials[:n] = 0
         partials[0] = self._spmm_rows(rowptr, colidx, P, sel, row0, Z_old, X, gamma, Z_new, d)

@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: two `gloo` ranks run the row-partitioned SweepEngine (chunk-major layout,
+in-place all-gather per chunk, scalar all-reduce) with the oracle-backed test double as kernels,
+and every rank must reproduce the single-process oracle."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, chunks, name, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clane_amd.embedder import Embedder
+        from clane_amd.engine import SweepEngine
+        from clane_amd.graph import Graph
+        from clane_amd.similarity import CosineSimilarity
+        from oracle import clane_oracle as O
+        from tests.conftest import load_golden, write_data_root
+        from tests.oracle_kernels import OracleKernels
+
+        gold = load_golden(name)
+        k = load_golden("g2_karate_csr.npz")
+        src, dst = (gold["edge_src"], gold["edge_dst"]) if "edge_src" in gold.files else (k["edge_src"], k["edge_dst"])
+        root = write_data_root(Path(out_dir) / f"r{rank}", k["vertex_ids"], src, dst, gold["X"])
+        g = Graph(root)
+        eng = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), process_group=dist.group.WORLD, chunks=chunks, seed=3)
+        g._attach_engine(eng)
+        assert eng.world == world and eng.part.perm is not None          # shuffled partition by default for N > 1
+
+        # build_P: every rank assembles the full P in the reference's (row, col) order
+        P = g.build_P(CosineSimilarity())
+        np.testing.assert_allclose(P.values().numpy(), gold["P0_values"], rtol=3e-6, atol=1e-7)
+
+        # sweeps: full Z on every rank after the in-place all-gather, global delta after the all-reduce
+        gamma = float(gold["gamma"])
+        rowptr, colidx = g.csr.rowptr, g.csr.colidx
+        X = torch.from_numpy(gold["X"])
+        P_or = O.build_P_values(rowptr, colidx, X)
+        Z = X.clone()
+        for _ in range(4):
+            delta = eng.sweep(gamma)
+            Z, d_or = O.sweep(rowptr, colidx, P_or, X, Z, gamma)
+            assert abs(delta - float(d_or)) <= 1e-5 * max(1.0, float(d_or))
+            assert O.rel_l2(eng.get_Z(), Z) < 1e-6
+        # both ping-pong buffers agree on rows without out-edges (CLANE_SPMM_SINKS_UNTOUCHED invariant)
+        sink_pos = eng.pos[torch.from_numpy(np.diff(rowptr) == 0)]
+        assert torch.equal(eng.Zbuf[0][sink_pos], eng.Zbuf[1][sink_pos])
+
+        # full Embedder control flow on top: identical decisions on every rank, final Z = reference
+        g2 = Graph(root)
+        g2._attach_engine(SweepEngine(g2.csr, g2.X, "cpu", OracleKernels(), process_group=dist.group.WORLD,
+                                      chunks=chunks, seed=3))
+        emb = Embedder(g2, CosineSimilarity(), torch.device("cpu"), gamma=gamma, tolerence=int(gold["tolerence"]),
+                       verbose=False)
+        emb.iterate()
+        assert O.rel_l2(g2.Z, torch.from_numpy(gold["Z_final"])) < 1e-6
+        counts = [None] * world
+        dist.all_gather_object(counts, emb.sweep_counts)
+        assert all(c == counts[0] for c in counts)
+        (Path(out_dir) / f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,chunks", [("g5_symkarate_d16_g0.76.npz", 1), ("g5_symkarate_d16_g0.76.npz", 3),
+                                         ("g4_karate_d2.npz", 2)])
+def test_two_rank_gloo_matches_reference(tmp_path, name, chunks):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), chunks, name, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))

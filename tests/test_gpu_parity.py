@@ -377,3 +377,23 @@ def test_rmat_200k_parity_and_properties(dev):
     lin = (full - X) - 2 * (half - X)
     nzc = torch.from_numpy(np.diff(csr.rowptr) > 0)
     assert float(lin[nzc].abs().max()) < 1e-4 * float(full.abs().max())
+
+
+def test_spmm_sinks_untouched_flag(dev, k):
+    """CLANE_SPMM_SINKS_UNTOUCHED: rows without out-edges are neither read nor written."""
+    csr = ragged_csr(300, seed=11, empty_frac=0.5)
+    V, d, gamma = 300, 256, 0.76
+    X, Zold = synth.gaussian_X(V, d, seed=1), synth.gaussian_X(V, d, seed=2)
+    P = O.build_P_values(csr.rowptr, csr.colidx, X.double()).float().to(dev)
+    rowptr, colidx = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    sink = torch.from_numpy(np.diff(csr.rowptr) == 0)
+    out = {}
+    for flag in (False, True):
+        Zn = torch.full((V, d), 7.0, device=dev)
+        partials = torch.zeros(k.spmm_partials_len(V, 0), dtype=torch.float64, device=dev)
+        k.spmm_update(rowptr, colidx, P, V, 0, Zold.to(dev), X.to(dev), gamma, Zn, d, 0, partials, sinks_untouched=flag)
+        out[flag] = (Zn.cpu(), partials.cpu())
+    assert torch.equal(out[False][0][sink], Zold[sink])                 # default: copied (embedder.py:88-89)
+    assert torch.equal(out[True][0][sink], torch.full((int(sink.sum()), d), 7.0))   # flag: left alone
+    assert torch.equal(out[False][0][~sink], out[True][0][~sink])
+    assert torch.equal(out[False][1], out[True][1])                     # sinks contribute 0 to the delta either way
