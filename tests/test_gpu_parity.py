@@ -347,7 +347,7 @@ def test_rmat_200k_parity_and_properties(dev):
     csr = synth.rmat_csr(V, E, seed=1)
     assert csr.num_edges == E and int(np.diff(csr.rowptr).max()) > 1024       # has hub rows -> long-row pass
     X = synth.gaussian_X(V, d, seed=2)
-    eng = SweepEngine(csr, X, dev)
+    eng = SweepEngine(csr, X, dev, long_threshold=64, hub_threshold=256)      # exercise all three K3 kernels
     assert eng.hub_rows[0] is not None and eng.mid_rows[0] is not None
     eng.build_P()
     P_or = O.build_P_values(csr.rowptr, csr.colidx, X)

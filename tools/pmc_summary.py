@@ -56,11 +56,20 @@ def main():
                      f"{(fb + wb) / us / 1e3:.0f} |")
         summary[k] = {"fetch_bytes": fb, "write_bytes": wb, "avg_us_under_pmc": us}
     (out / f"{args.tag}_pmc_traffic_{args.workload}.md").write_text("\n".join(lines) + "\n")
-    main_k = [k for k in fetch if "spmm_update_kernel" in k][0]
+    def bench_name(k):       # names used by bench.py's roofline.kernels
+        if "spmm_update_kernel" in k:
+            return "spmm_update_kernel"
+        if "spmm_long_kernel" in k:
+            return f"spmm_long_kernel<{k.rstrip('>').split(',')[-1].strip()} waves>"
+        return None
+
     tfile = out / "traffic.json"
     data = json.loads(tfile.read_text()) if tfile.exists() else {}
-    data[args.workload] = {"kernel": main_k, "bytes_per_launch": summary[main_k]["fetch_bytes"] + summary[main_k]["write_bytes"],
-                           "fetch_correction": factor, "source": f"profiles/{args.tag}_pmc_traffic_{args.workload}.md"}
+    entry = {"fetch_correction": factor, "source": f"profiles/{args.tag}_pmc_traffic_{args.workload}.md"}
+    for k, v in summary.items():
+        if bench_name(k):
+            entry[bench_name(k)] = {"bytes_per_launch": v["fetch_bytes"] + v["write_bytes"], "rocprof_name": k}
+    data[args.workload] = entry
     tfile.write_text(json.dumps(data, indent=1) + "\n")
     if args.stats:
         f = glob.glob(f"{args.stats}/**/*kernel_stats.csv", recursive=True)[0]
