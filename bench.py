@@ -107,6 +107,7 @@ def main():
         f"thresholds {eng.long_threshold}/{eng.hub_threshold}")
 
     # build_P once (timed separately, not part of a step), P frozen afterwards
+    eng.build_P()                      # first call loads the code objects; time the second
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.build_P()

@@ -22,6 +22,8 @@ ABI_VERSION = 1
 
 SCORE_REFERENCE, SCORE_PER_EDGE, SCORE_RAW_DOT = 0, 1, 2
 SPMM_SINKS_UNTOUCHED = 1
+SCORE_FUSE_SOFTMAX = 1
+FUSED_SOFTMAX_MAX_DEGREE = 64
 SCORE_MODES = {"reference": SCORE_REFERENCE, "per_edge": SCORE_PER_EDGE, "raw_dot": SCORE_RAW_DOT}
 
 _p, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
@@ -32,12 +34,12 @@ SIGNATURES = {
     "clane_last_error": (C.c_char_p, []),
     "clane_spmm_partials_len": (_i64, [_i64, _i64]),
     "clane_reduce_ws_len": (_i64, []),
-    "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p]),
+    "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p, _p]),
 }
 for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_row_sqnorm_{_s}"] = (C.c_int, [_p, _i64, _i32, _i64, _p, _p])
     SIGNATURES[f"clane_edge_score_{_s}"] = (
-        C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i64, _i64, _p])
+        C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _i64, _p, _i64, _p])
     _g = C.c_double if _s == "f64" else C.c_float
     SIGNATURES[f"clane_spmm_update_{_s}"] = (
         C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _i32, _p, _p])
@@ -46,7 +48,7 @@ for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 for _s in ("f32", "f64"):
     SIGNATURES[f"clane_degree_weighted_sums_{_s}"] = (C.c_int, [_p, _p, _p, _i64, _p, _p, _p])
-    SIGNATURES[f"clane_segment_softmax_{_s}"] = (C.c_int, [_p, _i64, _p, _p])
+    SIGNATURES[f"clane_segment_softmax_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p])
     SIGNATURES[f"clane_pair_cosine_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 
 _SUFFIX = {torch.float32: "f32", torch.float64: "f64", torch.bfloat16: "bf16"}
@@ -146,18 +148,21 @@ class HipKernels:
 
     # -- K1 / K2 ------------------------------------------------------------------------
     def edge_score(self, rowptr, colidx, nrows: int, row0: int, Z, d: int, mode: int, sums2, sq, scores,
-                   long_threshold: int = 0, long_rows=None, max_long_degree: int = 0):
+                   long_threshold: int = 0, long_rows=None, fuse_softmax: bool = False):
         zp, ldz = _mat(Z, "Z")
         n_long = 0 if long_rows is None else long_rows.numel()
         self._check(self._fn("clane_edge_score", Z.dtype)(
             _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"), nrows, row0, zp, ldz, d, mode,
-            _ptr(sums2), _ptr(sq), _vec(scores, acc_dtype(Z.dtype), "scores"), long_threshold,
-            None if n_long == 0 else _vec(long_rows, torch.int32, "long_rows"), n_long, max_long_degree,
+            _ptr(sums2), _ptr(sq), _vec(scores, acc_dtype(Z.dtype), "scores"),
+            SCORE_FUSE_SOFTMAX if fuse_softmax else 0, long_threshold,
+            None if n_long == 0 else _vec(long_rows, torch.int32, "long_rows"), n_long,
             self._stream(Z)), "clane_edge_score")
 
-    def segment_softmax(self, rowptr, nrows: int, vals):
+    def segment_softmax(self, rowptr, nrows: int, vals, min_degree: int = 0, max_degree: int = 0, long_rows=None):
+        n_long = 0 if long_rows is None else long_rows.numel()
         self._check(self._fn("clane_segment_softmax", vals.dtype)(
-            _vec(rowptr, torch.int64, "rowptr"), nrows, vals.data_ptr(), self._stream(vals)),
+            _vec(rowptr, torch.int64, "rowptr"), nrows, vals.data_ptr(), min_degree, max_degree,
+            None if n_long == 0 else _vec(long_rows, torch.int32, "long_rows"), n_long, self._stream(vals)),
             "clane_segment_softmax")
 
     # -- K3 -----------------------------------------------------------------------------
@@ -191,9 +196,10 @@ class HipKernels:
             waves_per_row, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d, _vec(partials, torch.float64, "partials"),
             self._stream(Z_old)), "clane_spmm_update_long")
 
-    def reduce_partials(self, partials, n: int, out):
+    def reduce_partials(self, partials, n: int, ws, out):
         self._check(self.lib.clane_reduce_partials(
-            _vec(partials, torch.float64, "partials"), n, _vec(out, torch.float64, "out"), self._stream(out)),
+            _vec(partials, torch.float64, "partials"), n, _vec(ws, torch.float64, "ws"),
+            _vec(out, torch.float64, "out"), self._stream(out)),
             "clane_reduce_partials")
 
     def l1_distance(self, A, B, d: int, ws, out):

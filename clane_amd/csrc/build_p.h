@@ -75,23 +75,25 @@ __global__ __launch_bounds__(1024) void reduce_fixed_kernel(const double *__rest
     }
 }
 
-// ---- K2 ------------------------------------------------------------------------------------
-template <typename A>
-__device__ __forceinline__ A exp_acc(A v);
-template <>
-__device__ __forceinline__ float exp_acc<float>(float v) {
-    return expf(v);
-}
-template <>
-__device__ __forceinline__ double exp_acc<double>(double v) {
-    return exp(v);
+// ws[b] = sum of in[b*slice, min(n, (b+1)*slice)) in a fixed order -- first stage of a long reduction.
+__global__ __launch_bounds__(kBlock) void reduce_slices_kernel(const double *__restrict__ in, int64_t n, int64_t slice,
+                                                               double *__restrict__ ws) {
+    __shared__ double smem[kWavesPerBlock];
+    const int64_t a = int64_t(blockIdx.x) * slice;
+    const int64_t b = a + slice < n ? a + slice : n;
+    double s = 0.0;
+    for (int64_t i = a + threadIdx.x; i < b; i += kBlock) s += in[i];
+    const double t = block_sum_fixed(s, smem);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
 }
 
+// ---- K2 ------------------------------------------------------------------------------------
 // One wave per row; rows of <= 64 edges stay in registers, longer rows take three passes
 // over their (L2-resident) segment.
 template <typename A>
 __global__ __launch_bounds__(kBlock) void segment_softmax_kernel(const int64_t *__restrict__ rowptr, int64_t nrows,
-                                                                 A *__restrict__ vals, int rows_per_block) {
+                                                                 A *__restrict__ vals, int64_t min_degree,
+                                                                 int64_t max_degree, int rows_per_block) {
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(kBlock) void segment_softmax_kernel(const int64_t *
         const int64_t e0 = rowptr[r];
         const int64_t e1 = rowptr[r + 1];
         const int64_t deg = e1 - e0;
-        if (deg == 0) continue;
+        if (deg == 0 || deg <= min_degree) continue;  // short rows may already be normalised by K1
+        if (max_degree > 0 && deg > max_degree) continue;  // long rows: segment_softmax_long_kernel
         if (deg <= kWave) {
             const bool in = lane < deg;
             const A v = in ? vals[e0 + lane] : neg_inf;
@@ -122,6 +125,52 @@ __global__ __launch_bounds__(kBlock) void segment_softmax_kernel(const int64_t *
             for (int64_t e = e0 + lane; e < e1; e += kWave) vals[e] = exp_acc<A>(vals[e] - m) / s;
         }
     }
+}
+
+// One workgroup per long row (a single wave would walk a 70k-edge hub three times on its own):
+// workgroup max, workgroup sum of exp, normalise -- thread-strided passes over the (L2-resident)
+// segment, fixed-order LDS folds.
+template <typename A, int WAVES>
+__global__ __launch_bounds__(WAVES *kWave) void segment_softmax_long_kernel(const int64_t *__restrict__ rowptr,
+                                                                           const int32_t *__restrict__ long_rows,
+                                                                           A *__restrict__ vals, int64_t min_degree) {
+    __shared__ A smem[WAVES];
+    __shared__ A bcast;
+    const int64_t r = long_rows[blockIdx.x];
+    const int64_t e0 = rowptr[r];
+    const int64_t e1 = rowptr[r + 1];
+    if (e1 - e0 <= min_degree) return;
+    const int wave = threadIdx.x / kWave, lane = lane_id();
+    constexpr int T = WAVES * kWave;
+    A m = -A(INFINITY);
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += T) {
+        const A v = vals[e];
+        m = v > m ? v : m;
+    }
+    m = group_max<kWave>(m);
+    if (lane == 0) smem[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        A t = smem[0];
+        for (int w = 1; w < WAVES; ++w) t = smem[w] > t ? smem[w] : t;
+        bcast = t;
+    }
+    __syncthreads();
+    m = bcast;
+    A s = A(0);
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += T) s += exp_acc<A>(vals[e] - m);
+    s = group_sum<kWave>(s);
+    __syncthreads();
+    if (lane == 0) smem[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        A t = A(0);
+        for (int w = 0; w < WAVES; ++w) t += smem[w];
+        bcast = t;
+    }
+    __syncthreads();
+    s = bcast;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += T) vals[e] = exp_acc<A>(vals[e] - m) / s;
 }
 
 // ---- sum|A - B| (outer-loop delta, embedder.py:60) -------------------------------------------

@@ -136,41 +136,46 @@ int degree_weighted_sums(const A *sq, const int64_t *rowptr, const int32_t *inde
 template <typename T>
 int edge_score(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const T *Z, int64_t ldz,
                int32_t d, int32_t mode, const double *sums2, const typename Elem<T>::acc_t *sq,
-               typename Elem<T>::acc_t *scores, int64_t long_threshold, const int32_t *long_rows, int64_t n_long,
-               int64_t max_long_degree, void *stream) {
+               typename Elem<T>::acc_t *scores, int32_t flags, int64_t long_threshold, const int32_t *long_rows,
+               int64_t n_long, void *stream) {
     REQUIRE(nrows >= 0 && row0 >= 0 && d > 0 && ldz >= d, "edge_score: bad shape");
     REQUIRE(mode == CLANE_SCORE_REFERENCE || mode == CLANE_SCORE_PER_EDGE || mode == CLANE_SCORE_RAW_DOT,
             "edge_score: unknown mode %d", mode);
     REQUIRE(long_threshold >= 0 && n_long >= 0 && n_long <= INT32_MAX, "edge_score: bad long-row parameters");
-    REQUIRE(n_long == 0 || (long_rows && long_threshold > 0 && max_long_degree > long_threshold),
-            "edge_score: long_rows needs a list, a threshold and max_long_degree > threshold");
+    REQUIRE(n_long == 0 || (long_rows && long_threshold > 0), "edge_score: long_rows needs a list and a threshold");
     if (nrows == 0) return CLANE_OK;
     REQUIRE(rowptr && colidx && Z && scores, "edge_score: null pointer");
     REQUIRE(mode != CLANE_SCORE_REFERENCE || sums2, "edge_score: mode REFERENCE needs sums2");
     REQUIRE(mode != CLANE_SCORE_PER_EDGE || sq, "edge_score: mode PER_EDGE needs sq");
     const Layout L = pick_layout<T>(d, {Z}, {ldz});
+    const bool fuse = (flags & CLANE_SCORE_FUSE_SOFTMAX) != 0;
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? 8 : 4;
         edge_score_kernel<T, VEC, LPR, U><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(
-            rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, long_threshold, rows_per_block(nrows));
-        if (n_long > 0) {
-            constexpr int kEdgesPerWave = 256;
-            const int64_t slices = ceil_div(max_long_degree, int64_t(kLongWaves) * kEdgesPerWave);
+            rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, long_threshold, fuse,
+            rows_per_block(nrows));
+        if (n_long > 0)
             edge_score_long_kernel<T, VEC, LPR, U, kLongWaves>
-                <<<dim3(unsigned(n_long), unsigned(slices)), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
-                    rowptr, colidx, long_rows, row0, Z, ldz, d, mode, sums2, sq, scores, kEdgesPerWave);
-        }
+                <<<unsigned(n_long), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
+                    rowptr, colidx, long_rows, row0, Z, ldz, d, mode, sums2, sq, scores, fuse);
     });
     return check_launch("edge_score");
 }
 
 template <typename A>
-int segment_softmax(const int64_t *rowptr, int64_t nrows, A *vals, void *stream) {
-    REQUIRE(nrows >= 0, "segment_softmax: nrows < 0");
+int segment_softmax(const int64_t *rowptr, int64_t nrows, A *vals, int64_t min_degree, int64_t max_degree,
+                    const int32_t *long_rows, int64_t n_long, void *stream) {
+    REQUIRE(nrows >= 0 && min_degree >= 0 && max_degree >= 0 && n_long >= 0 && n_long <= INT32_MAX,
+            "segment_softmax: negative argument");
+    REQUIRE(n_long == 0 || (long_rows && max_degree > 0), "segment_softmax: long_rows needs a list and max_degree");
     if (nrows == 0) return CLANE_OK;
     REQUIRE(rowptr && vals, "segment_softmax: null pointer");
-    segment_softmax_kernel<A><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(rowptr, nrows, vals,
-                                                                                  rows_per_block(nrows));
+    if (!(max_degree > 0 && max_degree <= min_degree))
+        segment_softmax_kernel<A><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(
+            rowptr, nrows, vals, min_degree, max_degree, rows_per_block(nrows));
+    if (n_long > 0)
+        segment_softmax_long_kernel<A, kLongWaves><<<unsigned(n_long), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
+            rowptr, long_rows, vals, min_degree);
     return check_launch("segment_softmax");
 }
 
@@ -298,21 +303,23 @@ int clane_degree_weighted_sums_f64(const double *sq, const int64_t *rowptr, cons
 #define CLANE_EDGE_SCORE_WRAPPER(SUF, CT, T, AT)                                                                      \
     int clane_edge_score_##SUF(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,             \
                                const CT *Z, int64_t ldz, int32_t d, int32_t mode, const double *sums2, const AT *sq,  \
-                               AT *scores, int64_t long_threshold, const int32_t *long_rows, int64_t n_long,          \
-                               int64_t max_long_degree, void *stream) {                                               \
+                               AT *scores, int32_t flags, int64_t long_threshold, const int32_t *long_rows,           \
+                               int64_t n_long, void *stream) {                                                        \
         return edge_score<T>(rowptr, colidx, nrows, row0, reinterpret_cast<const T *>(Z), ldz, d, mode, sums2, sq,    \
-                             scores, long_threshold, long_rows, n_long, max_long_degree, stream);                     \
+                             scores, flags, long_threshold, long_rows, n_long, stream);                               \
     }
 CLANE_EDGE_SCORE_WRAPPER(f32, float, float, float)
 CLANE_EDGE_SCORE_WRAPPER(f64, double, double, double)
 CLANE_EDGE_SCORE_WRAPPER(bf16, uint16_t, bf16_t, float)
 #undef CLANE_EDGE_SCORE_WRAPPER
 
-int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, void *stream) {
-    return segment_softmax<float>(rowptr, nrows, vals, stream);
+int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, int64_t min_degree,
+                              int64_t max_degree, const int32_t *long_rows, int64_t n_long, void *stream) {
+    return segment_softmax<float>(rowptr, nrows, vals, min_degree, max_degree, long_rows, n_long, stream);
 }
-int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals, void *stream) {
-    return segment_softmax<double>(rowptr, nrows, vals, stream);
+int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals, int64_t min_degree,
+                              int64_t max_degree, const int32_t *long_rows, int64_t n_long, void *stream) {
+    return segment_softmax<double>(rowptr, nrows, vals, min_degree, max_degree, long_rows, n_long, stream);
 }
 
 #define CLANE_SPMM_WRAPPERS(SUF, CT, T, PT, GT)                                                                        \
@@ -338,9 +345,17 @@ CLANE_SPMM_WRAPPERS(f64, double, double, double, double)
 CLANE_SPMM_WRAPPERS(bf16, uint16_t, bf16_t, float, float)
 #undef CLANE_SPMM_WRAPPERS
 
-int clane_reduce_partials(const double *partials, int64_t n, double *out, void *stream) {
-    if (n < 0 || !out || (n > 0 && !partials)) return fail(CLANE_ERR_INVALID_ARGUMENT, "reduce_partials: bad arguments");
-    reduce_fixed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partials, n, n, 1, out);
+int clane_reduce_partials(const double *partials, int64_t n, double *ws, double *out, void *stream) {
+    if (n < 0 || !out || !ws || (n > 0 && !partials))
+        return fail(CLANE_ERR_INVALID_ARGUMENT, "reduce_partials: bad arguments");
+    if (n <= 8192) {
+        reduce_fixed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partials, n, n, 1, out);
+    } else {  // two stages, both in a fixed order: kReduceGrid slice sums, then their sum
+        const int64_t slice = ceil_div(n, kReduceGrid);
+        const int grid = int(ceil_div(n, slice));
+        reduce_slices_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(partials, n, slice, ws);
+        reduce_fixed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ws, grid, grid, 1, out);
+    }
     return check_launch("reduce_partials");
 }
 

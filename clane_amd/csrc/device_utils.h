@@ -115,6 +115,17 @@ __device__ __forceinline__ double block_sum_fixed(double v, double *smem) {
     return s;
 }
 
+template <typename A>
+__device__ __forceinline__ A exp_acc(A v);
+template <>
+__device__ __forceinline__ float exp_acc<float>(float v) {
+    return expf(v);
+}
+template <>
+__device__ __forceinline__ double exp_acc<double>(double v) {
+    return exp(v);
+}
+
 __host__ __device__ __forceinline__ int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace clane

@@ -1,14 +1,23 @@
-// K1 -- per-edge similarity scores in CSR order.
+// K1 -- per-edge similarity scores in CSR order, with the row softmax fused for short rows.
 //
 // Reference being replaced: the gather `self.Z[edges]` + one batched similarity call of
-// clane/graph.py:119-121 with CosineSimilarity.__call__ (clane/similarity.py:26-37); the
-// [2, E, d] gather (82 GB at |E|=40M, d=256) is never materialised here.
+// clane/graph.py:119-121 with CosineSimilarity.__call__ (clane/similarity.py:26-37), and for rows
+// of <= 64 edges also the per-row softmax of graph.py:122-123.  The [2, E, d] gather (82 GB at
+// |E|=40M, d=256) is never materialised.
 //
 // Same lane layout and gather shape as K3 (spmm_update.h): one wave per source row, the source
 // row stays in registers while the wave walks the neighbour list, U neighbour rows in flight.
-// The per-edge dot is a butterfly over the LPR lanes of a row.  Rows longer than
-// `long_threshold` go to edge_score_long_kernel: edges are independent, so a long row is
-// simply cut into per-wave slices (no fold needed).
+//  * The U = 8 per-lane partial dots of a group are reduced TOGETHER by a transposed butterfly:
+//    the first three exchange steps halve the number of live values (8 -> 4 -> 2 -> 1) while
+//    doubling the lanes each value has absorbed, the remaining log2(LPR)-3 steps finish the one
+//    survivor: 10 cross-lane ops per 8 edges at LPR = 64 instead of 48.  Every edge goes through
+//    the same exchange tree whatever slot it sits in, so its score does not depend on where a
+//    row is cut (the long-row kernel reproduces the one-wave scores bit for bit).
+//  * The finished scores are handed to lane = (edge index in the 64-edge chunk) with one more
+//    permute, so a chunk is stored with one coalesced instruction, and a row that fits one
+//    chunk is soft-maxed in registers (max / exp / sum butterflies) before it is stored.
+//  * Rows longer than `long_threshold` go to edge_score_long_kernel: edges are independent, so
+//    a long row is simply cut into per-wave slices; K2 normalises rows of > 64 edges afterwards.
 #pragma once
 
 #include "device_utils.h"
@@ -19,16 +28,45 @@ constexpr int kScoreReference = 0;
 constexpr int kScorePerEdge = 1;
 constexpr int kScoreRawDot = 2;
 
+// v[0..7]: per-lane partials of 8 independent sums over the LPR lanes of a sub-wave (LPR >= 8).
+// Returns, in every lane, the finished sum number  u = sl / (LPR/8)  (the top three bits of the
+// lane's position in its sub-wave).
+template <int LPR, typename A>
+__device__ __forceinline__ A transpose_reduce8(const A (&v)[8], int sl) {
+    static_assert(LPR >= 8, "needs at least 8 lanes per row");
+    constexpr int m0 = LPR / 2, m1 = LPR / 4, m2 = LPR / 8;
+    const bool h0 = (sl & m0) != 0, h1 = (sl & m1) != 0, h2 = (sl & m2) != 0;
+    A r[4], q[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (h0 ? v[i + 4] : v[i]) + __shfl_xor(h0 ? v[i] : v[i + 4], m0, kWave);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) q[i] = (h1 ? r[i + 2] : r[i]) + __shfl_xor(h1 ? r[i] : r[i + 2], m1, kWave);
+    A t = (h2 ? q[1] : q[0]) + __shfl_xor(h2 ? q[0] : q[1], m2, kWave);
+#pragma unroll
+    for (int m = m2 / 2; m >= 1; m >>= 1) t += __shfl_xor(t, m, kWave);
+    return t;
+}
+
+template <typename A>
+__device__ __forceinline__ A finalize_score(A dot, int mode, A D, A nsrc, const A *__restrict__ sq, int col) {
+    if (mode == kScoreReference) return dot / D;
+    if (mode == kScorePerEdge) return dot / (nsrc * sqrt(sq[col]));
+    return dot;
+}
+
 // Scores of edges [ea, eb) of the row whose source is global row `src_row` (a whole row, or one
-// wave's slice of a long row).  Must be called by all 64 lanes.
+// wave's slice of a long row).  `softmax`: [ea, eb) is a whole row of <= 64 edges -- normalise it
+// before storing.  Must be called by all 64 lanes.
 template <typename T, int VEC, int LPR, int U>
 __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ colidx, int64_t ea, int64_t eb,
                                                  int64_t src_row, const T *__restrict__ Z, int64_t ldz, int d,
                                                  int mode, typename Elem<T>::acc_t D,
                                                  const typename Elem<T>::acc_t *__restrict__ sq,
-                                                 typename Elem<T>::acc_t *__restrict__ scores) {
+                                                 typename Elem<T>::acc_t *__restrict__ scores, bool softmax) {
     using A = typename Elem<T>::acc_t;
     constexpr int EPW = kWave / LPR;
+    constexpr bool kTransposed = (U == 8 && LPR >= 8);
+    static_assert(kTransposed || LPR >= U, "fallback delivery needs one lane per value in a sub-wave");
     const int lane = lane_id();
     const int sub = lane / LPR, sl = lane % LPR;
     const bool single = d <= LPR * VEC;  // whole row in one pack per lane: keep the source row in registers
@@ -40,12 +78,14 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
     for (int64_t e = ea; e < eb; e += kWave) {
         const int64_t left = eb - e;
         const int n = left < kWave ? int(left) : kWave;
-        const int c = lane < n ? colidx[e + lane] : 0;
-        A mine = A(0);  // LPR == 64: score of edge e + lane, stored coalesced once per 64 edges
+        // Lanes past the end of the row hold the chunk's FIRST column: every address formed below is
+        // valid, so the gathers need no branch (see pin_loaded in device_utils.h for why that matters).
+        int c = lane < n ? colidx[e + lane] : 0;
+        c = lane < n ? c : lane_get_uniform(c, 0);
+        A mine = A(0);  // score of edge e + lane
         for (int j = 0; j < n; j += EPW * U) {
             A part[U];
             int cj[U];
-            bool act[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = j + u * EPW + sub;
@@ -53,23 +93,20 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
                     cj[u] = lane_get_uniform(c, idx & (kWave - 1));
                 else
                     cj[u] = lane_get(c, idx & (kWave - 1));
-                act[u] = idx < n;
                 part[u] = A(0);
             }
             for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
                 const int c0 = t0 + sl * VEC;
                 const bool ok = c0 < d;
+                const int c0s = ok ? c0 : 0;  // out-of-range lanes read column 0 and multiply it by a zero source pack
                 Pack<T, VEC> s = s0;
                 if (!single) {
-                    s = Pack<T, VEC>{};
-                    if (ok) s = load_pack<T, VEC>(zsrc + c0);
+                    s = load_pack<T, VEC>(zsrc + c0s);
+                    if (!ok) s = Pack<T, VEC>{};
                 }
                 Pack<T, VEC> z[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    z[u] = Pack<T, VEC>{};
-                    if (act[u] && ok) z[u] = load_pack<T, VEC>(Z + int64_t(cj[u]) * ldz + c0);
-                }
+                for (int u = 0; u < U; ++u) z[u] = load_pack<T, VEC>(Z + int64_t(cj[u]) * ldz + c0s);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -77,24 +114,42 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
                         part[u] = fma(Elem<T>::to_acc(s.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
                 }
             }
+            // reduce over the row's lanes; `serve` = the finished dot this lane can hand out, u_serve = which
+            A serve;
+            int u_serve;
+            if constexpr (kTransposed) {
+                serve = transpose_reduce8<LPR>(part, sl);
+                u_serve = sl / (LPR / 8);
+            } else {
+                u_serve = sl % U;
+                serve = A(0);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const A dot = group_sum<LPR>(part[u]);  // every lane of the sub-wave holds the total
-                A score = dot;
-                if (mode == kScoreReference)
-                    score = dot / D;
-                else if (mode == kScorePerEdge)
-                    score = dot / (nsrc * sqrt(sq[act[u] ? cj[u] : 0]));
-                if constexpr (LPR == kWave) {
-                    if (lane == j + u) mine = score;
-                } else {
-                    if (act[u] && sl == 0) scores[e + j + u * EPW + sub] = score;
+                for (int u = 0; u < U; ++u) {
+                    const A dot = group_sum<LPR>(part[u]);
+                    if (u == u_serve) serve = dot;
                 }
             }
+            const int idx_serve = j + u_serve * EPW + sub;      // chunk-relative edge of `serve`
+            int col_serve = 0;
+            if (mode == kScorePerEdge) col_serve = lane_get(c, idx_serve & (kWave - 1));
+            serve = finalize_score<A>(serve, mode, D, nsrc, sq, col_serve);
+            // hand edge (j + rel) to lane (j + rel):  it sits in sub-wave rel % EPW, value slot rel / EPW
+            const int rel = lane - j;
+            const bool take = rel >= 0 && rel < EPW * U;
+            int src = 0;
+            if (take) src = (rel % EPW) * LPR + (kTransposed ? (rel / EPW) * (LPR / 8) : rel / EPW);
+            const A got = lane_get(serve, src);
+            if (take) mine = got;
         }
-        if constexpr (LPR == kWave) {
-            if (lane < n) scores[e + lane] = mine;
+        if (softmax) {  // whole row in this chunk (graph.py:122-123)
+            const bool in = lane < n;
+            const A v = in ? mine : -A(INFINITY);
+            const A m = group_max<kWave>(v);
+            const A ex = in ? exp_acc<A>(v - m) : A(0);
+            const A ssum = group_sum<kWave>(ex);
+            mine = ex / ssum;
         }
+        if (lane < n) scores[e + lane] = mine;
     }
 }
 
@@ -109,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void edge_score_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows, int64_t row0,
     const T *__restrict__ Z, int64_t ldz, int d, int mode, const double *__restrict__ sums2,
     const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores,
-    int64_t long_threshold, int rows_per_block) {
+    int64_t long_threshold, bool fuse_softmax, int rows_per_block) {
     using A = typename Elem<T>::acc_t;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
@@ -119,28 +174,31 @@ __global__ __launch_bounds__(kBlock) void edge_score_kernel(
         const int64_t e0 = rowptr[r];
         const int64_t e1 = rowptr[r + 1];
         if (e0 == e1 || (long_threshold > 0 && e1 - e0 > long_threshold)) continue;
-        score_edge_range<T, VEC, LPR, U>(colidx, e0, e1, row0 + r, Z, ldz, d, mode, D, sq, scores);
+        score_edge_range<T, VEC, LPR, U>(colidx, e0, e1, row0 + r, Z, ldz, d, mode, D, sq, scores,
+                                         fuse_softmax && e1 - e0 <= kWave);
     }
 }
 
-// grid = (n_long, slices): wave w of workgroup (i, y) scores edges
-// [e0 + (y*WAVES + w)*edges_per_wave, +edges_per_wave) of long row i; edges_per_wave % 64 == 0.
+// One workgroup of WAVES waves per long row: wave w scores the 64-aligned slice w (same slicing as
+// spmm_long_kernel); a wave with an empty slice leaves at once.  Edges are independent: no fold.
 template <typename T, int VEC, int LPR, int U, int WAVES>
 __global__ __launch_bounds__(WAVES *kWave) void edge_score_long_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const int32_t *__restrict__ long_rows,
     int64_t row0, const T *__restrict__ Z, int64_t ldz, int d, int mode, const double *__restrict__ sums2,
     const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores,
-    int edges_per_wave) {
+    bool fuse_softmax) {
     using A = typename Elem<T>::acc_t;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int64_t r = long_rows[blockIdx.x];
     const int64_t e0 = rowptr[r];
     const int64_t e1 = rowptr[r + 1];
-    const int64_t a = e0 + (int64_t(blockIdx.y) * WAVES + wave) * edges_per_wave;
+    const int64_t seg = ceil_div(ceil_div(e1 - e0, WAVES), kWave) * kWave;
+    const int64_t a = e0 + wave * seg;
     if (a >= e1) return;
-    const int64_t b = a + edges_per_wave < e1 ? a + edges_per_wave : e1;
+    const int64_t b = a + seg < e1 ? a + seg : e1;
     const A D = global_denominator<A>(mode, sums2);
-    score_edge_range<T, VEC, LPR, U>(colidx, a, b, row0 + r, Z, ldz, d, mode, D, sq, scores);
+    score_edge_range<T, VEC, LPR, U>(colidx, a, b, row0 + r, Z, ldz, d, mode, D, sq, scores,
+                                     fuse_softmax && e1 - e0 <= kWave);
 }
 
 }  // namespace clane

@@ -68,13 +68,22 @@ __device__ __forceinline__ EdgeChunk<A> load_chunk(const int32_t *__restrict__ c
 }
 
 // acc[k] += sum over the n (<= 64) edges held in `ch` of p * Z[c, col + k] for this lane's pack.
+// Two forms of the same loop:
+//  * masked (fp32 / fp64): loads of edges past the end of the row are exec-masked -- no request at all;
+//  * branch-free (bf16): hipcc puts phi copies of the unpacked values inside each conditional-load
+//    block and waits for every load on its own (seen in the .s), so there every load is
+//    unconditional from an always-valid address (edge past the end -> the chunk's first column,
+//    column lane past d -> column 0) and the VALUE is zeroed instead.
 template <typename T, int VEC, int LPR, int U>
 __device__ __forceinline__ void accumulate_chunk(const EdgeChunk<typename Elem<T>::acc_t> &ch, int n,
                                                  const T *__restrict__ zcol, int64_t ldz, bool col_ok,
                                                  typename Elem<T>::acc_t (&acc)[VEC]) {
     using A = typename Elem<T>::acc_t;
     constexpr int EPW = kWave / LPR;  // neighbour rows fetched by one wave-instruction
+    constexpr bool kBranchFree = sizeof(T) == 2;
     const int sub = lane_id() / LPR;
+    int c_all = ch.c;
+    if constexpr (kBranchFree) c_all = lane_id() < n ? ch.c : lane_get_uniform(ch.c, 0);
     for (int j = 0; j < n; j += EPW * U) {
         Pack<T, VEC> z[U];
         A pj[U];
@@ -84,21 +93,29 @@ __device__ __forceinline__ void accumulate_chunk(const EdgeChunk<typename Elem<T
             int cj;
             A pv;
             if constexpr (LPR == kWave) {
-                cj = lane_get_uniform(ch.c, idx & (kWave - 1));
+                cj = lane_get_uniform(c_all, idx & (kWave - 1));
                 pv = lane_get_uniform(ch.p, idx & (kWave - 1));
             } else {
-                cj = lane_get(ch.c, idx & (kWave - 1));
+                cj = lane_get(c_all, idx & (kWave - 1));
                 pv = lane_get(ch.p, idx & (kWave - 1));
             }
             const bool in_row = idx < n;
             pj[u] = in_row ? pv : A(0);
-            z[u] = Pack<T, VEC>{};
-            if (in_row && col_ok) z[u] = load_pack<T, VEC>(zcol + int64_t(cj) * ldz);
+            if constexpr (kBranchFree) {
+                z[u] = load_pack<T, VEC>(zcol + int64_t(cj) * ldz);  // zcol is column 0 for lanes past d (see callers)
+            } else {
+                z[u] = Pack<T, VEC>{};
+                if (in_row && col_ok) z[u] = load_pack<T, VEC>(zcol + int64_t(cj) * ldz);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = fma(pj[u], Elem<T>::to_acc(z[u].v[k]), acc[k]);
+            for (int k = 0; k < VEC; ++k) {
+                A zv = Elem<T>::to_acc(z[u].v[k]);
+                if constexpr (kBranchFree) zv = pj[u] != A(0) ? zv : A(0);  // keeps 0 * inf out of the sum
+                acc[k] = fma(pj[u], zv, acc[k]);
+            }
         }
     }
 }
@@ -228,7 +245,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
                 A acc[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = A(0);
-                gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + c0, ldz, col_ok, acc, ch, true);
+                gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
                 fold_subwaves<LPR>(acc);
                 if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0);
             }
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
         A acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = A(0);
-        gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, a, b, Zold + c0, ldz, col_ok, acc, none, false);
+        gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, a, b, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, none, false);
         fold_subwaves<LPR>(acc);
         if (wave > 0) {
 #pragma unroll

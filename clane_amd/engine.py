@@ -172,8 +172,11 @@ class SweepEngine:
         if self.E_loc > 0:
             for c in range(part.chunks):
                 k.edge_score(self.rowptr[c * vc:], self.colidx, vc, part.chunk_row0(c), Z, self.d, mode,
-                             self.sums2, sq, self.P, self.long_threshold, self.long_rows[c], self.max_degree)
-            k.segment_softmax(self.rowptr, part.n_local, self.P)
+                             self.sums2, sq, self.P, self.long_threshold, self.long_rows[c], fuse_softmax=True)
+                # rows of <= 64 edges were normalised by K1; the rest: one wave (<= T) or one workgroup per row
+                if self.max_degree > _hip.FUSED_SOFTMAX_MAX_DEGREE:
+                    k.segment_softmax(self.rowptr[c * vc:], vc, self.P, _hip.FUSED_SOFTMAX_MAX_DEGREE,
+                                      self.long_threshold, self.long_rows[c])
         self.P_valid = True
 
     def P_values_global_order(self) -> torch.Tensor:
@@ -216,7 +219,7 @@ class SweepEngine:
                 import torch.distributed as dist
                 b, e = part.chunk_span(c)
                 works.append(dist.all_gather_into_tensor(Znew[b:e], Znew[r0:r0 + vc], group=self.pg, async_op=True))
-        k.reduce_partials(self.partials, self.partials.numel(), self.delta)
+        k.reduce_partials(self.partials, self.partials.numel(), self.ws, self.delta)
         self._all_reduce(self.delta)
         for w in works:
             w.wait()
@@ -264,7 +267,7 @@ class SweepEngine:
             r0 = self.part.chunk_row0(c)
             self.k.l1_distance(self.Zcur[r0:r0 + vc], self.snap[c * vc:(c + 1) * vc], self.d, self.ws,
                                self.chunk_out[c:c + 1])
-        self.k.reduce_partials(self.chunk_out, self.part.chunks, self.delta)
+        self.k.reduce_partials(self.chunk_out, self.part.chunks, self.ws, self.delta)
         self._all_reduce(self.delta)
         return float(self.delta.item())
 

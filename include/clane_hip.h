@@ -49,6 +49,9 @@ extern "C" {
 #define CLANE_SCORE_PER_EDGE 1  /* dot / (||z_src|| * ||z_dst||)                 -- what its docstring describes  */
 #define CLANE_SCORE_RAW_DOT 2   /* dot                                           -- stage test                     */
 
+/* flags of clane_edge_score_* */
+#define CLANE_SCORE_FUSE_SOFTMAX 1
+
 /* flags of clane_spmm_update_* */
 #define CLANE_SPMM_SINKS_UNTOUCHED 1
 
@@ -82,25 +85,30 @@ int clane_degree_weighted_sums_f64(const double *sq, const int64_t *rowptr, cons
  *   mode PER_EDGE : sq = squared norms of ALL rows of Z; sums2 unused.
  *   mode RAW_DOT  : both unused.
  * Rows with more than `long_threshold` edges (0 = never) are cut into per-wave slices by a
- * second launch over `long_rows` (local row ids, n_long of them, none longer than
- * `max_long_degree`); pass n_long = 0 to have every row walked by a single wave. */
+ * second launch over `long_rows` (local row ids, n_long of them; one 16-wave workgroup per row);
+ * pass n_long = 0 to have every row walked by a single wave.
+ * flags & CLANE_SCORE_FUSE_SOFTMAX: rows of <= 64 edges are soft-maxed in registers before they are
+ * stored (graph.py:122-123 for those rows); follow with clane_segment_softmax_*(min_degree = 64). */
 int clane_edge_score_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const float *Z,
                          int64_t ldz, int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
-                         int64_t long_threshold, const int32_t *long_rows, int64_t n_long, int64_t max_long_degree,
-                         void *stream);
+                         int32_t flags, int64_t long_threshold, const int32_t *long_rows, int64_t n_long, void *stream);
 int clane_edge_score_f64(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const double *Z,
                          int64_t ldz, int32_t d, int32_t mode, const double *sums2, const double *sq, double *scores,
-                         int64_t long_threshold, const int32_t *long_rows, int64_t n_long, int64_t max_long_degree,
-                         void *stream);
+                         int32_t flags, int64_t long_threshold, const int32_t *long_rows, int64_t n_long, void *stream);
 int clane_edge_score_bf16(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
                           const uint16_t *Z, int64_t ldz, int32_t d, int32_t mode, const double *sums2,
-                          const float *sq, float *scores, int64_t long_threshold, const int32_t *long_rows,
-                          int64_t n_long, int64_t max_long_degree, void *stream);
+                          const float *sq, float *scores, int32_t flags, int64_t long_threshold,
+                          const int32_t *long_rows, int64_t n_long, void *stream);
 
 /* ---- K2: in-place softmax of vals within each CSR row.  Replaces the per-row boolean-mask
- * loop of graph.py:122-123.  Empty rows are skipped. */
-int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, void *stream);
-int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals, void *stream);
+ * loop of graph.py:122-123.  Rows with min_degree < deg <= max_degree (max_degree 0 = no upper
+ * limit) are normalised by one wave each; the rows listed in `long_rows` (deg > min_degree) by one
+ * 16-wave workgroup each.  Empty rows are skipped.  After clane_edge_score_* with
+ * CLANE_SCORE_FUSE_SOFTMAX pass min_degree = 64. */
+int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, int64_t min_degree,
+                              int64_t max_degree, const int32_t *long_rows, int64_t n_long, void *stream);
+int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals, int64_t min_degree,
+                              int64_t max_degree, const int32_t *long_rows, int64_t n_long, void *stream);
 
 /* ---- K3: one Jacobi sweep over the local rows, fused with the L1 delta.  Replaces the
  * per-vertex loop embedder.py:84-92 and the reduction embedder.py:94:
@@ -142,8 +150,9 @@ int clane_spmm_update_long_bf16(const int64_t *rowptr, const int32_t *colidx, co
                                 int64_t ldz, const uint16_t *X, int64_t ldx, float gamma, uint16_t *Z_new,
                                 int64_t ldo, int32_t d, double *delta_partials, void *stream);
 
-/* out[0] = sum of partials[0..n) in a fixed order (one workgroup).  Finishes embedder.py:94 / :60. */
-int clane_reduce_partials(const double *partials, int64_t n, double *out, void *stream);
+/* out[0] = sum of partials[0..n) in a fixed order (bitwise reproducible).  Finishes embedder.py:94 / :60.
+ * ws: clane_reduce_ws_len() doubles. */
+int clane_reduce_partials(const double *partials, int64_t n, double *ws, double *out, void *stream);
 
 /* sum|A - B| over an [nrows, d] matrix pair -> out[0] (outer-loop delta, embedder.py:60).
  * ws: clane_reduce_ws_len() doubles. */

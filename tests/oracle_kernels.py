@@ -31,7 +31,7 @@ class OracleKernels:
         out2[1] = (indeg[:nrows].double() * sq[:nrows].double()).sum()
 
     def edge_score(self, rowptr, colidx, nrows, row0, Z, d, mode, sums2, sq, scores, long_threshold=0,
-                   long_rows=None, max_long_degree=0):
+                   long_rows=None, fuse_softmax=False):
         rp = _np(rowptr[:nrows + 1])
         if rp[-1] == rp[0]:
             return
@@ -44,13 +44,16 @@ class OracleKernels:
         elif mode == 1:
             dots = dots / (sq[rows].sqrt() * sq[cols].sqrt())
         scores[rp[0]:rp[-1]] = dots
+        if fuse_softmax:
+            for r in range(nrows):
+                if 0 < rp[r + 1] - rp[r] <= 64:
+                    scores[rp[r]:rp[r + 1]] = torch.softmax(scores[rp[r]:rp[r + 1]], 0)
 
-    def segment_softmax(self, rowptr, nrows, vals):
+    def segment_softmax(self, rowptr, nrows, vals, min_degree=0, max_degree=0, long_rows=None):
         rp = _np(rowptr[:nrows + 1])
-        if rp[-1] == rp[0]:
-            return
-        seg = vals[rp[0]:rp[-1]]
-        seg.copy_(O.segment_softmax(rp - rp[0], seg.clone()))
+        for r in range(nrows):
+            if rp[r + 1] - rp[r] > min_degree:
+                vals[rp[r]:rp[r + 1]] = torch.softmax(vals[rp[r]:rp[r + 1]], 0)
 
     def _spmm_rows(self, rowptr, colidx, P, rows_sel, row0, Z_old, X, gamma, Z_new, d):
         rp = _np(rowptr)
@@ -84,7 +87,7 @@ class OracleKernels:
         for i, r in enumerate(long_rows.tolist()):
             partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d)
 
-    def reduce_partials(self, partials, n, out):
+    def reduce_partials(self, partials, n, ws, out):
         out[0] = partials[:n].sum()
 
     def l1_distance(self, A, B, d, ws, out):

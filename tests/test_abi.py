@@ -47,5 +47,5 @@ def test_argument_validation_reaches_last_error():
     assert rc == -1 and b"delta_partials" in lib.clane_last_error()
     rc = lib.clane_row_sqnorm_f32(None, 4, 0, 0, None, None)
     assert rc == -1 and b"bad shape" in lib.clane_last_error()
-    rc = lib.clane_edge_score_f32(None, None, 4, 0, None, 8, 8, 7, None, None, None, 0, None, 0, 0, None)
+    rc = lib.clane_edge_score_f32(None, None, 4, 0, None, 8, 8, 7, None, None, None, 0, 0, None, 0, None)
     assert rc == -1 and b"unknown mode" in lib.clane_last_error()

@@ -125,7 +125,7 @@ def test_edge_score_and_softmax_stages(dev, k, dtype, d, pad):
     deg = np.diff(csr.rowptr)
     long_rows = torch.from_numpy(np.nonzero(deg > 48)[0].astype(np.int32)).to(dev)
     sliced = torch.full_like(scores, float("nan"))
-    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, sliced, 48, long_rows, int(deg.max()))
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, sliced, 48, long_rows)
     assert torch.equal(sliced, scores)
 
     # reference mode: denominators from K0 + degree-weighted reduction
@@ -198,7 +198,7 @@ def test_spmm_update_vs_oracle(dev, k, dtype, d, pad, long_threshold, waves):
     out = torch.zeros(1, dtype=torch.float64, device=dev)
 
     run_sweep(k, rowptr, colidx, P.to(dev), V, Zo, Xd, gamma, Zn, d, long_threshold, long_rows, partials, waves)
-    k.reduce_partials(partials, partials.numel(), out)
+    k.reduce_partials(partials, partials.numel(), torch.zeros(k.reduce_ws_len(), dtype=torch.float64, device=dev), out)
     Z_ref, _ = O.sweep(csr.rowptr, csr.colidx, P.double(), X.double(), Zold.double(), gamma)
     got = Zn[:, :d].cpu()
     assert not torch.isnan(got.float()).any()
@@ -397,3 +397,29 @@ def test_spmm_sinks_untouched_flag(dev, k):
     assert torch.equal(out[True][0][sink], torch.full((int(sink.sum()), d), 7.0))   # flag: left alone
     assert torch.equal(out[False][0][~sink], out[True][0][~sink])
     assert torch.equal(out[False][1], out[True][1])                     # sinks contribute 0 to the delta either way
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
+@pytest.mark.parametrize("d,pad", [(2, True), (16, True), (128, True), (256, True), (1433, True), (37, False)])
+def test_edge_score_fused_softmax(dev, k, dtype, d, pad):
+    """K1 with CLANE_SCORE_FUSE_SOFTMAX (+ K2 over rows > 64 edges) == K1 raw + K2 over every row."""
+    csr = ragged_csr(400, seed=d + 7, max_deg=70, hubs=(64, 65, 200, 1))
+    V, acc = csr.num_vertices, _hip.acc_dtype(dtype)
+    Zc = synth.gaussian_X(V, d, seed=5).to(dtype)
+    Zd = padded(Zc, dtype, dev) if pad else Zc.to(dev).contiguous()
+    rowptr, colidx = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    deg = np.diff(csr.rowptr)
+    sq = torch.empty(V, dtype=acc, device=dev)
+    k.row_sqnorm(Zd, d, sq)
+    for lt, lr in ((0, None), (32, torch.from_numpy(np.nonzero(deg > 32)[0].astype(np.int32)).to(dev))):
+        two_pass = torch.zeros(csr.num_edges, dtype=acc, device=dev)
+        k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_PER_EDGE, None, sq, two_pass, lt, lr)
+        k.segment_softmax(rowptr, V, two_pass)
+        fused = torch.zeros_like(two_pass)
+        k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_PER_EDGE, None, sq, fused, lt, lr, fuse_softmax=True)
+        k.segment_softmax(rowptr, V, fused, _hip.FUSED_SOFTMAX_MAX_DEGREE, lt, lr)     # long rows: workgroup per row
+        short = torch.from_numpy(np.repeat(deg <= 64, deg)).to(dev)
+        assert torch.equal(fused[short], two_pass[short])
+        assert rel(fused, two_pass) < (1e-14 if dtype == torch.float64 else 3e-7)
+    ref = O.build_P_values(csr.rowptr, csr.colidx, Zc.to(acc).double(), mode="per_edge")
+    assert rel(fused, ref) < (1e-13 if dtype == torch.float64 else 5e-6)
