@@ -148,17 +148,17 @@ def main():
     # Roofline of the DOMINANT K3 kernel (largest share of the sweep), from HIP events recorded on the
     # launch stream inside the timed region.  One launch of each kernel per chunk, so per-launch
     # bytes = that kernel's algorithmic bytes per sweep / chunks (SURVEY.md section 8d gather model).
-    chunks = eng.part.chunks
+    chunks = len(eng.blocks)          # launches of each kernel per sweep
     kbytes = eng.kernel_bytes()
     names = {"main": "spmm_update_kernel", "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>"}
     per_kernel = {}
     for key, ms in ktimes.items():
-        if kbytes[key] > 0 and ms > 0:
-            gbps = kbytes[key] / chunks / (ms * 1e-3) / 1e9
-            per_kernel[names[key]] = {"avg_launch_ms": ms, "algorithmic_bytes_per_launch": kbytes[key] / chunks,
+        if kbytes[key] > 0 and ms > 0:       # ms = per sweep, summed over the blocks
+            gbps = kbytes[key] / (ms * 1e-3) / 1e9
+            per_kernel[names[key]] = {"avg_launch_ms": ms / chunks, "algorithmic_bytes_per_launch": kbytes[key] / chunks,
                                       "GBps": gbps, "frac": gbps / HBM_PEAK_GBPS}
     dom = max(per_kernel, key=lambda n: per_kernel[n]["avg_launch_ms"])
-    pass_ms = sum(ktimes.values()) * chunks
+    pass_ms = sum(ktimes.values())
     pass_bytes = sum(kbytes.values())
     pass_gbps = pass_bytes / (pass_ms * 1e-3) / 1e9
     traffic = None
@@ -173,8 +173,10 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"R-MAT |V|={V} |E|={E} d={d} fp32, gamma={args.gamma}, CosineSimilarity "
                                f"(reference mode), seeds {gseed}/{xseed}",
-                   "parallelism": f"row-partition x{world}, {chunks} chunk(s)/sweep"
-                                  + (", in-place RCCL all-gather per chunk + scalar all-reduce" if world > 1 else "")},
+                   "parallelism": f"row-partition x{world}, {chunks} launch block(s)/sweep"
+                                  + (f", in-place RCCL all-gather of the live rows per chunk "
+                                     f"({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep) + scalar "
+                                     f"all-reduce" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic,
                      "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],

@@ -9,14 +9,15 @@ the D2H copy of one scalar per sweep and ``torch.distributed`` (RCCL).
 HBM layout per rank (T = float32 / float64 / bfloat16, ld = d rounded up to a 16-byte pack,
 pad columns zero):
 
-    Zbuf[2]   [V_pad, ld] T    full embedding matrix, ping-pong (read old / write new)
+    Zbuf[2]   [V_pad, ld] T    full-size embedding matrix, ping-pong (read old / write new)
     X_loc     [n_loc, ld] T    content embeddings of the owned rows
     rowptr    [n_loc+1] i64, colidx [E_loc] i32 (positions), P [E_loc] acc, indeg [n_loc] i32
     partials  fixed-order L1-delta partial sums (double)
 
-Multi-GPU: rows are partitioned (partition.py); after the kernel of chunk c, its slice of
-Z_new is all-gathered in place (async, on RCCL's stream) while chunk c+1 computes; the scalar
-delta is all-reduced.  On one GPU no collective is issued.
+A sweep is one launch group per *block* of owned rows (partition.py): live chunks first -- each
+followed, on N > 1 GPUs, by the in-place all-gather of its span (async, RCCL's stream, overlapping
+the next block's kernels) -- then the quiet block, which is never exchanged during sweeps.  The
+scalar delta is all-reduced.  On one GPU no collective is issued.
 """
 from __future__ import annotations
 
@@ -26,7 +27,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from .partition import HostCSR, LocalCSR, RowPartition, localize
+from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
 
 # Rows are binned by out-degree once per graph.  Measured on R-MAT 2M/40M/d256 (MI355X): a single
 # wave walking a 65..1024-edge row streams at a fraction of what a multi-wave workgroup reaches,
@@ -53,7 +54,8 @@ def _round_up(a: int, b: int) -> int:
 class SweepEngine:
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
-                 hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0):
+                 hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
+                 exchange_live_only: bool = True):
         if X.dim() != 2 or X.shape[0] != csr.num_vertices:
             raise ValueError(f"X must be [V, d] with V={csr.num_vertices}, got {tuple(X.shape)}")
         if cosine_mode not in ("reference", "per_edge"):
@@ -74,7 +76,9 @@ class SweepEngine:
             chunks = 1 if self.world == 1 else 4
         self.V, self.d = csr.num_vertices, int(X.shape[1])
         self.ld = _round_up(self.d, _hip.VEC_ELEMS[X.dtype])
-        self.part = RowPartition.create(self.V, self.world, rank, chunks, shuffle=shuffle, seed=seed)
+        live = csr.live_mask() if (self.world > 1 and exchange_live_only) else None
+        self.part = RowPartition.create(self.V, self.world, rank, chunks, live_mask=live, shuffle=shuffle, seed=seed)
+        self.blocks: List[Block] = self.part.blocks()
         self.local: LocalCSR = localize(csr, self.part)
         if long_threshold is None:
             long_threshold = DEFAULT_STEPS_PER_WAVE * (64 // lanes_per_row(self.d, X.dtype))
@@ -89,22 +93,22 @@ class SweepEngine:
         self.E_loc = int(self.local.colidx.shape[0])
         self.P = torch.zeros(max(self.E_loc, 1), dtype=self.acc_dtype, device=dev)
         self.P_valid = False
-        vc = self.part.rows_per_chunk
         deg = np.diff(self.local.rowptr)
         self.max_degree = int(deg.max()) if deg.size else 0
-        self.long_rows: List[Optional[torch.Tensor]] = []     # every row above long_threshold (K1 slices these)
+        # per block: row lists relative to the block's first row (the kernels get rowptr / X / Z_new offset to it)
+        self.long_rows: List[Optional[torch.Tensor]] = []     # every row above long_threshold (K1 / K2 slice these)
         self.mid_rows: List[Optional[torch.Tensor]] = []      # long_threshold < deg <= hub_threshold: 4 waves/row
         self.hub_rows: List[Optional[torch.Tensor]] = []      # deg > hub_threshold: 16 waves/row
         self.partial_off = [0]
         to_dev = lambda a: torch.from_numpy(a.astype(np.int32)).to(dev) if a.size else None  # noqa: E731
-        for c in range(self.part.chunks):
-            dc = deg[c * vc:(c + 1) * vc]
-            is_long = dc > self.long_threshold if self.long_threshold > 0 else np.zeros_like(dc, dtype=bool)
-            is_hub = is_long & (dc > self.hub_threshold)
+        for b in self.blocks:
+            db = deg[b.local_start:b.local_start + b.nrows]
+            is_long = db > self.long_threshold if self.long_threshold > 0 else np.zeros_like(db, dtype=bool)
+            is_hub = is_long & (db > self.hub_threshold)
             self.long_rows.append(to_dev(np.nonzero(is_long)[0]))
             self.mid_rows.append(to_dev(np.nonzero(is_long & ~is_hub)[0]))
             self.hub_rows.append(to_dev(np.nonzero(is_hub)[0]))
-            self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(vc, int(is_long.sum())))
+            self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(b.nrows, int(is_long.sum())))
         self.partials = torch.zeros(self.partial_off[-1], dtype=torch.float64, device=dev)
 
         # ---- embeddings ---------------------------------------------------------------
@@ -116,20 +120,28 @@ class SweepEngine:
         ok = verts >= 0
         Xl[ok, :self.d] = X[verts[ok]]
         self.X_loc = Xl.to(dev)
+        self.quiet_stale = False          # other ranks' quiet rows are only refreshed when Z is read out
         self.set_Z(X)
 
         # ---- scalars / scratch --------------------------------------------------------
         self.ws = torch.zeros(self.k.reduce_ws_len(), dtype=torch.float64, device=dev)
         self.sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
         self.delta = torch.zeros(1, dtype=torch.float64, device=dev)
-        self.chunk_out = torch.zeros(self.part.chunks, dtype=torch.float64, device=dev)
+        self.block_out = torch.zeros(len(self.blocks), dtype=torch.float64, device=dev)
         self.sq_loc = torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev)
         self.sq_full: Optional[torch.Tensor] = None
         self.snap: Optional[torch.Tensor] = None
         self.sweeps_done = 0
         # optional per-kernel timing with HIP events on the launch stream (bench.py)
         self.time_kernels = False
-        self.kernel_events = []          # [(chunk, start, after_main, after_long)]
+        self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
+
+    # ---- views of one block -------------------------------------------------------------
+    def _rows(self, b: Block):
+        return slice(b.local_start, b.local_start + b.nrows)
+
+    def _zrows(self, Z: torch.Tensor, b: Block) -> torch.Tensor:
+        return Z[b.row0:b.row0 + b.nrows]
 
     # ---- Z in / out -------------------------------------------------------------------
     @property
@@ -137,7 +149,7 @@ class SweepEngine:
         return self.Zbuf[self.cur]
 
     def set_Z(self, Z: torch.Tensor) -> None:
-        """Load a [V, d] matrix (vertex order) into the current full-Z buffer."""
+        """Load a [V, d] matrix (vertex order) into the full-Z buffers."""
         if tuple(Z.shape) != (self.V, self.d):
             raise ValueError(f"set_Z: expected {(self.V, self.d)}, got {tuple(Z.shape)}")
         full = torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype)
@@ -147,101 +159,114 @@ class SweepEngine:
         for buf in self.Zbuf:
             buf.copy_(full)
         self.P_valid = False
+        self.quiet_stale = False
 
     def get_Z(self) -> torch.Tensor:
-        """Current embeddings as a fresh CPU tensor [V, d] in vertex order."""
+        """Current embeddings as a fresh CPU tensor [V, d] in vertex order (collective when N > 1)."""
+        self._sync_quiet_rows()
         return self.Zcur.to("cpu")[self.pos, :self.d].clone()
+
+    def _sync_quiet_rows(self) -> None:
+        """Quiet rows (no out-edges, or never read) are not exchanged during sweeps; bring the other
+        ranks' copies up to date before the matrix leaves the engine."""
+        span = self.part.quiet_span()
+        if span is None or not self.quiet_stale:
+            return
+        import torch.distributed as dist
+        begin, end, q = span
+        mine = self.Zcur[begin + self.part.rank * q: begin + (self.part.rank + 1) * q]
+        dist.all_gather_into_tensor(self.Zcur[begin:end], mine, group=self.pg)
+        self.quiet_stale = False
 
     # ---- build_P (graph.py:118-128) -----------------------------------------------------
     def build_P(self) -> None:
-        k, part, vc = self.k, self.part, self.part.rows_per_chunk
+        k, part = self.k, self.part
         Z = self.Zcur
         mode = _hip.SCORE_MODES[self.cosine_mode]
         sq = None
         if self.cosine_mode == "reference":
-            for c in range(part.chunks):
-                r0 = part.chunk_row0(c)
-                k.row_sqnorm(Z[r0:r0 + vc], self.d, self.sq_loc[c * vc:(c + 1) * vc])
+            for b in self.blocks:
+                k.row_sqnorm(self._zrows(Z, b), self.d, self.sq_loc[self._rows(b)])
             k.degree_weighted_sums(self.sq_loc, self.rowptr, self.indeg, part.n_local, self.ws, self.sums2)
             self._all_reduce(self.sums2)
         else:
             if self.sq_full is None:
                 self.sq_full = torch.zeros(part.padded_vertices, dtype=self.acc_dtype, device=self.device)
-            k.row_sqnorm(Z, self.d, self.sq_full)
+            k.row_sqnorm(Z, self.d, self.sq_full)       # every rank holds valid copies of all rows that are read
             sq = self.sq_full
         if self.E_loc > 0:
-            for c in range(part.chunks):
-                k.edge_score(self.rowptr[c * vc:], self.colidx, vc, part.chunk_row0(c), Z, self.d, mode,
-                             self.sums2, sq, self.P, self.long_threshold, self.long_rows[c], fuse_softmax=True)
+            for i, b in enumerate(self.blocks):
+                rp = self.rowptr[b.local_start:]
+                k.edge_score(rp, self.colidx, b.nrows, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
+                             self.long_threshold, self.long_rows[i], fuse_softmax=True)
                 # rows of <= 64 edges were normalised by K1; the rest: one wave (<= T) or one workgroup per row
                 if self.max_degree > _hip.FUSED_SOFTMAX_MAX_DEGREE:
-                    k.segment_softmax(self.rowptr[c * vc:], vc, self.P, _hip.FUSED_SOFTMAX_MAX_DEGREE,
-                                      self.long_threshold, self.long_rows[c])
+                    k.segment_softmax(rp, b.nrows, self.P, _hip.FUSED_SOFTMAX_MAX_DEGREE, self.long_threshold,
+                                      self.long_rows[i])
         self.P_valid = True
-
-    def P_values_global_order(self) -> torch.Tensor:
-        """Local P values as a CPU tensor plus their index in the global CSR order."""
-        return self.P[:self.E_loc].to("cpu")
 
     # ---- one sweep (embedder.py:84-94) --------------------------------------------------
     def sweep(self, gamma: float) -> float:
         """Z <- X + gamma * P Z on the owned rows, exchange, return sum|Z_new - Z_old| (global)."""
         if not self.P_valid:
             raise RuntimeError("sweep() before build_P()")
-        k, part, vc = self.k, self.part, self.part.rows_per_chunk
+        k = self.k
         Zold, Znew = self.Zbuf[self.cur], self.Zbuf[1 - self.cur]
         works = []
-        for c in range(part.chunks):
-            r0 = part.chunk_row0(c)
-            rp, Xc, Zn = self.rowptr[c * vc:], self.X_loc[c * vc:(c + 1) * vc], Znew[r0:r0 + vc]
-            po = self.partial_off[c]
-            ev = self._events(c) if self.time_kernels else None
+        for i, b in enumerate(self.blocks):
+            rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
+            po = self.partial_off[i]
+            po_mid = po + k.spmm_partials_len(b.nrows, 0)
+            po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
+            ev = self._events(i) if self.time_kernels else None
             # hubs first (longest tail), then mid rows, then the one-wave-per-row pass
-            po_mid = po + k.spmm_partials_len(vc, 0)
-            po_hub = po_mid + (0 if self.mid_rows[c] is None else self.mid_rows[c].numel())
             if ev:
                 ev[0].record()
-            if self.hub_rows[c] is not None:
-                k.spmm_update_long(rp, self.colidx, self.P, self.hub_rows[c], 16, r0, Zold, Xc, gamma, Zn, self.d,
+            if self.hub_rows[i] is not None:
+                k.spmm_update_long(rp, self.colidx, self.P, self.hub_rows[i], 16, b.row0, Zold, Xb, gamma, Zn, self.d,
                                    self.partials[po_hub:])
             if ev:
                 ev[1].record()
-            if self.mid_rows[c] is not None:
-                k.spmm_update_long(rp, self.colidx, self.P, self.mid_rows[c], 4, r0, Zold, Xc, gamma, Zn, self.d,
+            if self.mid_rows[i] is not None:
+                k.spmm_update_long(rp, self.colidx, self.P, self.mid_rows[i], 4, b.row0, Zold, Xb, gamma, Zn, self.d,
                                    self.partials[po_mid:])
             if ev:
                 ev[2].record()
-            k.spmm_update(rp, self.colidx, self.P, vc, r0, Zold, Xc, gamma, Zn, self.d, self.long_threshold,
+            k.spmm_update(rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb, gamma, Zn, self.d, self.long_threshold,
                           self.partials[po:], sinks_untouched=True)
             if ev:
                 ev[3].record()
-            if self.world > 1:
+            if b.span is not None:
                 import torch.distributed as dist
-                b, e = part.chunk_span(c)
-                works.append(dist.all_gather_into_tensor(Znew[b:e], Znew[r0:r0 + vc], group=self.pg, async_op=True))
+                works.append(dist.all_gather_into_tensor(Znew[b.span[0]:b.span[1]], Zn, group=self.pg, async_op=True))
         k.reduce_partials(self.partials, self.partials.numel(), self.ws, self.delta)
         self._all_reduce(self.delta)
         for w in works:
             w.wait()
         self.cur = 1 - self.cur
         self.sweeps_done += 1
+        self.quiet_stale = True
         return float(self.delta.item())
 
-    def _events(self, c: int):
+    def _events(self, i: int):
         ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
-        self.kernel_events.append((c,) + ev)
+        self.kernel_events.append((i,) + ev)
         return ev
 
     def kernel_times_ms(self):
-        """{'hub','mid','main'} -> mean ms per launch over the recorded sweeps; call after a synchronize."""
+        """{'hub','mid','main'} -> ms per SWEEP (summed over the blocks, averaged over the recorded
+        sweeps); call after a synchronize."""
         t = np.array([(a.elapsed_time(b), b.elapsed_time(m), m.elapsed_time(e))
                       for _, a, b, m, e in self.kernel_events]).reshape(-1, 3)
         self.kernel_events = []
-        return dict(zip(("hub", "mid", "main"), t.mean(0).tolist())) if len(t) else {}
+        if not len(t):
+            return {}
+        per_sweep = t.reshape(-1, len(self.blocks), 3).sum(1).mean(0)
+        return dict(zip(("hub", "mid", "main"), per_sweep.tolist()))
 
     def kernel_bytes(self):
         """Algorithmic bytes per SWEEP of each K3 kernel (SURVEY.md section 8d gather model, split by the
-        rows each kernel owns): per row  deg*(d*s + 4 + sizeof P) + 3*d*s + 8."""
+        rows each kernel owns): per row  deg*(d*s + 4 + sizeof P) + 3*d*s + 8;  rows without out-edges: 8."""
         s, ps = self.Zcur.element_size(), self.P.element_size()
         deg = np.diff(self.local.rowptr)
         per_row = deg * (self.d * s + 4 + ps) + np.where(deg > 0, 3 * self.d * s, 0) + 8   # sinks: rowptr only
@@ -250,24 +275,25 @@ class SweepEngine:
         return {"main": int(per_row[~is_long].sum()) + 8, "mid": int(per_row[is_long & ~is_hub].sum()),
                 "hub": int(per_row[is_hub].sum())}
 
+    def exchange_bytes_per_sweep(self) -> int:
+        """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""
+        s = self.Zcur.element_size()
+        return sum((b.span[1] - b.span[0] - b.nrows) * self.ld * s for b in self.blocks if b.span is not None)
+
     # ---- outer-loop delta (embedder.py:58-60) -------------------------------------------
     def snapshot(self) -> None:
-        vc = self.part.rows_per_chunk
         if self.snap is None:
             self.snap = torch.empty(self.part.n_local, self.ld, dtype=self.dtype, device=self.device)
-        for c in range(self.part.chunks):
-            r0 = self.part.chunk_row0(c)
-            self.snap[c * vc:(c + 1) * vc].copy_(self.Zcur[r0:r0 + vc])
+        for b in self.blocks:
+            self.snap[self._rows(b)].copy_(self._zrows(self.Zcur, b))
 
     def distance_from_snapshot(self) -> float:
         if self.snap is None:
             raise RuntimeError("distance_from_snapshot() before snapshot()")
-        vc = self.part.rows_per_chunk
-        for c in range(self.part.chunks):
-            r0 = self.part.chunk_row0(c)
-            self.k.l1_distance(self.Zcur[r0:r0 + vc], self.snap[c * vc:(c + 1) * vc], self.d, self.ws,
-                               self.chunk_out[c:c + 1])
-        self.k.reduce_partials(self.chunk_out, self.part.chunks, self.ws, self.delta)
+        for i, b in enumerate(self.blocks):
+            self.k.l1_distance(self._zrows(self.Zcur, b), self.snap[self._rows(b)], self.d, self.ws,
+                               self.block_out[i:i + 1])
+        self.k.reduce_partials(self.block_out, len(self.blocks), self.ws, self.delta)
         self._all_reduce(self.delta)
         return float(self.delta.item())
 
@@ -276,10 +302,3 @@ class SweepEngine:
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
-
-    # ---- accounting (bench.py / DESIGN.md) ----------------------------------------------
-    def algorithmic_bytes_per_sweep(self) -> int:
-        """SURVEY.md section 8d gather model, for the rows this rank owns."""
-        s = self.Zcur.element_size()
-        n, E, d = self.part.n_local, self.E_loc, self.d
-        return E * d * s + E * (4 + self.P.element_size()) + (n + 1) * 8 + 3 * n * d * s

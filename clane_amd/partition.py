@@ -3,23 +3,30 @@
 The reference runs in one process and has no partitioning (the path
 shards by rows with one exchange per sweep).  Layout chosen for RCCL over xGMI:
 
-* every rank owns ``n_local = chunks * rows_per_chunk`` rows and keeps the FULL ``Z``
-  (two ping-pong buffers) in its own HBM, so the gather in a sweep never leaves the GPU;
-* rows are stored *chunk-major*:  position ``g = c*(W*Vc) + r*Vc + i``  holds row ``i`` of
-  chunk ``c`` of rank ``r``.  The rows that chunk ``c`` of all ranks produce are therefore one
-  contiguous span ``[c*W*Vc, (c+1)*W*Vc)`` and rank ``r``'s piece sits at offset ``r*Vc`` in
-  it -- exactly the in-place form of an all-gather (send = recv + rank*count).  Splitting a
-  sweep into ``chunks`` launches lets the all-gather of chunk ``c`` run over xGMI while the
-  kernel of chunk ``c+1`` is still reading HBM;
-* vertices are assigned to positions through an optional random permutation, which
-  balances edges per rank in expectation and spreads hub rows (R-MAT / power-law inputs).
+* every rank keeps a FULL-size ``Z`` (two ping-pong buffers) in its own HBM, so the gathers of a
+  sweep never leave the GPU, and owns ``n_local`` rows of it;
+* only rows that can both CHANGE and BE READ have to travel: a row without out-edges never
+  changes (embedder.py:88-89) and a row without in-edges is never gathered by anyone.  Rows
+  with ``outdeg > 0 and indeg > 0`` are *live*, the rest *quiet*.  A rank's rows are ordered
+  ``[live chunk 0 | ... | live chunk C-1 | quiet]``; only live chunks are exchanged during
+  sweeps (on R-MAT 2M/40M that is ~45 % of the rows), quiet rows are synchronised once when
+  ``Z`` is read out;
+* live rows are stored *chunk-major*:  position ``g = c*(W*Lc) + r*Lc + i``  holds live row ``i``
+  of chunk ``c`` of rank ``r``.  The rows that chunk ``c`` of all ranks produce are one contiguous
+  span and rank ``r``'s piece sits at offset ``r*Lc`` in it -- exactly the in-place form of an
+  all-gather (send = recv + rank*count).  A sweep is one launch per chunk, so the all-gather
+  of chunk ``c`` runs over xGMI while chunk ``c+1`` (and finally the quiet block) computes;
+* quiet rows follow, rank-major: position ``live_total + r*Q + i``;
+* vertices are dealt to ranks through a seeded random permutation (per class), which balances
+  edges per rank in expectation and spreads hub rows (R-MAT / power-law inputs).
 
+With one rank there is nothing to exchange: all rows form ``chunks`` plain blocks.
 Everything here is host-side index arithmetic (numpy); it runs once per graph.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import Optional
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -42,6 +49,20 @@ class HostCSR:
     def indeg(self) -> np.ndarray:
         return np.bincount(self.colidx, minlength=self.num_vertices).astype(np.int32)
 
+    def live_mask(self) -> np.ndarray:
+        """Rows that change during sweeps AND are read by some row: the only ones worth exchanging."""
+        return (self.outdeg() > 0) & (self.indeg() > 0)
+
+
+@dataclass
+class Block:
+    """One kernel launch of a sweep: ``nrows`` consecutive local rows starting at ``local_start``,
+    stored at positions ``row0 ...``; ``span`` = positions the all-gather after it fills (None: no exchange)."""
+    local_start: int
+    nrows: int
+    row0: int
+    span: Optional[Tuple[int, int]]
+
 
 @dataclass
 class RowPartition:
@@ -49,55 +70,88 @@ class RowPartition:
     world_size: int
     rank: int
     chunks: int
-    rows_per_chunk: int
-    perm: Optional[np.ndarray] = None   # vertex -> natural slot (None = identity)
+    live_per_chunk: int                 # Lc: live rows per (rank, chunk), padded
+    quiet_per_rank: int                 # Q : quiet rows per rank, padded
+    live_per_rank: int                  # live vertices dealt to each rank before chunk padding (ceil(nlive / W))
+    vertex_slot: np.ndarray = field(repr=False, default=None)   # int64 [V]: slot within its class
+    vertex_live: np.ndarray = field(repr=False, default=None)   # bool  [V]
 
     @classmethod
     def create(cls, num_vertices: int, world_size: int = 1, rank: int = 0, chunks: int = 1,
-               shuffle: Optional[bool] = None, seed: int = 0) -> "RowPartition":
+               live_mask: Optional[np.ndarray] = None, shuffle: Optional[bool] = None, seed: int = 0) -> "RowPartition":
         if not (0 <= rank < world_size) or chunks < 1 or num_vertices < 1:
             raise ValueError(f"bad partition: V={num_vertices} world={world_size} rank={rank} chunks={chunks}")
-        vc = -(-num_vertices // (world_size * chunks))
         if shuffle is None:
             shuffle = world_size > 1
-        perm = np.random.default_rng(seed).permutation(num_vertices).astype(np.int64) if shuffle else None
-        return cls(num_vertices, world_size, rank, chunks, vc, perm)
+        if world_size == 1 or live_mask is None:
+            live = np.ones(num_vertices, dtype=bool)          # nothing to exchange / nothing known: all rows chunked
+        else:
+            live = np.asarray(live_mask, dtype=bool)
+            if live.shape != (num_vertices,):
+                raise ValueError("live_mask must have one entry per vertex")
+        rng = np.random.default_rng(seed)
+        slot = np.empty(num_vertices, dtype=np.int64)
+        for mask in (live, ~live):
+            ids = np.nonzero(mask)[0]
+            order = rng.permutation(ids.size) if shuffle else np.arange(ids.size)
+            slot[ids[order]] = np.arange(ids.size, dtype=np.int64)
+        n_live, n_quiet = int(live.sum()), int((~live).sum())
+        live_per_rank = max(1, -(-n_live // world_size))
+        lc = -(-live_per_rank // chunks)
+        q = -(-n_quiet // world_size)
+        return cls(num_vertices, world_size, rank, chunks, lc, q, live_per_rank, slot, live)
 
     # ---- sizes ------------------------------------------------------------------------
     @property
+    def live_total(self) -> int:
+        return self.world_size * self.chunks * self.live_per_chunk
+
+    @property
     def n_local(self) -> int:
-        return self.chunks * self.rows_per_chunk
+        return self.chunks * self.live_per_chunk + self.quiet_per_rank
 
     @property
     def padded_vertices(self) -> int:
-        return self.world_size * self.n_local
+        return self.live_total + self.world_size * self.quiet_per_rank
 
     # ---- index maps -------------------------------------------------------------------
-    def slot_to_position(self, slot: np.ndarray) -> np.ndarray:
-        """natural slot p = r*n_local + c*Vc + i  ->  chunk-major position g."""
-        vc, w = self.rows_per_chunk, self.world_size
-        r, l = np.divmod(slot, self.n_local)
-        c, i = np.divmod(l, vc)
-        return c * (w * vc) + r * vc + i
+    def _live_position(self, r, l):
+        c, i = np.divmod(l, self.live_per_chunk)
+        return c * (self.world_size * self.live_per_chunk) + r * self.live_per_chunk + i
 
     def position_of_vertex(self) -> np.ndarray:
         """int64 [V]: row of the full Z buffer that holds vertex v."""
-        slot = self.perm if self.perm is not None else np.arange(self.num_vertices, dtype=np.int64)
-        return self.slot_to_position(slot)
+        s = self.vertex_slot
+        r_live, l_live = np.divmod(s, self.live_per_rank)
+        pos_live = self._live_position(r_live, l_live)
+        pos_quiet = self.live_total + s          # slot t -> rank t // Q, offset t % Q  ==  live_total + t
+        return np.where(self.vertex_live, pos_live, pos_quiet).astype(np.int64)
 
     def local_positions(self, rank: Optional[int] = None) -> np.ndarray:
-        """int64 [n_local]: positions of this rank's rows, in local order (chunk by chunk)."""
+        """int64 [n_local]: positions of this rank's rows in local order (live chunks, then quiet)."""
         r = self.rank if rank is None else rank
-        return self.slot_to_position(r * self.n_local + np.arange(self.n_local, dtype=np.int64))
+        live = self._live_position(r, np.arange(self.chunks * self.live_per_chunk, dtype=np.int64))
+        quiet = self.live_total + r * self.quiet_per_rank + np.arange(self.quiet_per_rank, dtype=np.int64)
+        return np.concatenate([live, quiet])
 
-    def chunk_row0(self, c: int) -> int:
-        """position of the first row of this rank's chunk c (= `row0` of the kernel call)."""
-        return c * self.world_size * self.rows_per_chunk + self.rank * self.rows_per_chunk
+    def blocks(self) -> List[Block]:
+        """Launch plan of one sweep for this rank."""
+        lc, w = self.live_per_chunk, self.world_size
+        out = []
+        for c in range(self.chunks):
+            b = c * w * lc
+            span = (b, b + w * lc) if w > 1 else None
+            out.append(Block(c * lc, lc, b + self.rank * lc, span))
+        if self.quiet_per_rank:
+            out.append(Block(self.chunks * lc, self.quiet_per_rank,
+                             self.live_total + self.rank * self.quiet_per_rank, None))
+        return out
 
-    def chunk_span(self, c: int):
-        """[begin, end) positions written by the all-gather of chunk c."""
-        n = self.world_size * self.rows_per_chunk
-        return c * n, (c + 1) * n
+    def quiet_span(self) -> Optional[Tuple[int, int, int]]:
+        """(begin, end, rows per rank) of the quiet region -- all-gathered only when Z is read out."""
+        if self.world_size == 1 or self.quiet_per_rank == 0:
+            return None
+        return self.live_total, self.padded_vertices, self.quiet_per_rank
 
 
 @dataclass
@@ -128,7 +182,7 @@ def localize(csr: HostCSR, part: RowPartition) -> LocalCSR:
     row_of = np.repeat(np.arange(part.n_local, dtype=np.int64), deg)
     origin = csr.rowptr[safe][row_of] + (np.arange(rowptr[-1], dtype=np.int64) - rowptr[:-1][row_of])
     cols = pos[csr.colidx[origin]]
-    identity = part.perm is None and part.world_size == 1 and part.chunks == 1
+    identity = part.world_size == 1 and part.chunks == 1 and np.array_equal(pos, np.arange(V))
     if not identity:
         order = np.lexsort((cols, row_of))      # stable: by row, then by new column
         cols, origin = cols[order], origin[order]

@@ -41,7 +41,9 @@ def _worker(rank, world, port, chunks, name, out_dir):
         g = Graph(root)
         eng = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), process_group=dist.group.WORLD, chunks=chunks, seed=3)
         g._attach_engine(eng)
-        assert eng.world == world and eng.part.perm is not None          # shuffled partition by default for N > 1
+        n_quiet = int((~g.csr.live_mask()).sum())                          # live / quiet split for N > 1
+        assert eng.world == world and eng.part.quiet_per_rank == -(-n_quiet // world)
+        assert 0 < eng.exchange_bytes_per_sweep() <= (world - 1) * eng.part.n_local * eng.ld * 4
 
         # build_P: every rank assembles the full P in the reference's (row, col) order
         P = g.build_P(CosineSimilarity())

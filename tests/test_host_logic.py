@@ -140,22 +140,35 @@ def test_similarity_plugin_surface():
 
 
 # ---- partition ------------------------------------------------------------------------------
-@pytest.mark.parametrize("V,W,C", [(34, 1, 1), (34, 2, 1), (34, 2, 3), (5, 4, 2), (1000, 8, 4)])
-def test_partition_is_a_bijection_with_contiguous_chunk_spans(V, W, C):
-    parts = [RowPartition.create(V, W, r, C, seed=3) for r in range(W)]
+@pytest.mark.parametrize("V,W,C", [(34, 1, 1), (34, 1, 3), (34, 2, 1), (34, 2, 3), (5, 4, 2), (1000, 8, 4)])
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_partition_is_a_bijection_with_in_place_allgather_spans(V, W, C, with_mask):
+    live = (np.random.default_rng(V + W + C).random(V) < 0.4) if with_mask else None
+    parts = [RowPartition.create(V, W, r, C, live_mask=live, seed=3) for r in range(W)]
     p0 = parts[0]
     pos = p0.position_of_vertex()
-    assert len(np.unique(pos)) == V and pos.max() < p0.padded_vertices
+    assert len(np.unique(pos)) == V and pos.max() < p0.padded_vertices and pos.min() >= 0
     owned = np.concatenate([p.local_positions() for p in parts])
-    assert sorted(owned.tolist()) == list(range(p0.padded_vertices))
-    vc = p0.rows_per_chunk
+    assert sorted(owned.tolist()) == list(range(p0.padded_vertices))          # every position has exactly one owner
+    if with_mask and W > 1:                                                     # live rows sit in the exchanged region
+        assert (pos[live] < p0.live_total).all() and (pos[~live] >= p0.live_total).all()
+    covered = np.zeros(p0.padded_vertices, dtype=int)
     for r, p in enumerate(parts):
         lp = p.local_positions()
-        for c in range(C):
-            b, e = p.chunk_span(c)
-            r0 = p.chunk_row0(c)
-            assert r0 == b + r * vc and e - b == W * vc          # in-place all-gather form
-            np.testing.assert_array_equal(lp[c * vc:(c + 1) * vc], np.arange(r0, r0 + vc))
+        blocks = p.blocks()
+        assert sum(b.nrows for b in blocks) == p.n_local
+        for b in blocks:
+            np.testing.assert_array_equal(lp[b.local_start:b.local_start + b.nrows], np.arange(b.row0, b.row0 + b.nrows))
+            if W == 1:
+                assert b.span is None
+            elif b.span is not None:                                             # in-place all-gather form
+                assert (b.span[1] - b.span[0]) == W * b.nrows and b.row0 == b.span[0] + r * b.nrows
+                if r == 0:
+                    covered[b.span[0]:b.span[1]] += 1
+    if W > 1:
+        assert (covered[:p0.live_total] == 1).all() and (covered[p0.live_total:] == 0).all()
+        qs = p0.quiet_span()
+        assert qs is None or (qs[0] == p0.live_total and qs[1] == p0.padded_vertices and qs[1] - qs[0] == W * qs[2])
 
 
 def test_localize_relabels_and_keeps_every_edge():
@@ -165,7 +178,7 @@ def test_localize_relabels_and_keeps_every_edge():
     csr = HostCSR(34, rowptr, colidx)
     seen = np.zeros(csr.num_edges, dtype=int)
     for r in range(3):
-        part = RowPartition.create(34, 3, r, 2, seed=1)
+        part = RowPartition.create(34, 3, r, 2, live_mask=csr.live_mask(), seed=1)
         loc = localize(csr, part)
         pos = part.position_of_vertex()
         seen[loc.edge_origin] += 1
