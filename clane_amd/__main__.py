@@ -61,10 +61,15 @@ def embedding(args):
         for outer, history_Z in enumerate(embedder.history["Z"]):
             args.output_root.joinpath(f'{outer}').mkdir(parents=True, exist_ok=True)
             for sweep, Z in enumerate(history_Z):
-                np.save(args.output_root.joinpath(f'{outer}/Z_{sweep}.npy'), Z.cpu().numpy())
-    np.save(args.output_root.joinpath('Z.npy'), g.Z.cpu().numpy())
+                np.save(args.output_root.joinpath(f'{outer}/Z_{sweep}.npy'), _to_numpy(Z))
+    np.save(args.output_root.joinpath('Z.npy'), _to_numpy(g.Z))
 
     print(f"The embeddings are stored in {args.output_root.joinpath('Z.npy').absolute()}.")
+
+
+def _to_numpy(Z: torch.Tensor) -> np.ndarray:
+    Z = Z.cpu()
+    return (Z.float() if Z.dtype == torch.bfloat16 else Z).numpy()      # NumPy has no bfloat16
 
 
 def get_parser():

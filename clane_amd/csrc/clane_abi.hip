@@ -197,9 +197,14 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
     const int grid = int(spmm_main_grid(nrows));
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
-        spmm_update_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-            rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-            (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), delta_partials);
+        if constexpr (LPR < kWave && VEC > 1)      // short rows of narrow matrices: one sub-wave per row
+            spmm_update_subrow_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+                rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
+                (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), delta_partials);
+        else
+            spmm_update_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+                rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
+                (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), delta_partials);
     });
     return check_launch("spmm_update");
 }

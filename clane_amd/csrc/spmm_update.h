@@ -275,6 +275,118 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     if (lane == 0) partials[blockIdx.x] = dsum;
 }
 
+// Rows that need fewer than 64 lanes (LPR < 64; e.g. d=128 bf16: 16 lanes x 16 B): one SUB-WAVE per
+// destination row, so a wave keeps 64/LPR rows in flight and nothing has to be folded across
+// sub-waves.  (Splitting ONE short row's edges over the sub-waves, as the long-row kernel does,
+// leaves most lanes of a 5-edge row idle: 3.5 TB/s on the 10M-vertex power-law graph.)
+// Same workgroup structure as spmm_update_kernel: consecutive rows, rowptr slice in LDS, waves
+// claim GROUPS of 64/LPR consecutive rows, per-row deltas summed in row order by the last wave.
+// Gathers are branch-free (see accumulate_chunk): a sub-wave that has run out of edges re-reads
+// its last neighbour row (an L1 hit) with weight zero until the longest row of the group is done.
+template <typename T, typename PT, int VEC, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
+    int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
+    typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
+    bool skip_sinks, int rows_per_block, double *__restrict__ partials) {
+    using A = typename Elem<T>::acc_t;
+    static_assert(LPR < kWave, "use spmm_update_kernel for rows that fill a wave");
+    constexpr int RPW = kWave / LPR;  // rows per wave
+    __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
+    __shared__ double s_rowsum[kMaxRowsPerBlock];
+    __shared__ int s_next;
+    __shared__ int s_done;
+
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int sub = lane / LPR;
+    const int sl = lane % LPR;
+    const int sub_base = sub * LPR;
+    const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
+    const int nb = int((row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows) - row_begin);
+    const int c0 = sl * VEC;                 // LPR * VEC >= d: a row is one pack per lane
+    const bool col_ok = c0 < d;
+    const int c0s = col_ok ? c0 : 0;
+
+    for (int i = threadIdx.x; i <= nb; i += kBlock) s_rowptr[i] = rowptr[row_begin + i];
+    for (int i = threadIdx.x; i < nb; i += kBlock) s_rowsum[i] = 0.0;
+    if (threadIdx.x == 0) {
+        s_next = kWavesPerBlock * RPW;
+        s_done = 0;
+    }
+    __syncthreads();
+
+    for (int base = wave * RPW; base < nb;) {
+        const int mine = base + sub;
+        int64_t e0 = 0;
+        int deg = 0;
+        bool work = false;
+        if (mine < nb) {
+            e0 = s_rowptr[mine];
+            const int64_t dg = s_rowptr[mine + 1] - e0;
+            const bool is_long = long_threshold > 0 && dg > long_threshold;
+            work = !is_long && !(skip_sinks && dg == 0);
+            deg = work ? int(dg) : 0;
+        }
+        const int64_t r = row_begin + mine;
+        Pack<T, VEC> x{}, zo{};
+        if (work && col_ok) {
+            x = load_pack<T, VEC>(X + r * ldx + c0);
+            zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
+        }
+        A acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+        // each sub-wave walks ITS row: LPR edges of colidx / P per refill, U neighbour rows in flight
+        for (int eb = 0; __any(eb < deg); eb += LPR) {
+            const int n = deg - eb < LPR ? (deg - eb > 0 ? deg - eb : 0) : LPR;
+            int c = 0;
+            A p = A(0);
+            if (sl < n) {
+                c = colidx[e0 + eb + sl];
+                p = A(P[e0 + eb + sl]);
+            }
+            for (int j = 0; __any(j < n); j += U) {
+                Pack<T, VEC> z[U];
+                A pj[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = j + u;                                   // < LPR + U
+                    const int src = sub_base + (idx < LPR ? idx : LPR - 1);  // lanes >= n hold c = 0: row 0 is valid
+                    const int cj = lane_get(c, src);
+                    pj[u] = idx < n ? lane_get(p, src) : A(0);
+                    z[u] = load_pack<T, VEC>(Zold + int64_t(cj) * ldz + c0s);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        A zv = Elem<T>::to_acc(z[u].v[k]);
+                        zv = pj[u] != A(0) ? zv : A(0);   // keeps 0 * inf (and the zero-weight re-reads) out of the sum
+                        acc[k] = fma(pj[u], zv, acc[k]);
+                    }
+                }
+            }
+        }
+        A rsum = A(0);
+        if (work && col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, deg > 0, Znew + r * ldo + c0);
+        rsum = group_sum<LPR>(rsum);
+        if (work && sl == 0) s_rowsum[mine] = double(rsum);
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&s_next, RPW);
+        base = __builtin_amdgcn_readfirstlane(v);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's s_rowsum stores have landed
+    int ticket = 0;
+    if (lane == 0) ticket = atomicAdd(&s_done, 1);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != kWavesPerBlock - 1) return;
+    double dsum = 0.0;
+    for (int i = lane; i < nb; i += kWave) dsum += s_rowsum[i];
+    dsum = group_sum<kWave>(dsum);
+    if (lane == 0) partials[blockIdx.x] = dsum;
+}
+
 // One workgroup of WAVES waves per long row.  Wave w gathers the 64-aligned edge slice w; slices are
 // folded through LDS in wave order (fixed order => reproducible) and wave 0 writes the row.  A wave
 // whose slice is empty leaves at once: on AMD hardware s_barrier waits only for the waves of the

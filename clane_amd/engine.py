@@ -29,15 +29,16 @@ import torch
 from . import _hip
 from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
 
-# Rows are binned by out-degree once per graph.  Measured on R-MAT 2M/40M/d256 (MI355X): a single
-# wave walking a 65..1024-edge row streams at a fraction of what a multi-wave workgroup reaches,
-# and the 16-wave row-split kernel (idle waves exit at once) is the best streaming engine for
-# every row above ~32 gather steps (profiles/r01_threshold_sweep.md):
-#   deg <= T   one wave per row, rows claimed dynamically inside a workgroup  (spmm_update_kernel)
-#   deg >  T   16-wave workgroup per row, 64-aligned slices                    (spmm_long_kernel)
-# with T = 32 gather steps = 32 * (64 / lanes-per-row) edges.  A 4-wave bin (T < deg <= hub_threshold)
-# exists in the ABI and can be enabled with hub_threshold > long_threshold; it did not pay.
-DEFAULT_STEPS_PER_WAVE = 32
+# Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md):
+#   deg <= T   one (sub-)wave per row, rows claimed dynamically inside a workgroup
+#              (spmm_update_kernel when a row fills a wave, spmm_update_subrow_kernel otherwise)
+#   deg >  T   16-wave workgroup per row, 64-aligned slices, idle waves exit at once (spmm_long_kernel)
+# Measured on MI355X: a single wave walking a 65..1024-edge row of 1-KiB rows streams at a fraction of
+# what the multi-wave kernel reaches, so T is small when a row fills a wave (d=256 fp32: T=32); with
+# narrow rows (d=128 bf16: 4 rows per wave-instruction) the sub-wave kernel is the efficient one and a
+# workgroup per 100-edge row is not, so T grows with the rows a wave covers per instruction.
+# A 4-wave bin (T < deg <= hub_threshold) exists in the ABI; it did not pay.
+LONG_THRESHOLD_BY_ROWS_PER_WAVE = {1: 32, 2: 64, 4: 384, 8: 512}
 HUB_FACTOR = 1
 
 
@@ -81,7 +82,7 @@ class SweepEngine:
         self.blocks: List[Block] = self.part.blocks()
         self.local: LocalCSR = localize(csr, self.part)
         if long_threshold is None:
-            long_threshold = DEFAULT_STEPS_PER_WAVE * (64 // lanes_per_row(self.d, X.dtype))
+            long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[64 // lanes_per_row(self.d, X.dtype)]
         self.long_threshold = int(long_threshold)
         self.hub_threshold = int(hub_threshold) if hub_threshold is not None else HUB_FACTOR * self.long_threshold
         dev = self.device

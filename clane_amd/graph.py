@@ -58,6 +58,18 @@ def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray) -> HostC
     return HostCSR(num_vertices, rowptr, (key % num_vertices).astype(np.int32))
 
 
+def _parse_dtype(dtype) -> torch.dtype:
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    names = {"float32": torch.float32, "fp32": torch.float32, "f32": torch.float32,
+             "float64": torch.float64, "fp64": torch.float64, "f64": torch.float64, "double": torch.float64,
+             "bfloat16": torch.bfloat16, "bf16": torch.bfloat16}
+    try:
+        return names[str(dtype).lower().replace("torch.", "")]
+    except KeyError:
+        raise ValueError(f"unsupported embedding dtype {dtype!r} (float32, float64 or bfloat16)") from None
+
+
 # ---- object-model facade ----------------------------------------------------------------------
 class Vertex(object):
     """View of one vertex (reference graph.py:9-21).  ``x`` / ``z`` are rows of the graph's matrices."""
@@ -118,7 +130,9 @@ class _LazySeq:
 
 
 class Graph(torch.utils.data.Dataset):
-    def __init__(self, data_root: Path, embedding_dim: int = 128) -> None:
+    def __init__(self, data_root: Path, embedding_dim: int = 128, dtype=None) -> None:
+        """``dtype`` (extension, default None = keep what the files hold, as upstream): storage type of the
+        embeddings on the GPU -- "float32", "float64" or "bfloat16" (bf16 storage, fp32 accumulate and P)."""
         super().__init__()
         data_root = Path(data_root)
         self.d = embedding_dim
@@ -132,6 +146,8 @@ class Graph(torch.utils.data.Dataset):
                 self.X = torch.load(data_root.joinpath("C.pt"))
             except FileNotFoundError:
                 self.X = torch.normal(0, 1, [len(self.vertex_ids), self.d])
+        if dtype is not None:
+            self.X = self.X.to(_parse_dtype(dtype))
         if self.X.dim() != 2 or self.X.shape[0] != len(self.vertex_ids):
             raise ValueError(f"content embeddings have shape {tuple(self.X.shape)}, expected "
                              f"[{len(self.vertex_ids)}, d]")

@@ -45,6 +45,39 @@ def rmat_csr(num_vertices: int, num_edges: int, seed: int = 1, abcd=(0.57, 0.19,
     return _csr_from_keys(num_vertices, have)
 
 
+def powerlaw_csr(num_vertices: int, num_edges: int, alpha: float = 2.1, max_degree: int = 100_000, seed: int = 5,
+                 device: Optional[str] = None) -> HostCSR:
+    """Zipf(alpha) out-degrees clipped to [1, max_degree] and scaled to sum ~ num_edges; destinations drawn
+    proportionally to an independent Zipf in-weight.  Duplicate edges are
+    merged, so the edge count is slightly below ``num_edges``."""
+    dev = torch.device(device) if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    u = torch.rand(num_vertices, generator=gen, device=dev).clamp_min(1e-12)
+    shape = u.pow(-1.0 / (alpha - 1.0)).clamp(1, max_degree)
+    w = torch.rand(num_vertices, generator=gen, device=dev).clamp_min(1e-12).pow(-1.0 / (alpha - 1.0)).clamp(1, max_degree)
+    cdf = torch.cumsum(w.double(), 0)
+    cdf /= cdf[-1].clone()
+    target, keys = float(num_edges), None
+    for _ in range(4):      # hub destinations collide inside a row: draw more until ~num_edges survive the merge
+        deg = (shape * (target / float(shape.sum()))).round().clamp(0, max_degree).long()
+        src_all = torch.repeat_interleave(torch.arange(num_vertices, device=dev), deg)
+        parts, step = [], 1 << 26
+        for a in range(0, src_all.numel(), step):
+            src = src_all[a:a + step]
+            dst = torch.searchsorted(cdf, torch.rand(src.numel(), generator=gen, device=dev, dtype=torch.float64))
+            parts.append(src * num_vertices + dst.clamp_max(num_vertices - 1))
+        del src_all
+        keys = torch.unique(torch.cat(parts))
+        del parts
+        if keys.numel() >= 0.97 * num_edges:
+            break
+        target *= num_edges / keys.numel()
+    if keys.numel() > num_edges:
+        keep = torch.randperm(keys.numel(), generator=gen, device=dev)[:num_edges]
+        keys = torch.sort(keys[keep]).values
+    return _csr_from_keys(num_vertices, keys)
+
+
 def uniform_csr(num_vertices: int, num_edges: int, seed: int = 0) -> HostCSR:
     """``num_edges`` distinct directed edges drawn uniformly (Cora-shaped synthetic, config 1)."""
     rng = np.random.default_rng(seed)

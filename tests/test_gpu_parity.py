@@ -423,3 +423,34 @@ def test_edge_score_fused_softmax(dev, k, dtype, d, pad):
         assert rel(fused, two_pass) < (1e-14 if dtype == torch.float64 else 3e-7)
     ref = O.build_P_values(csr.rowptr, csr.colidx, Zc.to(acc).double(), mode="per_edge")
     assert rel(fused, ref) < (1e-13 if dtype == torch.float64 else 5e-6)
+
+
+def test_bf16_storage_end_to_end(tmp_path):
+    """Graph(dtype="bfloat16"): bf16 Z/X in HBM, fp32 accumulate and P; converges next to the fp32 reference."""
+    gold, _ = graph_from_golden(tmp_path, "g5_symkarate_d16_g0.76.npz")
+    g = Graph(tmp_path / "g5_symkarate_d16_g0.76.npz", dtype="bfloat16")
+    assert g.X.dtype == torch.bfloat16
+    P = g.build_P(CosineSimilarity())
+    assert P.dtype == torch.float32
+    np.testing.assert_allclose(P.values().numpy(), gold["P0_values"], rtol=2e-2)
+    emb = Embedder(g, CosineSimilarity(), torch.device("cuda"), gamma=float(gold["gamma"]), tolerence=10,
+                   verbose=False, max_sweeps=300)
+    emb.iterate()
+    Z = g.Z
+    assert Z.dtype == torch.bfloat16 and len(emb.outer_deltas) < 40
+    assert O.rel_l2(Z.float(), torch.from_numpy(gold["Z_final"])) < 2e-2
+
+
+def test_powerlaw_generator_and_bf16_sweep(dev):
+    csr = synth.powerlaw_csr(100_000, 2_000_000, seed=5)
+    deg = np.diff(csr.rowptr)
+    assert 1_800_000 < csr.num_edges <= 2_000_000 and deg.max() > 1000 and (np.diff(csr.colidx.astype(np.int64))[
+        np.diff(np.repeat(np.arange(100_000), deg)) == 0] > 0).all()          # sorted, unique within rows
+    X = synth.gaussian_X(100_000, 128, seed=6).to(torch.bfloat16)
+    eng = SweepEngine(csr, X, dev)
+    eng.build_P()
+    P_or = O.build_P_values(csr.rowptr, csr.colidx, X.float())
+    assert rel(eng.P[:csr.num_edges], P_or) < 1e-5
+    delta = eng.sweep(0.76)
+    Z1, d_or = O.sweep(csr.rowptr, csr.colidx, P_or, X.float(), X.float(), 0.76)
+    assert O.rel_l2(eng.get_Z().float(), Z1) < 8e-3 and delta == pytest.approx(float(d_or), rel=2e-2)

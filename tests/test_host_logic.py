@@ -75,6 +75,14 @@ def test_duplicates_selfloop_string_ids_f64(tmp_path):
     assert g.V[0].outgoing_indices == [1, 2, 1]          # per-line list keeps the duplicate (graph.py:82)
 
 
+def test_graph_dtype_option(karate_root):
+    assert Graph(karate_root, embedding_dim=4).X.dtype == torch.float32            # default: as upstream
+    assert Graph(karate_root, embedding_dim=4, dtype="bfloat16").X.dtype == torch.bfloat16
+    assert Graph(karate_root, embedding_dim=4, dtype=torch.float64).X.dtype == torch.float64
+    with pytest.raises(ValueError):
+        Graph(karate_root, embedding_dim=4, dtype="int8")
+
+
 def test_loader_errors(tmp_path):
     with pytest.raises(FileNotFoundError):
         Graph(tmp_path / "nope")
