@@ -30,7 +30,19 @@ def read_edge_indices(data_root: Path, vertex_ids: Sequence[str]):
 
     An id resolves to the index of its FIRST occurrence in ``V`` (``list.index``,
     graph.py:81); an unknown id or a line without exactly one tab raises ValueError.
+    Parsed by the native loader (csrc/host_loader.cpp, O(|V| + |E|)) when libclane_host.so is
+    built, else by the equivalent Python loop below.
     """
+    data_root = Path(data_root)
+    with open(data_root.joinpath("E"), "r"):                    # FileNotFoundError propagates, as upstream
+        pass
+    native = _native_parse_edges(data_root)
+    if native is not None:
+        return native
+    return _python_parse_edges(data_root, vertex_ids)
+
+
+def _python_parse_edges(data_root: Path, vertex_ids: Sequence[str]):
     with open(Path(data_root).joinpath("E"), "r") as io:
         lines = io.read().strip().split("\n")
     first = {}
@@ -47,6 +59,48 @@ def read_edge_indices(data_root: Path, vertex_ids: Sequence[str]):
         except KeyError as exc:
             raise ValueError(f"{exc.args[0]!r} is not in list") from None
     return src, dst
+
+
+_HOST_LIB = None
+
+
+def _host_lib():
+    """ctypes handle of libclane_host.so (host-side parser), or None when it has not been built."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        import ctypes as C
+        path = Path(__file__).resolve().parent / "libclane_host.so"
+        if not path.exists():
+            _HOST_LIB = False
+        else:
+            lib = C.CDLL(str(path))
+            lib.clane_count_lines.restype = C.c_int64
+            lib.clane_count_lines.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+            lib.clane_parse_edges.restype = C.c_int64
+            lib.clane_parse_edges.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p,
+                                              C.c_int]
+            _HOST_LIB = lib
+    return _HOST_LIB or None
+
+
+def _native_parse_edges(data_root: Path):
+    lib = _host_lib()
+    if lib is None:
+        return None
+    import ctypes as C
+    err = C.create_string_buffer(256)
+    e_path, v_path = str(data_root / "E").encode(), str(data_root / "V").encode()
+    n = lib.clane_count_lines(e_path, err, len(err))
+    if n < 0:
+        raise OSError(err.value.decode())
+    src = np.empty(n, dtype=np.int64)
+    dst = np.empty(n, dtype=np.int64)
+    got = lib.clane_parse_edges(v_path, e_path, src.ctypes.data, dst.ctypes.data, n, err, len(err))
+    if got in (-2, -3):
+        raise ValueError(err.value.decode())
+    if got < 0:
+        raise OSError(err.value.decode())
+    return src[:got], dst[:got]
 
 
 def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray) -> HostCSR:

@@ -274,3 +274,41 @@ def test_custom_similarity_callable_goes_through_plugin_protocol(tmp_path):
     P = g.build_P(sim)
     assert calls == [((156, 2), (156, 2))]                 # ONE batched call with all edges (graph.py:121)
     np.testing.assert_allclose(P.values().numpy(), gold["P0_values"], rtol=3e-6, atol=1e-7)
+
+
+# ---- native loader (csrc/host_loader.cpp) == Python loader == reference semantics --------------------
+def test_native_loader_matches_python_loader(tmp_path, karate_root):
+    from clane_amd import graph as G
+    assert G._host_lib() is not None, "libclane_host.so not built (run __graft_entry__.build())"
+    cases = {"karate": karate_root,
+             "strings": write_data_root(tmp_path / "s", ["a", "b b", "a", "", " d"], ["a", "b b", "", " d"],
+                                        ["b b", "a", "a", "b b"])}
+    crlf = write_data_root(tmp_path / "crlf", ["x", "y", "z"], ["x", "z"], ["y", "x"])
+    for f in ("V", "E"):
+        (crlf / f).write_bytes((crlf / f).read_bytes().replace(b"\n", b"\r\n"))
+    cases["crlf"] = crlf
+    rng = np.random.default_rng(0)
+    ids = [f"v{i}" for i in rng.permutation(5000)]
+    cases["big"] = write_data_root(tmp_path / "big", ids, rng.choice(ids, 40000), rng.choice(ids, 40000))
+    for name, root in cases.items():
+        vids = G.read_vertex_ids(root)
+        ns, nd = G._native_parse_edges(Path(root))
+        ps, pd_ = G._python_parse_edges(Path(root), vids)
+        np.testing.assert_array_equal(ns, ps, err_msg=name)
+        np.testing.assert_array_equal(nd, pd_, err_msg=name)
+    for bad_lines, exc in (("1 2\n", ValueError), ("1\t2\t3\n", ValueError), ("1\t9\n", ValueError), ("", ValueError)):
+        root = write_data_root(tmp_path / f"bad{abs(hash(bad_lines))}", ["1", "2"], ["1"], ["2"])
+        (root / "E").write_text(bad_lines)
+        with pytest.raises(exc):
+            G._native_parse_edges(root)
+        with pytest.raises(exc):
+            G._python_parse_edges(root, ["1", "2"])
+
+
+def test_clane_import_shim():
+    import clane.graph, clane.similarity, clane.embedder                    # noqa: E401
+    from clane.__main__ import get_parser
+    import clane_amd.graph
+    assert clane.graph.Graph is clane_amd.graph.Graph
+    assert clane.similarity.CosineSimilarity().is_trainable() is False
+    assert clane.embedder.Embedder.Tolerence(3).value == 3 and get_parser().prog == "clane"
