@@ -42,25 +42,29 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(csr, X, P_host, gamma, Z1_gpu, budget_s=25.0):
-    """Oracle sweep (PyTorch-CPU sparse mm, the 'port') timed on this box's host cores."""
+def cpu_baseline(csr, X, P_host, gamma, Z1_gpu, budget_s=20.0):
+    """The oracle's sweep timed on this box's host cores: the plain-C restatement (oracle/clane_oracle.c,
+    OpenMP over rows, same CSR / fp32) -- kind "port".  Also the parity check of the first GPU sweep."""
     from oracle import clane_oracle as O
-    threads = torch.get_num_threads()
-    if X.dtype == torch.bfloat16:       # the oracle computes in fp32 on the bf16-rounded inputs
+    from oracle import clane_oracle_c as OC
+    if X.dtype != torch.float32:        # the oracle computes in fp32 on the (bf16-)rounded inputs
         X = X.float()
-    Ps = O.as_sparse(csr.rowptr, csr.colidx, P_host)
-    Z = X.clone()
+    P_host = P_host.float()
+    threads = OC.threads()
+    out = torch.empty_like(X)
     t0 = time.perf_counter()
-    Z, _ = O.sweep(csr.rowptr, csr.colidx, P_host, X, Z, gamma, Ps)          # warm-up, also the parity sweep
+    Z, _ = OC.sweep(csr.rowptr, csr.colidx, P_host, X, X, gamma, out=out)      # warm-up, also the parity sweep
     first = time.perf_counter() - t0
-    parity = O.rel_l2(Z1_gpu, Z)
-    n = int(max(1, min(10, budget_s // max(first, 1e-3))))
+    parity = O.rel_l2(Z1_gpu.float(), Z)
+    n = int(max(1, min(20, budget_s // max(first, 1e-3))))
+    Za, Zb = Z.clone(), out
     t0 = time.perf_counter()
     for _ in range(n):
-        Z, _ = O.sweep(csr.rowptr, csr.colidx, P_host, X, Z, gamma, Ps)
+        Zb, _ = OC.sweep(csr.rowptr, csr.colidx, P_host, X, Za, gamma, out=Zb)
+        Za, Zb = Zb, Za
     per = (time.perf_counter() - t0) / n
     return {"value": 1.0 / per, "unit": "sweeps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} full sweeps of the same graph (oracle/clane_oracle.py sweep, torch.sparse.mm, "
+            "sample": f"{n} full sweeps of the same graph by oracle/clane_oracle.c (plain C, OpenMP over rows, "
                       f"{threads} threads), P taken from the GPU build_P"}, parity
 
 

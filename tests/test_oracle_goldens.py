@@ -141,3 +141,34 @@ def test_read_graph_files_errors(tmp_path):
     (root / "E").write_text("1 2\n")
     with pytest.raises(ValueError):
         O.read_graph_files(root)
+
+
+# ---- the plain-C oracle (oracle/clane_oracle.c) against the same reference fixtures ---------------------
+@pytest.mark.parametrize("name", [n for n in KARATE_LIKE if "f64" not in n] + ["g8_corashape.npz"])
+def test_c_oracle_matches_reference_and_python_oracle(name):
+    from oracle import clane_oracle_c as OC
+    g = load_golden(name)
+    if name == "g8_corashape.npz":
+        V, d = int(g["V"]), int(g["d"])
+        X = torch.zeros(V, d)
+        X[torch.from_numpy(g["X_nz_row"].astype(np.int64)), torch.from_numpy(g["X_nz_col"].astype(np.int64))] = 1.0
+        rowptr, colidx = O.build_csr(V, g["src"], g["dst"])
+        P_ref, Z1_ref = g["P_values"], None
+    else:
+        X = torch.from_numpy(g["X"])
+        rowptr, colidx = _csr_of(g)
+        P_ref, Z1_ref = g["P0_values"], g["Z_sweep1"]
+    P, D = OC.build_P(rowptr, colidx, X)
+    np.testing.assert_allclose(P.numpy(), P_ref, rtol=3e-6, atol=1e-7)
+    assert D == pytest.approx(O.global_denominator(rowptr, colidx, X), rel=1e-6)
+    Z1, delta = OC.sweep(rowptr, colidx, P, X, X, float(g["gamma"]))
+    Z1_py, delta_py = O.sweep(rowptr, colidx, P, X, X.clone(), float(g["gamma"]))
+    assert O.rel_l2(Z1, Z1_py) < 1e-6 and delta == pytest.approx(float(delta_py), rel=1e-5)
+    if Z1_ref is not None:
+        assert O.rel_l2(Z1, torch.from_numpy(Z1_ref)) < 1e-6
+    else:
+        np.testing.assert_allclose(Z1[:24].numpy(), g["Z1_head"], rtol=1e-6, atol=1e-7)
+        assert delta == pytest.approx(float(g["delta1"]), rel=1e-5)
+    sink = np.diff(rowptr) == 0
+    assert torch.equal(Z1[torch.from_numpy(sink)], X[torch.from_numpy(sink)])
+    assert OC.threads() >= 1
