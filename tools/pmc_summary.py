@@ -17,8 +17,13 @@ import json
 from pathlib import Path
 
 
+def _newest(pattern):
+    import os
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)   # gpurun merges runs into one directory
+
+
 def per_kernel(dirname):
-    f = glob.glob(f"{dirname}/**/*counter_collection.csv", recursive=True)[0]
+    f = _newest(f"{dirname}/**/*counter_collection.csv")
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "clane::" in r["Kernel_Name"]:
@@ -72,7 +77,7 @@ def main():
     data[args.workload] = entry
     tfile.write_text(json.dumps(data, indent=1) + "\n")
     if args.stats:
-        f = glob.glob(f"{args.stats}/**/*kernel_stats.csv", recursive=True)[0]
+        f = _newest(f"{args.stats}/**/*kernel_stats.csv")
         rows = list(csv.DictReader(open(f)))
         sl = [f"# rocprofv3 --kernel-trace --stats, {args.workload} ({args.tag})", "",
               "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
