@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=None)
     ap.add_argument("--long-threshold", type=int, default=None)
     ap.add_argument("--hub-threshold", type=int, default=None)
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather", "allgather_all"],
+                    help="N > 1: how updated rows travel (see clane_amd/halo.py, partition.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch l1_distance over two [V,d] matrices (known bytes) -- PMC calibration")
@@ -112,7 +114,7 @@ def main():
 
     t0 = time.perf_counter()
     eng = SweepEngine(csr, X, dev, process_group=pg, chunks=args.chunks, long_threshold=args.long_threshold,
-                      hub_threshold=args.hub_threshold)
+                      hub_threshold=args.hub_threshold, exchange=args.exchange)
     torch.cuda.synchronize()
     log(f"engine up in {time.perf_counter() - t0:.1f}s; rank rows={eng.part.n_local} edges={eng.E_loc} "
         f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
@@ -188,7 +190,7 @@ def main():
                                f"gamma={args.gamma}, CosineSimilarity "
                                f"(reference mode), seeds {gseed}/{xseed}",
                    "parallelism": f"row-partition x{world}, {chunks} launch block(s)/sweep"
-                                  + (f", in-place RCCL all-gather of the live rows per chunk "
+                                  + (f", exchange={args.exchange} over RCCL per chunk "
                                      f"({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep) + scalar "
                                      f"all-reduce" if world > 1 else "")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBPS,

@@ -45,6 +45,7 @@ for _s in ("f32", "f64", "bf16"):
         C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _i32, _p, _p])
     SIGNATURES[f"clane_spmm_update_long_{_s}"] = (
         C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p])
+    SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 for _s in ("f32", "f64"):
     SIGNATURES[f"clane_degree_weighted_sums_{_s}"] = (C.c_int, [_p, _p, _p, _i64, _p, _p, _p])
@@ -208,6 +209,13 @@ class HipKernels:
         self._check(self._fn("clane_l1_distance", A.dtype)(
             ap, lda, bp, ldb, A.shape[0], d, _vec(ws, torch.float64, "ws"), _vec(out, torch.float64, "out"),
             self._stream(A)), "clane_l1_distance")
+
+    def gather_rows(self, src, idx, d: int, dst):
+        """dst[i, :] = src[idx[i], :] (send-buffer packing of the halo exchange)."""
+        sp, lds = _mat(src, "src")
+        dp, ldd = _mat(dst, "dst")
+        self._check(self._fn("clane_gather_rows", src.dtype)(
+            sp, lds, _vec(idx, torch.int32, "idx"), idx.numel(), d, dp, ldd, self._stream(src)), "clane_gather_rows")
 
     # -- CosineSimilarity on explicit pairs ------------------------------------------------
     def pair_cosine(self, A, B, d: int, out, ws):

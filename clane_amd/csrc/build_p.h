@@ -202,6 +202,25 @@ __global__ __launch_bounds__(kBlock) void l1_distance_kernel(const T *__restrict
     if (threadIdx.x == 0) ws[blockIdx.x] = t;
 }
 
+// ---- dst[i, :] = src[idx[i], :]  -- packs the rows other ranks read before the halo exchange -------
+template <typename T, int VEC, int LPR>
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const T *__restrict__ src, int64_t lds,
+                                                             const int32_t *__restrict__ idx, int64_t n, int d,
+                                                             T *__restrict__ dst, int64_t ldd) {
+    constexpr int RPW = kWave / LPR;
+    const int lane = lane_id();
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t wave = int64_t(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+    const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
+    for (int64_t base = wave * RPW; base < n; base += nwaves * RPW) {
+        const int64_t r = base + sub;
+        if (r >= n) continue;
+        const int64_t row = idx[r];
+        for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC)
+            store_pack<T, VEC>(dst + r * ldd + c0, load_pack<T, VEC>(src + row * lds + c0));
+    }
+}
+
 // ---- CosineSimilarity on explicit pairs (similarity.py:26-37) --------------------------------
 // out[r] <- dot(A_r, B_r); ws[b], ws[G+b] <- block partials of |A_r|^2, |B_r|^2.
 template <typename T, int VEC, int LPR>

@@ -253,6 +253,19 @@ int l1_distance(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows,
 }
 
 template <typename T>
+int gather_rows(const T *src, int64_t lds, const int32_t *idx, int64_t n, int32_t d, T *dst, int64_t ldd, void *stream) {
+    REQUIRE(n >= 0 && d > 0 && lds >= d && ldd >= d, "gather_rows: bad shape");
+    if (n == 0) return CLANE_OK;
+    REQUIRE(src && idx && dst, "gather_rows: null pointer");
+    const Layout L = pick_layout<T>(d, {src, dst}, {lds, ldd});
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        const int grid = grid_for_waves(ceil_div(n, kWave / LPR));
+        gather_rows_kernel<T, VEC, LPR><<<grid, kBlock, 0, (hipStream_t)stream>>>(src, lds, idx, n, d, dst, ldd);
+    });
+    return check_launch("gather_rows");
+}
+
+template <typename T>
 int pair_cosine(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows, int32_t d,
                 typename Elem<T>::acc_t *out, double *ws, void *stream) {
     REQUIRE(nrows >= 0 && d > 0 && lda >= d && ldb >= d, "pair_cosine: bad shape");
@@ -376,6 +389,20 @@ int clane_l1_distance_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, in
                            double *ws, double *out, void *stream) {
     return l1_distance<bf16_t>(reinterpret_cast<const bf16_t *>(A), lda, reinterpret_cast<const bf16_t *>(B), ldb,
                                nrows, d, ws, out, stream);
+}
+
+int clane_gather_rows_f32(const float *src, int64_t lds, const int32_t *idx, int64_t n, int32_t d, float *dst,
+                          int64_t ldd, void *stream) {
+    return gather_rows<float>(src, lds, idx, n, d, dst, ldd, stream);
+}
+int clane_gather_rows_f64(const double *src, int64_t lds, const int32_t *idx, int64_t n, int32_t d, double *dst,
+                          int64_t ldd, void *stream) {
+    return gather_rows<double>(src, lds, idx, n, d, dst, ldd, stream);
+}
+int clane_gather_rows_bf16(const uint16_t *src, int64_t lds, const int32_t *idx, int64_t n, int32_t d, uint16_t *dst,
+                           int64_t ldd, void *stream) {
+    return gather_rows<bf16_t>(reinterpret_cast<const bf16_t *>(src), lds, idx, n, d,
+                               reinterpret_cast<bf16_t *>(dst), ldd, stream);
 }
 
 int clane_pair_cosine_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t nrows, int32_t d,

@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import _hip
+from .halo import HaloLayout, build_halo_layout
 from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
 
 # Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md):
@@ -56,7 +57,10 @@ class SweepEngine:
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
-                 exchange_live_only: bool = True):
+                 exchange: str = "halo"):
+        """``exchange`` (N > 1 only): "halo" -- a compact per-rank table, rows sent only to the ranks that read
+        them (halo.py); "allgather" -- full-size Z on every rank, in-place all-gather of the live rows
+        (partition.py); "allgather_all" -- the same without the live/quiet split."""
         if X.dim() != 2 or X.shape[0] != csr.num_vertices:
             raise ValueError(f"X must be [V, d] with V={csr.num_vertices}, got {tuple(X.shape)}")
         if cosine_mode not in ("reference", "per_edge"):
@@ -77,10 +81,19 @@ class SweepEngine:
             chunks = 1 if self.world == 1 else 4
         self.V, self.d = csr.num_vertices, int(X.shape[1])
         self.ld = _round_up(self.d, _hip.VEC_ELEMS[X.dtype])
-        live = csr.live_mask() if (self.world > 1 and exchange_live_only) else None
-        self.part = RowPartition.create(self.V, self.world, rank, chunks, live_mask=live, shuffle=shuffle, seed=seed)
-        self.blocks: List[Block] = self.part.blocks()
-        self.local: LocalCSR = localize(csr, self.part)
+        if exchange not in ("halo", "allgather", "allgather_all"):
+            raise ValueError(f"exchange must be 'halo', 'allgather' or 'allgather_all', got {exchange!r}")
+        self.halo = self.world > 1 and exchange == "halo"
+        if self.halo:
+            self.part = build_halo_layout(csr, self.world, rank, chunks, shuffle=shuffle is not False, seed=seed)
+            self.blocks: List[Block] = self.part.blocks
+            self.local: LocalCSR = self.part.local
+        else:
+            live = csr.live_mask() if (self.world > 1 and exchange == "allgather") else None
+            self.part = RowPartition.create(self.V, self.world, rank, chunks, live_mask=live, shuffle=shuffle,
+                                            seed=seed)
+            self.blocks = self.part.blocks()
+            self.local = localize(csr, self.part)
         if long_threshold is None:
             long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[64 // lanes_per_row(self.d, X.dtype)]
         self.long_threshold = int(long_threshold)
@@ -112,8 +125,22 @@ class SweepEngine:
             self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(b.nrows, int(is_long.sum())))
         self.partials = torch.zeros(self.partial_off[-1], dtype=torch.float64, device=dev)
 
+        # ---- halo exchange: send lists and send buffers (one per own chunk) -----------------
+        self.send_rows: List[Optional[torch.Tensor]] = []
+        self.send_buf: List[Optional[torch.Tensor]] = []
+        for b in self.blocks:
+            ex = b.exchange
+            has = ex is not None and ex.send_rows.size > 0
+            self.send_rows.append(torch.from_numpy(ex.send_rows).to(dev) if has else None)
+            self.send_buf.append(torch.zeros(ex.send_rows.size, self.ld, dtype=self.dtype, device=dev) if has
+                                 else (torch.zeros(0, self.ld, dtype=self.dtype, device=dev) if ex is not None else None))
+
         # ---- embeddings ---------------------------------------------------------------
-        self.pos = torch.from_numpy(self.part.position_of_vertex())           # host, int64 [V]
+        if self.halo:
+            self.table_vertex = torch.from_numpy(self.part.table_vertex)      # host, int64 [table_rows]
+            self.slot = torch.from_numpy(self.part.vertex_slot)               # host, int64 [V]
+        else:
+            self.pos = torch.from_numpy(self.part.position_of_vertex())       # host, int64 [V]
         self.Zbuf = [torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype, device=dev) for _ in range(2)]
         self.cur = 0
         verts = torch.from_numpy(self.local.vertex)
@@ -154,7 +181,12 @@ class SweepEngine:
         if tuple(Z.shape) != (self.V, self.d):
             raise ValueError(f"set_Z: expected {(self.V, self.d)}, got {tuple(Z.shape)}")
         full = torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype)
-        full[self.pos, :self.d] = Z.detach().to("cpu", self.dtype)
+        Zc = Z.detach().to("cpu", self.dtype)
+        if self.halo:       # own rows, every remote row this rank reads, and the constant (sink) halo rows
+            held = self.table_vertex >= 0
+            full[held, :self.d] = Zc[self.table_vertex[held]]
+        else:
+            full[self.pos, :self.d] = Zc
         # BOTH ping-pong buffers: rows without out-edges never change (embedder.py:88-89), so the sweep
         # kernel leaves them alone (CLANE_SPMM_SINKS_UNTOUCHED) and relies on the two copies agreeing.
         for buf in self.Zbuf:
@@ -164,13 +196,19 @@ class SweepEngine:
 
     def get_Z(self) -> torch.Tensor:
         """Current embeddings as a fresh CPU tensor [V, d] in vertex order (collective when N > 1)."""
+        if self.halo:       # own rows of every rank, in slot order (slot = owner * n_local + local row)
+            import torch.distributed as dist
+            n = self.part.n_local
+            everyone = torch.empty(self.world * n, self.ld, dtype=self.dtype, device=self.device)
+            dist.all_gather_into_tensor(everyone, self.Zcur[:n].contiguous(), group=self.pg)
+            return everyone.to("cpu")[self.slot, :self.d].clone()
         self._sync_quiet_rows()
         return self.Zcur.to("cpu")[self.pos, :self.d].clone()
 
     def _sync_quiet_rows(self) -> None:
         """Quiet rows (no out-edges, or never read) are not exchanged during sweeps; bring the other
         ranks' copies up to date before the matrix leaves the engine."""
-        span = self.part.quiet_span()
+        span = None if self.halo else self.part.quiet_span()
         if span is None or not self.quiet_stale:
             return
         import torch.distributed as dist
@@ -240,6 +278,14 @@ class SweepEngine:
             if b.span is not None:
                 import torch.distributed as dist
                 works.append(dist.all_gather_into_tensor(Znew[b.span[0]:b.span[1]], Zn, group=self.pg, async_op=True))
+            elif b.exchange is not None:      # halo: pack the rows of this chunk that others read, swap, no unpack
+                import torch.distributed as dist
+                ex = b.exchange
+                if self.send_rows[i] is not None:
+                    k.gather_rows(Znew, self.send_rows[i], self.d, self.send_buf[i])
+                works.append(dist.all_to_all_single(Znew[ex.recv_start:ex.recv_start + ex.recv_rows], self.send_buf[i],
+                                                    output_split_sizes=ex.out_splits, input_split_sizes=ex.in_splits,
+                                                    group=self.pg, async_op=True))
         k.reduce_partials(self.partials, self.partials.numel(), self.ws, self.delta)
         self._all_reduce(self.delta)
         for w in works:
@@ -279,6 +325,8 @@ class SweepEngine:
     def exchange_bytes_per_sweep(self) -> int:
         """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""
         s = self.Zcur.element_size()
+        if self.halo:
+            return self.part.recv_rows_per_sweep() * self.ld * s
         return sum((b.span[1] - b.span[0] - b.nrows) * self.ld * s for b in self.blocks if b.span is not None)
 
     # ---- outer-loop delta (embedder.py:58-60) -------------------------------------------

@@ -331,7 +331,7 @@ class Graph(torch.utils.data.Dataset):
             rows = torch.repeat_interleave(torch.arange(eng.part.n_local, device=eng.device),
                                            eng.rowptr[1:] - eng.rowptr[:-1])
             Zd = eng.Zcur[:, :eng.d]
-            src_Z = Zd[torch.from_numpy(eng.part.local_positions()).to(eng.device)[rows]]
+            src_Z = Zd[torch.from_numpy(eng.part.local_positions()).to(eng.device)[rows]]   # single GPU: RowPartition
             dst_Z = Zd[eng.colidx.long()]
             scores = similarity(src_Z, dst_Z).detach().to(eng.acc_dtype).reshape(-1)
             eng.P[:eng.E_loc].copy_(scores)

@@ -62,6 +62,7 @@ class Block:
     nrows: int
     row0: int
     span: Optional[Tuple[int, int]]
+    exchange: Optional[object] = None      # halo.HaloExchange in halo mode
 
 
 @dataclass

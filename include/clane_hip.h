@@ -163,6 +163,15 @@ int clane_l1_distance_f64(const double *A, int64_t lda, const double *B, int64_t
 int clane_l1_distance_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, int64_t nrows, int32_t d,
                            double *ws, double *out, void *stream);
 
+/* dst[i,:] = src[idx[i],:] for i < n: packs the rows other ranks read into the send buffer of the
+ * multi-GPU halo exchange (no counterpart in the single-process reference). */
+int clane_gather_rows_f32(const float *src, int64_t lds, const int32_t *idx, int64_t n, int32_t d, float *dst,
+                          int64_t ldd, void *stream);
+int clane_gather_rows_f64(const double *src, int64_t lds, const int32_t *idx, int64_t n, int32_t d, double *dst,
+                          int64_t ldd, void *stream);
+int clane_gather_rows_bf16(const uint16_t *src, int64_t lds, const int32_t *idx, int64_t n, int32_t d, uint16_t *dst,
+                           int64_t ldd, void *stream);
+
 /* ---- CosineSimilarity.__call__ on explicit pairs (similarity.py:26-37):
  *   out[i] = dot(A[i,:], B[i,:]) / (||A||_F * ||B||_F)      -- global denominators.
  * ws: clane_reduce_ws_len() doubles. */

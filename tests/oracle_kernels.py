@@ -94,5 +94,8 @@ class OracleKernels:
         acc = torch.float64 if A.dtype == torch.float64 else torch.float32
         out[0] = (A[:, :d].to(acc) - B[:, :d].to(acc)).abs().sum().double()
 
+    def gather_rows(self, src, idx, d, dst):
+        dst[:idx.numel(), :d] = src[idx.long(), :d]
+
     def pair_cosine(self, A, B, d, out, ws):
         out.copy_(O.cosine_similarity(A[:, :d], B[:, :d]))

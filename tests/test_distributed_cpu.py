@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, chunks, name, out_dir):
+def _worker(rank, world, port, chunks, name, out_dir, exchange):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,11 +39,15 @@ def _worker(rank, world, port, chunks, name, out_dir):
         src, dst = (gold["edge_src"], gold["edge_dst"]) if "edge_src" in gold.files else (k["edge_src"], k["edge_dst"])
         root = write_data_root(Path(out_dir) / f"r{rank}", k["vertex_ids"], src, dst, gold["X"])
         g = Graph(root)
-        eng = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), process_group=dist.group.WORLD, chunks=chunks, seed=3)
+        eng = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), process_group=dist.group.WORLD, chunks=chunks, seed=3,
+                          exchange=exchange)
         g._attach_engine(eng)
-        n_quiet = int((~g.csr.live_mask()).sum())                          # live / quiet split for N > 1
-        assert eng.world == world and eng.part.quiet_per_rank == -(-n_quiet // world)
-        assert 0 < eng.exchange_bytes_per_sweep() <= (world - 1) * eng.part.n_local * eng.ld * 4
+        assert eng.world == world and eng.halo == (exchange == "halo")
+        full = (world - 1) * -(-len(g) // world) * eng.ld * 4
+        if exchange == "allgather":                                        # live / quiet split
+            n_quiet = int((~g.csr.live_mask()).sum())
+            assert eng.part.quiet_per_rank == -(-n_quiet // world)
+        assert 0 < eng.exchange_bytes_per_sweep() <= full + 4 * eng.ld * 4 * world
 
         # build_P: every rank assembles the full P in the reference's (row, col) order
         P = g.build_P(CosineSimilarity())
@@ -61,13 +65,14 @@ def _worker(rank, world, port, chunks, name, out_dir):
             assert abs(delta - float(d_or)) <= 1e-5 * max(1.0, float(d_or))
             assert O.rel_l2(eng.get_Z(), Z) < 1e-6
         # both ping-pong buffers agree on rows without out-edges (CLANE_SPMM_SINKS_UNTOUCHED invariant)
-        sink_pos = eng.pos[torch.from_numpy(np.diff(rowptr) == 0)]
-        assert torch.equal(eng.Zbuf[0][sink_pos], eng.Zbuf[1][sink_pos])
+        if not eng.halo:
+            sink_pos = eng.pos[torch.from_numpy(np.diff(rowptr) == 0)]
+            assert torch.equal(eng.Zbuf[0][sink_pos], eng.Zbuf[1][sink_pos])
 
         # full Embedder control flow on top: identical decisions on every rank, final Z = reference
         g2 = Graph(root)
         g2._attach_engine(SweepEngine(g2.csr, g2.X, "cpu", OracleKernels(), process_group=dist.group.WORLD,
-                                      chunks=chunks, seed=3))
+                                      chunks=chunks, seed=3, exchange=exchange))
         emb = Embedder(g2, CosineSimilarity(), torch.device("cpu"), gamma=gamma, tolerence=int(gold["tolerence"]),
                        verbose=False)
         emb.iterate()
@@ -80,9 +85,18 @@ def _worker(rank, world, port, chunks, name, out_dir):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["halo", "allgather", "allgather_all"])
 @pytest.mark.parametrize("name,chunks", [("g5_symkarate_d16_g0.76.npz", 1), ("g5_symkarate_d16_g0.76.npz", 3),
                                          ("g4_karate_d2.npz", 2)])
-def test_two_rank_gloo_matches_reference(tmp_path, name, chunks):
+def test_two_rank_gloo_matches_reference(tmp_path, name, chunks, exchange):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), chunks, name, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), chunks, name, str(tmp_path), exchange), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_three_rank_gloo_halo(tmp_path):
+    """Odd world size: every (source, destination, chunk) list of the halo exchange is exercised."""
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), 2, "g5_symkarate_d16_g0.5.npz", str(tmp_path), "halo"), nprocs=world,
+             join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))

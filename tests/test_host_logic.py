@@ -312,3 +312,44 @@ def test_clane_import_shim():
     assert clane.graph.Graph is clane_amd.graph.Graph
     assert clane.similarity.CosineSimilarity().is_trainable() is False
     assert clane.embedder.Embedder.Tolerence(3).value == 3 and get_parser().prog == "clane"
+
+
+# ---- halo layout: sender and receiver agree on every (source, destination, chunk) list ----------------
+@pytest.mark.parametrize("W,C", [(2, 1), (3, 2), (8, 4)])
+def test_halo_layout_is_consistent_across_ranks(W, C):
+    from clane_amd.halo import build_halo_layout
+    from clane_amd import synth
+    csr = synth.rmat_csr(3000, 30000, seed=5, device="cpu")
+    outdeg = csr.outdeg()
+    L = [build_halo_layout(csr, W, r, C, seed=7) for r in range(W)]
+    n_local = L[0].n_local
+    assert all(l.n_local == n_local and np.array_equal(l.vertex_slot, L[0].vertex_slot) for l in L)
+    owned = np.concatenate([l.table_vertex[:n_local][l.table_vertex[:n_local] >= 0] for l in L])
+    assert sorted(owned.tolist()) == list(range(3000))                        # every vertex owned exactly once
+    for r, l in enumerate(L):
+        own = l.table_vertex[:n_local]
+        # every column this rank reads is in its table, and CSR rows match the global graph
+        for lr in range(n_local):
+            v = own[lr]
+            cols = l.table_vertex[l.local.colidx[l.local.rowptr[lr]:l.local.rowptr[lr + 1]]]
+            ref = csr.colidx[csr.rowptr[v]:csr.rowptr[v + 1]] if v >= 0 else []
+            assert sorted(cols.tolist()) == sorted(np.asarray(ref).tolist())
+        assert len(l.blocks) == C and sum(b.nrows for b in l.blocks) == n_local
+        for c, b in enumerate(l.blocks):
+            ex = b.exchange
+            assert len(ex.in_splits) == len(ex.out_splits) == W and ex.in_splits[r] == 0 and ex.out_splits[r] == 0
+            assert sum(ex.in_splits) == ex.send_rows.size and sum(ex.out_splits) == ex.recv_rows
+            assert ((ex.send_rows >= b.local_start) & (ex.send_rows < b.local_start + b.nrows)).all()
+            assert (outdeg[own[ex.send_rows]] > 0).all()                     # constant rows are never re-sent
+            # what rank r sends to q in chunk c is exactly what q expects from r in its chunk-c halo slice
+            off = 0
+            for q in range(W):
+                sent = own[ex.send_rows[off:off + ex.in_splits[q]]]
+                off += ex.in_splits[q]
+                exq = L[q].blocks[c].exchange
+                start = exq.recv_start + sum(exq.out_splits[:r])
+                expect = L[q].table_vertex[start:start + exq.out_splits[r]]
+                np.testing.assert_array_equal(sent, expect)
+        # the constant tail of the halo holds remote rows without out-edges
+        tail = l.table_vertex[l.blocks[-1].exchange.recv_start + l.blocks[-1].exchange.recv_rows:]
+        assert (outdeg[tail] == 0).all()
