@@ -1,0 +1,50 @@
+"""The three collectives of the row-partitioned sweep behind one small interface.
+
+``TorchComm`` is the product implementation: ``torch.distributed`` on a process group (backend "nccl" =
+RCCL over xGMI on ROCm, one process per GPU; "gloo" in the CPU tests).  The engine never calls
+``torch.distributed`` directly, so tests can also drive several engines inside ONE process (threads sharing a
+GPU) through an in-memory implementation of the same interface and check the exchange layouts with the real
+HIP kernels on a single card.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class TorchComm:
+    def __init__(self, process_group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if process_group is not None else 1
+        self.rank = dist.get_rank(process_group) if process_group is not None else 0
+
+    def all_reduce_sum(self, t: torch.Tensor) -> None:
+        if self.world > 1:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.pg)
+
+    def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+        """out = concat over ranks of inp (inp may be the rank's own slice of out: in-place form)."""
+        w = self._dist.all_gather_into_tensor(out, inp, group=self.pg, async_op=async_op)
+        return w if async_op else _Done()
+
+    def all_to_all_rows(self, out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_splits: List[int],
+                        async_op: bool = False):
+        """Row blocks of `inp` (in_splits[q] rows to rank q) -> row blocks of `out` (out_splits[q] rows from q)."""
+        w = self._dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                         group=self.pg, async_op=async_op)
+        return w if async_op else _Done()
+
+    def all_gather_object(self, obj) -> list:
+        if self.world == 1:
+            return [obj]
+        out: List[Optional[object]] = [None] * self.world
+        self._dist.all_gather_object(out, obj, group=self.pg)
+        return out

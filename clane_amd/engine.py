@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import _hip
+from .comm import TorchComm
 from .halo import HaloLayout, build_halo_layout
 from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
 
@@ -57,7 +58,7 @@ class SweepEngine:
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
-                 exchange: str = "halo"):
+                 exchange: str = "halo", comm=None):
         """``exchange`` (N > 1 only): "halo" -- a compact per-rank table, rows sent only to the ranks that read
         them (halo.py); "allgather" -- full-size Z on every rank, in-place all-gather of the live rows
         (partition.py); "allgather_all" -- the same without the live/quiet split."""
@@ -71,12 +72,9 @@ class SweepEngine:
         self.acc_dtype = _hip.acc_dtype(X.dtype)
         self.cosine_mode = cosine_mode
         self.pg = process_group
-        self.world = 1
-        rank = 0
-        if process_group is not None:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(process_group)
-            rank = dist.get_rank(process_group)
+        self.comm = comm if comm is not None else (TorchComm(process_group) if process_group is not None else None)
+        self.world = self.comm.world if self.comm is not None else 1
+        rank = self.comm.rank if self.comm is not None else 0
         if chunks is None:
             chunks = 1 if self.world == 1 else 4
         self.V, self.d = csr.num_vertices, int(X.shape[1])
@@ -197,10 +195,9 @@ class SweepEngine:
     def get_Z(self) -> torch.Tensor:
         """Current embeddings as a fresh CPU tensor [V, d] in vertex order (collective when N > 1)."""
         if self.halo:       # own rows of every rank, in slot order (slot = owner * n_local + local row)
-            import torch.distributed as dist
             n = self.part.n_local
             everyone = torch.empty(self.world * n, self.ld, dtype=self.dtype, device=self.device)
-            dist.all_gather_into_tensor(everyone, self.Zcur[:n].contiguous(), group=self.pg)
+            self.comm.all_gather_into(everyone, self.Zcur[:n].contiguous())
             return everyone.to("cpu")[self.slot, :self.d].clone()
         self._sync_quiet_rows()
         return self.Zcur.to("cpu")[self.pos, :self.d].clone()
@@ -211,10 +208,9 @@ class SweepEngine:
         span = None if self.halo else self.part.quiet_span()
         if span is None or not self.quiet_stale:
             return
-        import torch.distributed as dist
         begin, end, q = span
         mine = self.Zcur[begin + self.part.rank * q: begin + (self.part.rank + 1) * q]
-        dist.all_gather_into_tensor(self.Zcur[begin:end], mine, group=self.pg)
+        self.comm.all_gather_into(self.Zcur[begin:end], mine)
         self.quiet_stale = False
 
     # ---- build_P (graph.py:118-128) -----------------------------------------------------
@@ -276,16 +272,13 @@ class SweepEngine:
             if ev:
                 ev[3].record()
             if b.span is not None:
-                import torch.distributed as dist
-                works.append(dist.all_gather_into_tensor(Znew[b.span[0]:b.span[1]], Zn, group=self.pg, async_op=True))
+                works.append(self.comm.all_gather_into(Znew[b.span[0]:b.span[1]], Zn, async_op=True))
             elif b.exchange is not None:      # halo: pack the rows of this chunk that others read, swap, no unpack
-                import torch.distributed as dist
                 ex = b.exchange
                 if self.send_rows[i] is not None:
                     k.gather_rows(Znew, self.send_rows[i], self.d, self.send_buf[i])
-                works.append(dist.all_to_all_single(Znew[ex.recv_start:ex.recv_start + ex.recv_rows], self.send_buf[i],
-                                                    output_split_sizes=ex.out_splits, input_split_sizes=ex.in_splits,
-                                                    group=self.pg, async_op=True))
+                works.append(self.comm.all_to_all_rows(Znew[ex.recv_start:ex.recv_start + ex.recv_rows],
+                                                       self.send_buf[i], ex.out_splits, ex.in_splits, async_op=True))
         k.reduce_partials(self.partials, self.partials.numel(), self.ws, self.delta)
         self._all_reduce(self.delta)
         for w in works:
@@ -349,5 +342,4 @@ class SweepEngine:
     # ---- collectives ------------------------------------------------------------------
     def _all_reduce(self, t: torch.Tensor) -> None:
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+            self.comm.all_reduce_sum(t)

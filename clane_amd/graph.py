@@ -344,11 +344,7 @@ class Graph(torch.utils.data.Dataset):
         """P values of every rank, put back into the global (row, col)-sorted edge order."""
         out = torch.empty(self.csr.num_edges, dtype=eng.acc_dtype)
         local = (torch.from_numpy(eng.local.edge_origin), eng.P[:eng.E_loc].to("cpu"))
-        pieces = [local]
-        if eng.world > 1:
-            import torch.distributed as dist
-            pieces = [None] * eng.world
-            dist.all_gather_object(pieces, local, group=eng.pg)
+        pieces = [local] if eng.world == 1 else eng.comm.all_gather_object(local)
         for origin, vals in pieces:
             out[origin] = vals
         return out

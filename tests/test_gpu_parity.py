@@ -454,3 +454,50 @@ def test_powerlaw_generator_and_bf16_sweep(dev):
     delta = eng.sweep(0.76)
     Z1, d_or = O.sweep(csr.rowptr, csr.colidx, P_or, X.float(), X.float(), 0.76)
     assert O.rel_l2(eng.get_Z().float(), Z1) < 8e-3 and delta == pytest.approx(float(d_or), rel=2e-2)
+
+
+@pytest.mark.parametrize("exchange,world", [("halo", 4), ("halo", 3), ("allgather", 4)])
+def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world):
+    """W ranks as threads of this process, all on cuda:0, collectives through tests/thread_comm.py: the halo /
+    all-gather layouts, chunking, relabelled CSR and send-buffer packing run with the real HIP kernels."""
+    import threading
+    from .thread_comm import ThreadWorld
+    V, E, d, gamma = 20_000, 300_000, 256, 0.76
+    csr = synth.rmat_csr(V, E, seed=9)
+    X = synth.gaussian_X(V, d, seed=10)
+    P_or = O.build_P_values(csr.rowptr, csr.colidx, X)
+    Z_or, deltas_or = X.clone(), []
+    Ps = O.as_sparse(csr.rowptr, csr.colidx, P_or)
+    for _ in range(3):
+        Z_or, dl = O.sweep(csr.rowptr, csr.colidx, P_or, X, Z_or, gamma, Ps)
+        deltas_or.append(float(dl))
+    shared, results, errors = ThreadWorld(world), [None] * world, []
+
+    def run(rank):
+        try:
+            with torch.cuda.device(dev):
+                eng = SweepEngine(csr, X, dev, comm=shared.comm(rank), chunks=3, exchange=exchange, seed=4)
+                eng.build_P()
+                P_local = eng.P[:eng.E_loc].cpu()
+                deltas = [eng.sweep(gamma) for _ in range(3)]
+                results[rank] = (eng.get_Z(), deltas, P_local, eng.local.edge_origin, eng.exchange_bytes_per_sweep())
+        except Exception as exc:                                    # surface the failure, release the others
+            errors.append((rank, exc))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    P_all = torch.empty(E)
+    for Z, deltas, P_local, origin, nbytes in results:
+        assert O.rel_l2(Z, Z_or) < 1e-5
+        for a, b in zip(deltas, deltas_or):
+            assert a == pytest.approx(b, rel=1e-4)
+        P_all[torch.from_numpy(origin)] = P_local
+        assert 0 < nbytes < (world - 1) * -(-V // world) * d * 4 + 1
+    assert rel(P_all, P_or) < 1e-5
+    if exchange == "halo":                                          # the point of the halo: fewer bytes than all rows
+        assert results[0][4] < 0.8 * (world - 1) * (V // world) * d * 4
