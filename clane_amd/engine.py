@@ -159,6 +159,7 @@ class SweepEngine:
         self.snap: Optional[torch.Tensor] = None
         self.sweeps_done = 0
         # optional per-kernel timing with HIP events on the launch stream (bench.py)
+        self._plans = {}                 # (parity, gamma, stream) -> launch list (see _build_plan)
         self.time_kernels = False
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
 
@@ -241,45 +242,73 @@ class SweepEngine:
         self.P_valid = True
 
     # ---- one sweep (embedder.py:84-94) --------------------------------------------------
-    def sweep(self, gamma: float) -> float:
-        """Z <- X + gamma * P Z on the owned rows, exchange, return sum|Z_new - Z_old| (global)."""
-        if not self.P_valid:
-            raise RuntimeError("sweep() before build_P()")
+    def _bind(self, method: str, *args, **kwargs):
+        if hasattr(self.k, "bind"):
+            return self.k.bind(method, *args, **kwargs)          # pre-marshalled ABI call
+        return lambda: getattr(self.k, method)(*args, **kwargs)  # substitute kernels (tests)
+
+    def _build_plan(self, cur: int, gamma: float):
+        """Flat launch list of one sweep reading Zbuf[cur]: bound kernel calls, event marks, exchanges.
+        Everything that can be computed once (views, pointers, offsets) is, so the per-sweep host cost is a
+        few microseconds per launch -- it matters at 8 GPUs, where a sweep is ~1 ms of GPU time."""
         k = self.k
-        Zold, Znew = self.Zbuf[self.cur], self.Zbuf[1 - self.cur]
-        works = []
+        Zold, Znew = self.Zbuf[cur], self.Zbuf[1 - cur]
+        steps = []
         for i, b in enumerate(self.blocks):
             rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
             po = self.partial_off[i]
             po_mid = po + k.spmm_partials_len(b.nrows, 0)
             po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
-            ev = self._events(i) if self.time_kernels else None
-            # hubs first (longest tail), then mid rows, then the one-wave-per-row pass
-            if ev:
-                ev[0].record()
+            # hubs first (longest tail), then mid rows, then the one-(sub-)wave-per-row pass
+            steps.append(("event", i, 0))
             if self.hub_rows[i] is not None:
-                k.spmm_update_long(rp, self.colidx, self.P, self.hub_rows[i], 16, b.row0, Zold, Xb, gamma, Zn, self.d,
-                                   self.partials[po_hub:])
-            if ev:
-                ev[1].record()
+                steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
+                                                 b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:])))
+            steps.append(("event", i, 1))
             if self.mid_rows[i] is not None:
-                k.spmm_update_long(rp, self.colidx, self.P, self.mid_rows[i], 4, b.row0, Zold, Xb, gamma, Zn, self.d,
-                                   self.partials[po_mid:])
-            if ev:
-                ev[2].record()
-            k.spmm_update(rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb, gamma, Zn, self.d, self.long_threshold,
-                          self.partials[po:], sinks_untouched=True)
-            if ev:
-                ev[3].record()
+                steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.mid_rows[i], 4,
+                                                 b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:])))
+            steps.append(("event", i, 2))
+            steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb, gamma,
+                                             Zn, self.d, self.long_threshold, self.partials[po:],
+                                             sinks_untouched=True)))
+            steps.append(("event", i, 3))
             if b.span is not None:
-                works.append(self.comm.all_gather_into(Znew[b.span[0]:b.span[1]], Zn, async_op=True))
+                steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))
             elif b.exchange is not None:      # halo: pack the rows of this chunk that others read, swap, no unpack
                 ex = b.exchange
                 if self.send_rows[i] is not None:
-                    k.gather_rows(Znew, self.send_rows[i], self.d, self.send_buf[i])
-                works.append(self.comm.all_to_all_rows(Znew[ex.recv_start:ex.recv_start + ex.recv_rows],
-                                                       self.send_buf[i], ex.out_splits, ex.in_splits, async_op=True))
-        k.reduce_partials(self.partials, self.partials.numel(), self.ws, self.delta)
+                    steps.append(("call", self._bind("gather_rows", Znew, self.send_rows[i], self.d, self.send_buf[i])))
+                steps.append(("alltoall", Znew[ex.recv_start:ex.recv_start + ex.recv_rows], self.send_buf[i],
+                              ex.out_splits, ex.in_splits))
+        steps.append(("call", self._bind("reduce_partials", self.partials, self.partials.numel(), self.ws, self.delta)))
+        return steps
+
+    def sweep(self, gamma: float) -> float:
+        """Z <- X + gamma * P Z on the owned rows, exchange, return sum|Z_new - Z_old| (global)."""
+        if not self.P_valid:
+            raise RuntimeError("sweep() before build_P()")
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        key = (self.cur, float(gamma), stream)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._build_plan(self.cur, float(gamma))
+        events = None
+        if self.time_kernels:
+            events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in self.blocks]
+            self.kernel_events.extend((i,) + tuple(ev) for i, ev in enumerate(events))
+        works = []
+        for step in plan:
+            kind = step[0]
+            if kind == "call":
+                step[1]()
+            elif kind == "event":
+                if events is not None:
+                    events[step[1]][step[2]].record()
+            elif kind == "allgather":
+                works.append(self.comm.all_gather_into(step[1], step[2], async_op=True))
+            else:
+                works.append(self.comm.all_to_all_rows(step[1], step[2], step[3], step[4], async_op=True))
         self._all_reduce(self.delta)
         for w in works:
             w.wait()
@@ -287,11 +316,6 @@ class SweepEngine:
         self.sweeps_done += 1
         self.quiet_stale = True
         return float(self.delta.item())
-
-    def _events(self, i: int):
-        ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
-        self.kernel_events.append((i,) + ev)
-        return ev
 
     def kernel_times_ms(self):
         """{'hub','mid','main'} -> ms per SWEEP (summed over the blocks, averaged over the recorded
