@@ -501,3 +501,29 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world):
     assert rel(P_all, P_or) < 1e-5
     if exchange == "halo":                                          # the point of the halo: fewer bytes than all rows
         assert results[0][4] < 0.8 * (world - 1) * (V // world) * d * 4
+
+
+def test_edge_cases_single_vertex_and_nan_termination(tmp_path):
+    # one vertex with a self-loop: P = [1], Z -> X / (1 - gamma)
+    root = write_data_root(tmp_path / "one", ["a"], ["a"], ["a"], np.array([[1.0, -2.0, 0.5]], dtype=np.float32))
+    g = Graph(root)
+    assert g.build_P(CosineSimilarity()).to_dense().item() == pytest.approx(1.0)
+    emb = Embedder(g, CosineSimilarity(), torch.device("cpu"), gamma=0.5, tolerence=3, verbose=False)
+    emb.iterate()
+    np.testing.assert_allclose(g.Z.numpy(), np.array([[2.0, -4.0, 1.0]]), rtol=1e-5)
+    # all-zero content: the reference's global denominator is 0 -> NaN scores (cs(zeros, ones) is nan upstream);
+    # NaN never compares smaller, so both tolerance counters run down and the loops terminate
+    k = load_golden("g2_karate_csr.npz")
+    root0 = write_data_root(tmp_path / "zero", k["vertex_ids"], k["edge_src"], k["edge_dst"],
+                            np.zeros((34, 4), dtype=np.float32))
+    g0 = Graph(root0)
+    emb0 = Embedder(g0, CosineSimilarity(), torch.device("cpu"), tolerence=3, verbose=False)
+    emb0.iterate()
+    Z0 = g0.Z
+    sink = torch.from_numpy(np.diff(g0.csr.rowptr) == 0)
+    assert torch.isnan(Z0[~sink]).all() and (Z0[sink] == 0).all()
+    assert emb0.sweep_counts == [3] * 3                    # 3 endures per propagate, 3 outer endures
+    # the oracle does the same
+    orc = O.OracleEmbedder(g0.csr.rowptr, g0.csr.colidx, torch.zeros(34, 4), tolerence=3)
+    Zo = orc.iterate()
+    assert torch.isnan(Zo[~sink]).all() and orc.sweep_counts == [3] * 3
