@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=None)
     ap.add_argument("--long-threshold", type=int, default=None)
     ap.add_argument("--hub-threshold", type=int, default=None)
+    ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather", "allgather_all"],
                     help="N > 1: how updated rows travel (see clane_amd/halo.py, partition.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,7 +115,8 @@ def main():
 
     t0 = time.perf_counter()
     eng = SweepEngine(csr, X, dev, process_group=pg, chunks=args.chunks, long_threshold=args.long_threshold,
-                      hub_threshold=args.hub_threshold, exchange=args.exchange)
+                      hub_threshold=args.hub_threshold, exchange=args.exchange,
+                      hot_rows_first=not args.natural_order)
     torch.cuda.synchronize()
     log(f"engine up in {time.perf_counter() - t0:.1f}s; rank rows={eng.part.n_local} edges={eng.E_loc} "
         f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
@@ -202,7 +204,7 @@ def main():
         "build_P_ms": build_p_ms, "last_delta": delta,
     }
     if world == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline(csr, X, eng.P[:eng.E_loc].cpu(), args.gamma, Z1)
+        base, parity = cpu_baseline(csr, X, eng.P_global(), args.gamma, Z1)
         result["cpu_baseline"] = base
         result["parity_rel_l2_vs_oracle_after_1_sweep"] = parity
         if not parity < PARITY_TOL[dname]:

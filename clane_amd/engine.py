@@ -58,7 +58,7 @@ class SweepEngine:
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
-                 exchange: str = "halo", comm=None):
+                 exchange: str = "halo", comm=None, hot_rows_first: bool = True):
         """``exchange`` (N > 1 only): "halo" -- a compact per-rank table, rows sent only to the ranks that read
         them (halo.py); "allgather" -- full-size Z on every rank, in-place all-gather of the live rows
         (partition.py); "allgather_all" -- the same without the live/quiet split."""
@@ -88,8 +88,10 @@ class SweepEngine:
             self.local: LocalCSR = self.part.local
         else:
             live = csr.live_mask() if (self.world > 1 and exchange == "allgather") else None
+            # one GPU: lay Z out by descending in-degree, so the rows gathered most often are contiguous
+            hot = csr.indeg() if (self.world == 1 and hot_rows_first and not shuffle) else None
             self.part = RowPartition.create(self.V, self.world, rank, chunks, live_mask=live, shuffle=shuffle,
-                                            seed=seed)
+                                            seed=seed, priority=hot)
             self.blocks = self.part.blocks()
             self.local = localize(csr, self.part)
         if long_threshold is None:
@@ -240,6 +242,13 @@ class SweepEngine:
                     k.segment_softmax(rp, b.nrows, self.P, _hip.FUSED_SOFTMAX_MAX_DEGREE, self.long_threshold,
                                       self.long_rows[i])
         self.P_valid = True
+
+    def P_global(self) -> torch.Tensor:
+        """P values of the rows this rank owns as a CPU tensor in the GLOBAL (row, col)-sorted edge order,
+        zeros elsewhere (the engine stores them in its own row / column order)."""
+        out = torch.zeros(int(self.local.edge_origin.max()) + 1 if self.E_loc else 0, dtype=self.acc_dtype)
+        out[torch.from_numpy(self.local.edge_origin)] = self.P[:self.E_loc].to("cpu")
+        return out
 
     # ---- one sweep (embedder.py:84-94) --------------------------------------------------
     def _bind(self, method: str, *args, **kwargs):
