@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=None)
     ap.add_argument("--long-threshold", type=int, default=None)
     ap.add_argument("--hub-threshold", type=int, default=None)
+    ap.add_argument("--no-split-hubs", action="store_true", help="hub rows by one workgroup each (no segment split)")
     ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather", "allgather_all"],
                     help="N > 1: how updated rows travel (see clane_amd/halo.py, partition.py)")
@@ -116,11 +117,12 @@ def main():
     t0 = time.perf_counter()
     eng = SweepEngine(csr, X, dev, process_group=pg, chunks=args.chunks, long_threshold=args.long_threshold,
                       hub_threshold=args.hub_threshold, exchange=args.exchange,
-                      hot_rows_first=not args.natural_order)
+                      hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs)
     torch.cuda.synchronize()
     log(f"engine up in {time.perf_counter() - t0:.1f}s; rank rows={eng.part.n_local} edges={eng.E_loc} "
         f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
         f"hub(16 waves)={sum(0 if l is None else l.numel() for l in eng.hub_rows)} "
+        f"split={sum(0 if l is None else l[0].numel() for l in eng.split_rows)} "
         f"thresholds {eng.long_threshold}/{eng.hub_threshold}")
 
     # build_P once (timed separately, not part of a step), P frozen afterwards
@@ -167,7 +169,8 @@ def main():
     # bytes = that kernel's algorithmic bytes per sweep / chunks (SURVEY.md section 8d gather model).
     chunks = len(eng.blocks)          # launches of each kernel per sweep
     kbytes = eng.kernel_bytes()
-    names = {"main": "spmm_update_kernel", "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>"}
+    names = {"main": "spmm_update_kernel", "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>",
+             "split": "spmm_split_segment_kernel+combine"}
     per_kernel = {}
     for key, ms in ktimes.items():
         if kbytes[key] > 0 and ms > 0:       # ms = per sweep, summed over the blocks

@@ -35,6 +35,7 @@ SIGNATURES = {
     "clane_spmm_partials_len": (_i64, [_i64, _i64]),
     "clane_reduce_ws_len": (_i64, []),
     "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p, _p]),
+    "clane_spmm_split_slab_len": (_i64, [_i64, _i32]),
 }
 for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_row_sqnorm_{_s}"] = (C.c_int, [_p, _i64, _i32, _i64, _p, _p])
@@ -45,6 +46,8 @@ for _s in ("f32", "f64", "bf16"):
         C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _i32, _p, _p])
     SIGNATURES[f"clane_spmm_update_long_{_s}"] = (
         C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p])
+    SIGNATURES[f"clane_spmm_update_split_{_s}"] = (
+        C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p])
     SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 for _s in ("f32", "f64"):
@@ -217,6 +220,24 @@ class HipKernels:
                      _vec(P, acc_dtype(Z_old.dtype), "P"), _vec(long_rows, torch.int32, "long_rows"),
                      long_rows.numel(), waves_per_row, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
                      _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+
+    def spmm_split_slab_len(self, n_segments: int, d: int) -> int:
+        return int(self.lib.clane_spmm_split_slab_len(n_segments, d))
+
+    def spmm_update_split(self, rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment: int, row0: int,
+                          Z_old, X, gamma: float, Z_new, d: int, slab, partials):
+        """Hub rows cut into segments over several workgroups + fixed-order combine; writes split_rows.numel()
+        partials."""
+        zo, ldz = _mat(Z_old, "Z_old")
+        xp, ldx = _mat(X, "X")
+        zn, ldo = _mat(Z_new, "Z_new")
+        self._invoke(self._fn("clane_spmm_update_split", Z_old.dtype), "clane_spmm_update_split",
+                     _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
+                     _vec(P, acc_dtype(Z_old.dtype), "P"), _vec(split_rows, torch.int32, "split_rows"),
+                     _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(seg_row, torch.int32, "seg_row"),
+                     split_rows.numel(), seg_row.numel(), edges_per_segment, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
+                     _vec(slab, acc_dtype(Z_old.dtype), "slab"), _vec(partials, torch.float64, "partials"),
+                     self._stream(Z_old))
 
     def reduce_partials(self, partials, n: int, ws, out):
         self._invoke(self.lib.clane_reduce_partials, "clane_reduce_partials",

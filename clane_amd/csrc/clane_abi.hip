@@ -235,6 +235,33 @@ int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, 
     return check_launch("spmm_update_long");
 }
 
+template <typename T, typename PT>
+int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P, const int32_t *split_rows,
+                      const int64_t *seg_ptr, const int32_t *seg_row, int64_t n_split, int64_t n_segments,
+                      int64_t edges_per_segment, int64_t row0, const T *Z_old, int64_t ldz, const T *X, int64_t ldx,
+                      typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d,
+                      typename Elem<T>::acc_t *slab, double *delta_partials, void *stream) {
+    REQUIRE(n_split >= 0 && n_split <= INT32_MAX && n_segments >= n_split && n_segments <= INT32_MAX && row0 >= 0 &&
+                d > 0 && edges_per_segment >= kWave && edges_per_segment % kWave == 0,
+            "spmm_update_split: bad shape (edges_per_segment must be a positive multiple of 64)");
+    REQUIRE(ldz >= d && ldx >= d && ldo >= d, "spmm_update_split: leading dimension < d");
+    if (n_split == 0) return CLANE_OK;
+    REQUIRE(rowptr && colidx && P && split_rows && seg_ptr && seg_row && Z_old && X && Z_new && slab && delta_partials,
+            "spmm_update_split: null pointer");
+    REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update_split: Z_new must not alias Z_old");
+    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new}, {ldz, ldx, ldo});
+    const int64_t ld_slab = ceil_div(d, 4) * 4;
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
+        spmm_split_segment_kernel<T, PT, VEC, LPR, U, kLongWaves>
+            <<<unsigned(n_segments), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
+                rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, Z_old, ldz, d, slab, ld_slab);
+    });
+    spmm_split_combine_kernel<T><<<unsigned(n_split), kWave, 0, (hipStream_t)stream>>>(
+        split_rows, seg_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, delta_partials);
+    return check_launch("spmm_update_split");
+}
+
 template <typename T>
 int l1_distance(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows, int32_t d, double *ws, double *out,
                 void *stream) {
@@ -358,6 +385,23 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
                                        reinterpret_cast<const T *>(Z_old), ldz, reinterpret_cast<const T *>(X), ldx,  \
                                        gamma, reinterpret_cast<T *>(Z_new), ldo, d, delta_partials, stream);          \
     }
+#define CLANE_SPLIT_WRAPPER(SUF, CT, T, PT, GT)                                                                         \
+    int clane_spmm_update_split_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P,                      \
+                                      const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,      \
+                                      int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,   \
+                                      const CT *Z_old, int64_t ldz, const CT *X, int64_t ldx, GT gamma, CT *Z_new,    \
+                                      int64_t ldo, int32_t d, GT *slab, double *delta_partials, void *stream) {       \
+        return spmm_update_split<T, PT>(rowptr, colidx, P, split_rows, seg_ptr, seg_row, n_split, n_segments,         \
+                                        edges_per_segment, row0, reinterpret_cast<const T *>(Z_old), ldz,             \
+                                        reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new),     \
+                                        ldo, d, slab, delta_partials, stream);                                        \
+    }
+CLANE_SPLIT_WRAPPER(f32, float, float, float, float)
+CLANE_SPLIT_WRAPPER(f64, double, double, double, double)
+CLANE_SPLIT_WRAPPER(bf16, uint16_t, bf16_t, float, float)
+#undef CLANE_SPLIT_WRAPPER
+int64_t clane_spmm_split_slab_len(int64_t n_segments, int32_t d) { return n_segments * (ceil_div(d, 4) * 4); }
+
 CLANE_SPMM_WRAPPERS(f32, float, float, float, float)
 CLANE_SPMM_WRAPPERS(f64, double, double, double, double)
 CLANE_SPMM_WRAPPERS(bf16, uint16_t, bf16_t, float, float)

@@ -450,3 +450,86 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
 }
 
 }  // namespace clane
+
+namespace clane {
+
+// ---- hub rows: one row over SEVERAL workgroups ------------------------------------------------------
+// A 70k-edge row done by one 16-wave workgroup is 4.4k edges per wave in sequence -- a ~0.25 ms tail
+// on every launch, which dominates once a sweep is cut into chunks (multi-GPU) or the graph is small.
+// Rows above `edges_per_segment` are cut into segments; workgroup s gathers segment s exactly like
+// spmm_long_kernel and leaves its partial sum (accumulate type) in slab[s]; spmm_split_combine_kernel
+// then adds a row's segments IN ORDER (reproducible) and runs the usual epilogue.
+template <typename T, typename PT, int VEC, int LPR, int U, int WAVES>
+__global__ __launch_bounds__(WAVES *kWave) void spmm_split_segment_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P,
+    const int32_t *__restrict__ split_rows, const int64_t *__restrict__ seg_ptr, const int32_t *__restrict__ seg_row,
+    int64_t edges_per_segment, const T *__restrict__ Zold, int64_t ldz, int d,
+    typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab) {
+    using A = typename Elem<T>::acc_t;
+    __shared__ A red[WAVES][kWave][VEC];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int sub = lane / LPR;
+    const int sl = lane % LPR;
+    const int64_t s = blockIdx.x;
+    const int i = seg_row[s];
+    const int64_t r = split_rows[i];
+    const int64_t e0 = rowptr[r] + (s - seg_ptr[i]) * edges_per_segment;
+    const int64_t e1 = e0 + edges_per_segment < rowptr[r + 1] ? e0 + edges_per_segment : rowptr[r + 1];
+    const int64_t seg = ceil_div(ceil_div(e1 - e0, WAVES), kWave) * kWave;
+    const int active = e1 > e0 ? int(ceil_div(e1 - e0, seg)) : 1;
+    if (wave >= active) return;
+    const int64_t a = e0 + wave * seg;
+    const int64_t b = a + seg < e1 ? a + seg : e1;
+    const EdgeChunk<A> none{0, A(0)};
+    for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
+        const int c0 = t0 + sl * VEC;
+        const bool col_ok = c0 < d;
+        A acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+        gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, a, b, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, none, false);
+        fold_subwaves<LPR>(acc);
+        if (wave > 0) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) red[wave][lane][k] = acc[k];
+        }
+        __syncthreads();
+        if (wave == 0 && col_ok && sub == 0) {
+            for (int w = 1; w < active; ++w) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                if (c0 + k < d) slab[s * ld_slab + c0 + k] = acc[k];
+        }
+        if (t0 + LPR * VEC < d) __syncthreads();
+    }
+}
+
+// One wave per split row: segments summed in order, then  z = x + gamma * sum,  delta, store.
+template <typename T>
+__global__ __launch_bounds__(kWave) void spmm_split_combine_kernel(
+    const int32_t *__restrict__ split_rows, const int64_t *__restrict__ seg_ptr, int64_t row0,
+    const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
+    const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
+    double *__restrict__ partials) {
+    using A = typename Elem<T>::acc_t;
+    const int i = blockIdx.x;
+    const int64_t r = split_rows[i];
+    const int64_t s0 = seg_ptr[i], s1 = seg_ptr[i + 1];
+    A rsum = A(0);
+    for (int c = lane_id(); c < d; c += kWave) {
+        A tot = A(0);
+        for (int64_t s = s0; s < s1; ++s) tot += slab[s * ld_slab + c];
+        const A zold = Elem<T>::to_acc(Zold[(row0 + r) * ldz + c]);
+        const T out = Elem<T>::from_acc(Elem<T>::to_acc(X[r * ldx + c]) + gamma * tot);
+        Znew[r * ldo + c] = out;
+        rsum += fabs(Elem<T>::to_acc(out) - zold);
+    }
+    rsum = group_sum<kWave>(rsum);
+    if (lane_id() == 0) partials[i] = double(rsum);
+}
+
+}  // namespace clane

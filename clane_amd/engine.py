@@ -21,6 +21,7 @@ scalar delta is all-reduced.  On one GPU no collective is issued.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import List, Optional
 
 import numpy as np
@@ -42,6 +43,9 @@ from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
 # A 4-wave bin (T < deg <= hub_threshold) exists in the ABI; it did not pay.
 LONG_THRESHOLD_BY_ROWS_PER_WAVE = {1: 32, 2: 64, 4: 384, 8: 512}
 HUB_FACTOR = 1
+# Rows above this many edges are cut into segments of that size, one 16-wave workgroup each (256 edges per wave):
+# a 70k-edge hub done by ONE workgroup is a ~0.25 ms tail on every launch.
+SPLIT_EDGES = 4096
 
 
 def lanes_per_row(d: int, dtype: torch.dtype) -> int:
@@ -58,7 +62,8 @@ class SweepEngine:
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
-                 exchange: str = "halo", comm=None, hot_rows_first: bool = True):
+                 exchange: str = "halo", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
+                 overlap_chunks: bool = True):
         """``exchange`` (N > 1 only): "halo" -- a compact per-rank table, rows sent only to the ranks that read
         them (halo.py); "allgather" -- full-size Z on every rank, in-place all-gather of the live rows
         (partition.py); "allgather_all" -- the same without the live/quiet split."""
@@ -83,7 +88,8 @@ class SweepEngine:
             raise ValueError(f"exchange must be 'halo', 'allgather' or 'allgather_all', got {exchange!r}")
         self.halo = self.world > 1 and exchange == "halo"
         if self.halo:
-            self.part = build_halo_layout(csr, self.world, rank, chunks, shuffle=shuffle is not False, seed=seed)
+            self.part = build_halo_layout(csr, self.world, rank, chunks, shuffle=shuffle is not False, seed=seed,
+                                          hot_rows_first=hot_rows_first)
             self.blocks: List[Block] = self.part.blocks
             self.local: LocalCSR = self.part.local
         else:
@@ -112,18 +118,36 @@ class SweepEngine:
         # per block: row lists relative to the block's first row (the kernels get rowptr / X / Z_new offset to it)
         self.long_rows: List[Optional[torch.Tensor]] = []     # every row above long_threshold (K1 / K2 slice these)
         self.mid_rows: List[Optional[torch.Tensor]] = []      # long_threshold < deg <= hub_threshold: 4 waves/row
-        self.hub_rows: List[Optional[torch.Tensor]] = []      # deg > hub_threshold: 16 waves/row
+        self.hub_rows: List[Optional[torch.Tensor]] = []      # hub_threshold < deg <= SPLIT_EDGES: 16 waves/row
+        self.split_rows: List[Optional[tuple]] = []           # deg > SPLIT_EDGES: (rows, seg_ptr, seg_row) on device
+        self.split_edges = SPLIT_EDGES if split_hubs else 0
+        max_segments = 0
         self.partial_off = [0]
         to_dev = lambda a: torch.from_numpy(a.astype(np.int32)).to(dev) if a.size else None  # noqa: E731
         for b in self.blocks:
             db = deg[b.local_start:b.local_start + b.nrows]
             is_long = db > self.long_threshold if self.long_threshold > 0 else np.zeros_like(db, dtype=bool)
-            is_hub = is_long & (db > self.hub_threshold)
+            is_split = is_long & (db > self.split_edges) if self.split_edges > 0 else np.zeros_like(is_long)
+            is_hub = is_long & (db > self.hub_threshold) & ~is_split
             self.long_rows.append(to_dev(np.nonzero(is_long)[0]))
-            self.mid_rows.append(to_dev(np.nonzero(is_long & ~is_hub)[0]))
+            self.mid_rows.append(to_dev(np.nonzero(is_long & ~is_hub & ~is_split)[0]))
             self.hub_rows.append(to_dev(np.nonzero(is_hub)[0]))
+            rows_s = np.nonzero(is_split)[0]
+            if rows_s.size:
+                nseg = -(-db[rows_s] // self.split_edges)
+                seg_ptr = np.zeros(rows_s.size + 1, dtype=np.int64)
+                np.cumsum(nseg, out=seg_ptr[1:])
+                seg_row = np.repeat(np.arange(rows_s.size, dtype=np.int32), nseg)
+                self.split_rows.append((to_dev(rows_s), torch.from_numpy(seg_ptr).to(dev),
+                                        torch.from_numpy(seg_row).to(dev)))
+                max_segments = max(max_segments, int(seg_ptr[-1]))
+            else:
+                self.split_rows.append(None)
             self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(b.nrows, int(is_long.sum())))
         self.partials = torch.zeros(self.partial_off[-1], dtype=torch.float64, device=dev)
+        # segment sums of the split hub rows: one slab per launch stream (blocks on a stream run in order)
+        self.slabs = [torch.zeros(max(1, self.k.spmm_split_slab_len(max_segments, self.d)), dtype=self.acc_dtype,
+                                  device=dev) for _ in range(2)]
 
         # ---- halo exchange: send lists and send buffers (one per own chunk) -----------------
         self.send_rows: List[Optional[torch.Tensor]] = []
@@ -162,6 +186,11 @@ class SweepEngine:
         self.sweeps_done = 0
         # optional per-kernel timing with HIP events on the launch stream (bench.py)
         self._plans = {}                 # (parity, gamma, stream) -> launch list (see _build_plan)
+        # Alternate chunks go to two side streams, so the tail of one chunk's kernels overlaps the head of the
+        # next chunk's (a chunk at 8 GPUs is only ~0.25 ms of kernels: ramp-up and tail are a third of it).
+        self.side_streams = None
+        if overlap_chunks and len(self.blocks) > 1 and self.device.type == "cuda" and hasattr(self.k, "bind"):
+            self.side_streams = [torch.cuda.Stream(self.device) for _ in range(2)]
         self.time_kernels = False
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
 
@@ -257,41 +286,54 @@ class SweepEngine:
         return lambda: getattr(self.k, method)(*args, **kwargs)  # substitute kernels (tests)
 
     def _build_plan(self, cur: int, gamma: float):
-        """Flat launch list of one sweep reading Zbuf[cur]: bound kernel calls, event marks, exchanges.
-        Everything that can be computed once (views, pointers, offsets) is, so the per-sweep host cost is a
-        few microseconds per launch -- it matters at 8 GPUs, where a sweep is ~1 ms of GPU time."""
+        """Launch lists of one sweep reading Zbuf[cur]: per block, bound kernel calls, event marks and the
+        exchange; then the final reduction.  Everything that can be computed once (views, pointers, offsets,
+        the stream each call goes to) is, so the per-sweep host cost is a few microseconds per launch -- it
+        matters at 8 GPUs, where a sweep is ~1 ms of GPU time."""
         k = self.k
         Zold, Znew = self.Zbuf[cur], self.Zbuf[1 - cur]
-        steps = []
+        per_block = []
         for i, b in enumerate(self.blocks):
-            rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
-            po = self.partial_off[i]
-            po_mid = po + k.spmm_partials_len(b.nrows, 0)
-            po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
-            # hubs first (longest tail), then mid rows, then the one-(sub-)wave-per-row pass
-            steps.append(("event", i, 0))
-            if self.hub_rows[i] is not None:
-                steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
-                                                 b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:])))
-            steps.append(("event", i, 1))
-            if self.mid_rows[i] is not None:
-                steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.mid_rows[i], 4,
-                                                 b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:])))
-            steps.append(("event", i, 2))
-            steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb, gamma,
-                                             Zn, self.d, self.long_threshold, self.partials[po:],
-                                             sinks_untouched=True)))
-            steps.append(("event", i, 3))
-            if b.span is not None:
-                steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))
-            elif b.exchange is not None:      # halo: pack the rows of this chunk that others read, swap, no unpack
-                ex = b.exchange
-                if self.send_rows[i] is not None:
-                    steps.append(("call", self._bind("gather_rows", Znew, self.send_rows[i], self.d, self.send_buf[i])))
-                steps.append(("alltoall", Znew[ex.recv_start:ex.recv_start + ex.recv_rows], self.send_buf[i],
-                              ex.out_splits, ex.in_splits))
-        steps.append(("call", self._bind("reduce_partials", self.partials, self.partials.numel(), self.ws, self.delta)))
-        return steps
+            steps = []
+            ctx = torch.cuda.stream(self.side_streams[i % 2]) if self.side_streams else contextlib.nullcontext()
+            with ctx:            # bound calls capture the current stream
+                rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
+                po = self.partial_off[i]
+                po_mid = po + k.spmm_partials_len(b.nrows, 0)
+                po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
+                po_split = po_hub + (0 if self.hub_rows[i] is None else self.hub_rows[i].numel())
+                # biggest rows first: split hubs, 16-wave rows, (4-wave rows), then the one-(sub-)wave-per-row pass
+                steps.append(("event", i, 0))
+                if self.split_rows[i] is not None:
+                    rows_s, seg_ptr, seg_row = self.split_rows[i]
+                    steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
+                                                     seg_row, self.split_edges, b.row0, Zold, Xb, gamma, Zn, self.d,
+                                                     self.slabs[i % 2], self.partials[po_split:])))
+                steps.append(("event", i, 4))
+                if self.hub_rows[i] is not None:
+                    steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
+                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:])))
+                steps.append(("event", i, 1))
+                if self.mid_rows[i] is not None:
+                    steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.mid_rows[i], 4,
+                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:])))
+                steps.append(("event", i, 2))
+                steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb,
+                                                 gamma, Zn, self.d, self.long_threshold, self.partials[po:],
+                                                 sinks_untouched=True)))
+                steps.append(("event", i, 3))
+                if b.span is not None:
+                    steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))
+                elif b.exchange is not None:  # halo: pack the rows of this chunk that others read, swap, no unpack
+                    ex = b.exchange
+                    if self.send_rows[i] is not None:
+                        steps.append(("call", self._bind("gather_rows", Znew, self.send_rows[i], self.d,
+                                                         self.send_buf[i])))
+                    steps.append(("alltoall", Znew[ex.recv_start:ex.recv_start + ex.recv_rows], self.send_buf[i],
+                                  ex.out_splits, ex.in_splits))
+            per_block.append(steps)
+        final = self._bind("reduce_partials", self.partials, self.partials.numel(), self.ws, self.delta)
+        return per_block, final
 
     def sweep(self, gamma: float) -> float:
         """Z <- X + gamma * P Z on the owned rows, exchange, return sum|Z_new - Z_old| (global)."""
@@ -304,20 +346,37 @@ class SweepEngine:
             plan = self._plans[key] = self._build_plan(self.cur, float(gamma))
         events = None
         if self.time_kernels:
-            events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in self.blocks]
+            events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in self.blocks]
             self.kernel_events.extend((i,) + tuple(ev) for i, ev in enumerate(events))
+        per_block, final = plan
         works = []
-        for step in plan:
-            kind = step[0]
-            if kind == "call":
-                step[1]()
-            elif kind == "event":
-                if events is not None:
-                    events[step[1]][step[2]].record()
-            elif kind == "allgather":
-                works.append(self.comm.all_gather_into(step[1], step[2], async_op=True))
-            else:
-                works.append(self.comm.all_to_all_rows(step[1], step[2], step[3], step[4], async_op=True))
+        side = self.side_streams
+        if side:
+            main = torch.cuda.current_stream(self.device)
+            start = torch.cuda.Event()
+            start.record(main)
+            for st in side:
+                st.wait_event(start)
+        for i, steps in enumerate(per_block):
+            ctx = torch.cuda.stream(side[i % 2]) if side else contextlib.nullcontext()
+            with ctx:
+                for step in steps:
+                    kind = step[0]
+                    if kind == "call":
+                        step[1]()
+                    elif kind == "event":
+                        if events is not None:
+                            events[step[1]][step[2]].record()
+                    elif kind == "allgather":
+                        works.append(self.comm.all_gather_into(step[1], step[2], async_op=True))
+                    else:
+                        works.append(self.comm.all_to_all_rows(step[1], step[2], step[3], step[4], async_op=True))
+        if side:
+            for st in side:
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
+        final()
         self._all_reduce(self.delta)
         for w in works:
             w.wait()
@@ -327,15 +386,16 @@ class SweepEngine:
         return float(self.delta.item())
 
     def kernel_times_ms(self):
-        """{'hub','mid','main'} -> ms per SWEEP (summed over the blocks, averaged over the recorded
-        sweeps); call after a synchronize."""
-        t = np.array([(a.elapsed_time(b), b.elapsed_time(m), m.elapsed_time(e))
-                      for _, a, b, m, e in self.kernel_events]).reshape(-1, 3)
+        """{'split','hub','mid','main'} -> ms per SWEEP (summed over the blocks, averaged over the recorded
+        sweeps); call after a synchronize.  Event order per block: 0 start, 4 after split, 1 after hub, 2 after mid,
+        3 after main."""
+        t = np.array([(e0.elapsed_time(e4), e4.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3))
+                      for _, e0, e1, e2, e3, e4 in self.kernel_events]).reshape(-1, 4)
         self.kernel_events = []
         if not len(t):
             return {}
-        per_sweep = t.reshape(-1, len(self.blocks), 3).sum(1).mean(0)
-        return dict(zip(("hub", "mid", "main"), per_sweep.tolist()))
+        per_sweep = t.reshape(-1, len(self.blocks), 4).sum(1).mean(0)
+        return dict(zip(("split", "hub", "mid", "main"), per_sweep.tolist()))
 
     def kernel_bytes(self):
         """Algorithmic bytes per SWEEP of each K3 kernel (SURVEY.md section 8d gather model, split by the
@@ -344,9 +404,10 @@ class SweepEngine:
         deg = np.diff(self.local.rowptr)
         per_row = deg * (self.d * s + 4 + ps) + np.where(deg > 0, 3 * self.d * s, 0) + 8   # sinks: rowptr only
         is_long = deg > self.long_threshold if self.long_threshold > 0 else np.zeros_like(deg, dtype=bool)
-        is_hub = is_long & (deg > self.hub_threshold)
-        return {"main": int(per_row[~is_long].sum()) + 8, "mid": int(per_row[is_long & ~is_hub].sum()),
-                "hub": int(per_row[is_hub].sum())}
+        is_split = is_long & (deg > self.split_edges) if self.split_edges > 0 else np.zeros_like(is_long)
+        is_hub = is_long & (deg > self.hub_threshold) & ~is_split
+        return {"main": int(per_row[~is_long].sum()) + 8, "mid": int(per_row[is_long & ~is_hub & ~is_split].sum()),
+                "hub": int(per_row[is_hub].sum()), "split": int(per_row[is_split].sum())}
 
     def exchange_bytes_per_sweep(self) -> int:
         """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""

@@ -150,6 +150,32 @@ int clane_spmm_update_long_bf16(const int64_t *rowptr, const int32_t *colidx, co
                                 int64_t ldz, const uint16_t *X, int64_t ldx, float gamma, uint16_t *Z_new,
                                 int64_t ldo, int32_t d, double *delta_partials, void *stream);
 
+/*  clane_spmm_update_split_* : hub rows, each cut into segments of `edges_per_segment` edges (a multiple of 64)
+ *                             that are gathered by separate 16-wave workgroups; segment sums go to `slab`
+ *                             (clane_spmm_split_slab_len(n_segments, d) accumulate-type elements) and are added
+ *                             per row in segment order, then the usual epilogue.  split_rows[n_split] local row
+ *                             ids; seg_ptr[n_split+1] prefix sums of the rows' segment counts
+ *                             (ceil(deg / edges_per_segment)); seg_row[n_segments] = index into split_rows of the
+ *                             row each segment belongs to.  Writes n_split doubles to delta_partials. */
+int64_t clane_spmm_split_slab_len(int64_t n_segments, int32_t d);
+int clane_spmm_update_split_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, const int32_t *split_rows,
+                                const int64_t *seg_ptr, const int32_t *seg_row, int64_t n_split, int64_t n_segments,
+                                int64_t edges_per_segment, int64_t row0, const float *Z_old, int64_t ldz,
+                                const float *X, int64_t ldx, float gamma, float *Z_new, int64_t ldo, int32_t d,
+                                float *slab, double *delta_partials, void *stream);
+int clane_spmm_update_split_f64(const int64_t *rowptr, const int32_t *colidx, const double *P,
+                                const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,
+                                int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,
+                                const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma,
+                                double *Z_new, int64_t ldo, int32_t d, double *slab, double *delta_partials,
+                                void *stream);
+int clane_spmm_update_split_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P,
+                                 const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,
+                                 int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,
+                                 const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
+                                 uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, double *delta_partials,
+                                 void *stream);
+
 /* out[0] = sum of partials[0..n) in a fixed order (bitwise reproducible).  Finishes embedder.py:94 / :60.
  * ws: clane_reduce_ws_len() doubles. */
 int clane_reduce_partials(const double *partials, int64_t n, double *ws, double *out, void *stream);

@@ -87,6 +87,15 @@ class OracleKernels:
         for i, r in enumerate(long_rows.tolist()):
             partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d)
 
+    def spmm_split_slab_len(self, n_segments, d):
+        return n_segments * d
+
+    def spmm_update_split(self, rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, row0, Z_old, X,
+                          gamma, Z_new, d, slab, partials):
+        assert edges_per_segment % 64 == 0 and seg_row.numel() == int(seg_ptr[-1])
+        for i, r in enumerate(split_rows.tolist()):
+            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d)
+
     def reduce_partials(self, partials, n, ws, out):
         out[0] = partials[:n].sum()
 

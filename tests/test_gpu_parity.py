@@ -528,3 +528,37 @@ def test_edge_cases_single_vertex_and_nan_termination(tmp_path):
     orc = O.OracleEmbedder(g0.csr.rowptr, g0.csr.colidx, torch.zeros(34, 4), tolerence=3)
     Zo = orc.iterate()
     assert torch.isnan(Zo[~sink]).all() and orc.sweep_counts == [3] * 3
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.float32, 256), (torch.float32, 100), (torch.float64, 64),
+                                     (torch.bfloat16, 128), (torch.float32, 1433)])
+def test_spmm_split_hub_rows(dev, k, dtype, d):
+    """Rows cut into segments over several workgroups + in-order combine == the one-workgroup-per-row kernel."""
+    csr = ragged_csr(900, seed=3, hubs=(700, 129, 64, 900, 385))
+    V, acc, gamma, seg = csr.num_vertices, _hip.acc_dtype(dtype), 0.76, 128
+    X = synth.gaussian_X(V, d, seed=1).to(dtype)
+    Zold = (synth.gaussian_X(V, d, seed=2) * 0.5).to(dtype)
+    P = O.build_P_values(csr.rowptr, csr.colidx, synth.gaussian_X(V, 8, seed=6).double()).to(acc).to(dev)
+    Xd, Zo = padded(X, dtype, dev), padded(Zold, dtype, dev)
+    rowptr, colidx = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    deg = np.diff(csr.rowptr)
+    rows = np.nonzero(deg > seg)[0].astype(np.int32)
+    nseg = -(-deg[rows] // seg)
+    seg_ptr = np.zeros(rows.size + 1, dtype=np.int64)
+    np.cumsum(nseg, out=seg_ptr[1:])
+    seg_row = np.repeat(np.arange(rows.size, dtype=np.int32), nseg)
+    rows_d, seg_ptr_d, seg_row_d = (torch.from_numpy(a).to(dev) for a in (rows, seg_ptr, seg_row))
+    slab = torch.full((k.spmm_split_slab_len(int(seg_ptr[-1]), d),), float("nan"), dtype=acc, device=dev)
+    Zs, Zl = torch.zeros_like(Zo), torch.zeros_like(Zo)
+    ps = torch.zeros(rows.size, dtype=torch.float64, device=dev)
+    pl = torch.zeros(rows.size, dtype=torch.float64, device=dev)
+    k.spmm_update_split(rowptr, colidx, P, rows_d, seg_ptr_d, seg_row_d, seg, 0, Zo, Xd, gamma, Zs, d, slab, ps)
+    k.spmm_update_long(rowptr, colidx, P, rows_d, 16, 0, Zo, Xd, gamma, Zl, d, pl)
+    Z_ref, _ = O.sweep(csr.rowptr, csr.colidx, P.cpu().double(), X.double(), Zold.double(), gamma)
+    sel = torch.from_numpy(rows.astype(np.int64))
+    assert rel(Zs[sel.to(dev), :d], Z_ref[sel]) < TOL[dtype]
+    assert rel(Zs[sel.to(dev), :d], Zl[sel.to(dev), :d]) < (1e-13 if dtype == torch.float64 else TOL[dtype])
+    assert torch.allclose(ps, pl, rtol=1e-5 if dtype != torch.bfloat16 else 2e-2)
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[sel] = False
+    assert float(Zs[untouched.to(dev)].abs().sum()) == 0.0           # only the listed rows are written

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""One rank's share of a W-GPU sweep, timed alone on one GPU: the engine is built for (world W, rank 0) with a
+comm whose collectives do nothing, so only the kernels (and the send-buffer packing) run.  Halo rows go stale,
+which does not change the memory traffic.  Usage: tools/rank_compute_time.py [--workload rmat2m] [--world 8]"""
+import argparse, json, sys, time
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from clane_amd import _hip, synth
+from clane_amd.engine import SweepEngine
+import bench
+
+
+class NullComm:
+    def __init__(self, world, rank=0):
+        self.world, self.rank = world, rank
+    def all_reduce_sum(self, t): pass
+    def all_gather_into(self, out, inp, async_op=False): return bench_done
+    def all_to_all_rows(self, out, inp, o, i, async_op=False): return bench_done
+    def all_gather_object(self, obj): return [obj] * self.world
+
+
+class _Done:
+    def wait(self): return True
+
+
+bench_done = _Done()
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="rmat2m")
+ap.add_argument("--world", type=int, nargs="+", default=[2, 4, 8])
+ap.add_argument("--exchange", default="halo")
+ap.add_argument("--chunks", type=int, default=4)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--natural-order", action="store_true")
+ap.add_argument("--no-split-hubs", action="store_true")
+ap.add_argument("--no-overlap", action="store_true")
+args = ap.parse_args()
+dev = _hip.require_gpu("cuda:0")
+gen, V, E, d, dname, gseed, xseed = bench.WORKLOADS[args.workload]
+csr = synth.rmat_csr(V, E, seed=gseed) if gen == "rmat" else synth.powerlaw_csr(V, E, seed=gseed)
+X = synth.gaussian_X(V, d, seed=xseed).to(bench.DTYPES[dname])
+for W in args.world:
+    eng = SweepEngine(csr, X, dev, comm=NullComm(W), chunks=args.chunks, exchange=args.exchange,
+                      hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs, overlap_chunks=not args.no_overlap)
+    eng.build_P()
+    for _ in range(5):
+        eng.sweep(0.76)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.sweep(0.76)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    print(json.dumps({"world": W, "exchange": args.exchange, "rank0_compute_ms_per_sweep": round(ms, 3),
+                      "recv_MB_per_sweep": round(eng.exchange_bytes_per_sweep() / 1e6), "table_rows": eng.part.padded_vertices,
+                      "n_local": eng.part.n_local, "E_loc": eng.E_loc, "hot_rows_first": not args.natural_order}), flush=True)
+    del eng
+    torch.cuda.empty_cache()
