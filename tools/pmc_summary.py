@@ -64,6 +64,8 @@ def main():
     def bench_name(k):       # names used by bench.py's roofline.kernels
         if "spmm_update_kernel" in k:
             return "spmm_update_kernel"
+        if "spmm_split_segment_kernel" in k:
+            return "spmm_split_segment_kernel+combine"
         if "spmm_long_kernel" in k:
             return f"spmm_long_kernel<{k.rstrip('>').split(',')[-1].strip()} waves>"
         return None
