@@ -111,6 +111,12 @@ def main():
         csr = synth.powerlaw_csr(V, E, seed=gseed, device=str(dev))
     E = csr.num_edges
     X = synth.gaussian_X(V, d, seed=xseed).to(DTYPES[dname])
+    if world > 1:       # every rank generated the graph on its own GPU from the same seed: make sure they agree
+        mine = (E, int(csr.colidx.astype(np.int64).sum()), int(csr.rowptr[::997].sum()), float(X[::9973].double().sum()))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if any(e != everyone[0] for e in everyone):
+            raise SystemExit(f"ranks disagree on the synthetic input: {everyone}")
     log(f"{args.workload}: |V|={V} |E|={csr.num_edges} d={d} max outdeg={int(np.diff(csr.rowptr).max())} "
         f"generated in {time.perf_counter() - t0:.1f}s")
 
