@@ -103,6 +103,26 @@ def _native_parse_edges(data_root: Path):
     return src[:got], dst[:got]
 
 
+def _cached_edge_indices(data_root: Path, vertex_ids: Sequence[str]):
+    """read_edge_indices() through a small binary cache beside the text files."""
+    stamp = np.array([[p.stat().st_size, p.stat().st_mtime_ns] for p in (data_root / "V", data_root / "E")],
+                     dtype=np.int64)
+    path = data_root / ".clane_edges.npz"
+    if path.exists():
+        try:
+            with np.load(path) as z:
+                if np.array_equal(z["stamp"], stamp):
+                    return z["src"], z["dst"]
+        except Exception:
+            pass                                            # unreadable / stale cache: parse again
+    src, dst = read_edge_indices(data_root, vertex_ids)
+    try:
+        np.savez(path, stamp=stamp, src=src, dst=dst)
+    except OSError:
+        pass                                                # read-only data_root: no cache, same result
+    return src, dst
+
+
 def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray) -> HostCSR:
     """Coalesced adjacency (graph.py:104-110): sorted by (src, dst), duplicates merged, self-loops kept."""
     key = np.unique(src.astype(np.int64) * np.int64(num_vertices) + dst.astype(np.int64))
@@ -184,9 +204,11 @@ class _LazySeq:
 
 
 class Graph(torch.utils.data.Dataset):
-    def __init__(self, data_root: Path, embedding_dim: int = 128, dtype=None) -> None:
+    def __init__(self, data_root: Path, embedding_dim: int = 128, dtype=None, cache: bool = False) -> None:
         """``dtype`` (extension, default None = keep what the files hold, as upstream): storage type of the
-        embeddings on the GPU -- "float32", "float64" or "bfloat16" (bf16 storage, fp32 accumulate and P)."""
+        embeddings on the GPU -- "float32", "float64" or "bfloat16" (bf16 storage, fp32 accumulate and P).
+        ``cache`` (extension, default off): keep the parsed edge list in ``data_root/.clane_edges.npz`` and reuse
+        it while ``V`` and ``E`` are unchanged (size + mtime), so a 40M-edge graph is parsed once."""
         super().__init__()
         data_root = Path(data_root)
         self.d = embedding_dim
@@ -206,7 +228,8 @@ class Graph(torch.utils.data.Dataset):
             raise ValueError(f"content embeddings have shape {tuple(self.X.shape)}, expected "
                              f"[{len(self.vertex_ids)}, d]")
 
-        self._raw_src, self._raw_dst = read_edge_indices(data_root, self.vertex_ids)
+        self._raw_src, self._raw_dst = (_cached_edge_indices(data_root, self.vertex_ids) if cache
+                                        else read_edge_indices(data_root, self.vertex_ids))
         self.csr = csr_from_edges(len(self.vertex_ids), self._raw_src, self._raw_dst)
 
         self.V = _LazySeq(len(self.vertex_ids), lambda i: Vertex(self, i, self.vertex_ids[i]))

@@ -562,3 +562,23 @@ def test_spmm_split_hub_rows(dev, k, dtype, d):
     untouched = torch.ones(V, dtype=torch.bool)
     untouched[sel] = False
     assert float(Zs[untouched.to(dev)].abs().sum()) == 0.0           # only the listed rows are written
+
+
+def test_custom_similarity_plugin_on_gpu(tmp_path):
+    """A user-defined similarity callable (plugin protocol, reference __main__.py:39-48 / graph.py:121): called
+    once with the gathered GPU batches, normalised by the HIP segmented softmax."""
+    gold, g = graph_from_golden(tmp_path, "g5_symkarate_d16_g0.76.npz")
+    calls = []
+
+    def dot_sim(a, b):
+        calls.append((a.is_cuda, tuple(a.shape)))
+        return (a * b).sum(1)
+
+    P = g.build_P(dot_sim)
+    assert calls == [(True, (156, 16))]
+    X = torch.from_numpy(gold["X"])
+    ref = O.build_P_values(g.csr.rowptr, g.csr.colidx, X, similarity=lambda a, b: (a * b).sum(1))
+    np.testing.assert_allclose(P.values().numpy(), ref.numpy(), rtol=1e-5, atol=1e-7)
+    emb = Embedder(g, dot_sim, torch.device("cuda"), gamma=0.3, tolerence=3, verbose=False, max_sweeps=50)
+    emb.propagate()
+    assert torch.isfinite(g.Z).all() and (g.Z - g.X).abs().sum() > 0

@@ -353,3 +353,29 @@ def test_halo_layout_is_consistent_across_ranks(W, C):
         # the constant tail of the halo holds remote rows without out-edges
         tail = l.table_vertex[l.blocks[-1].exchange.recv_start + l.blocks[-1].exchange.recv_rows:]
         assert (outdeg[tail] == 0).all()
+
+
+def test_edge_cache_roundtrip_and_invalidation(tmp_path, karate_root):
+    g1 = Graph(karate_root, embedding_dim=4, cache=True)
+    assert (karate_root / ".clane_edges.npz").exists()
+    g2 = Graph(karate_root, embedding_dim=4, cache=True)                    # served from the cache
+    np.testing.assert_array_equal(g1.csr.colidx, g2.csr.colidx)
+    assert len(g2.E) == 78
+    e = (karate_root / "E").read_text()
+    (karate_root / "E").write_text(e + "1\t34\n")                           # file changed -> cache ignored
+    g3 = Graph(karate_root, embedding_dim=4, cache=True)
+    assert len(g3.E) == 79 and g3.get_nbrs(0).tolist() == [33]
+
+
+def test_f1_harness_runs(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("evaluate_f1", Path(__file__).parent.parent / "tools" / "evaluate_f1.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(0)
+    y = rng.integers(0, 3, 300)
+    Z = np.eye(3)[y] + 0.1 * rng.standard_normal((300, 3))                   # separable embeddings -> F1 ~ 1
+    rows = mod.f1_table(Z, y, [0.1, 0.5, 0.9], runs=2)
+    assert len(rows) == 3 and all(m > 0.95 and M > 0.95 for _, m, M in rows)
+    (tmp_path / "Y").write_text("\n".join(f"{i}\t{'ABC'[c]}" for i, c in enumerate(y)) + "\n")
+    assert np.array_equal(mod.read_labels(tmp_path / "Y"), y)
