@@ -151,9 +151,14 @@ int edge_score(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int6
     const bool fuse = (flags & CLANE_SCORE_FUSE_SOFTMAX) != 0;
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? 8 : 4;
-        edge_score_kernel<T, VEC, LPR, U><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(
-            rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, long_threshold, fuse,
-            rows_per_block(nrows));
+        if constexpr (LPR < kWave && VEC > 1)      // narrow rows: one sub-wave per source row
+            edge_score_subrow_kernel<T, VEC, LPR, U><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(
+                rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, long_threshold, fuse,
+                rows_per_block(nrows));
+        else
+            edge_score_kernel<T, VEC, LPR, U><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(
+                rowptr, colidx, nrows, row0, Z, ldz, d, mode, sums2, sq, scores, long_threshold, fuse,
+                rows_per_block(nrows));
         if (n_long > 0)
             edge_score_long_kernel<T, VEC, LPR, U, kLongWaves>
                 <<<unsigned(n_long), kLongWaves * kWave, 0, (hipStream_t)stream>>>(

@@ -55,8 +55,9 @@ __device__ __forceinline__ A finalize_score(A dot, int mode, A D, A nsrc, const 
 }
 
 // Scores of edges [ea, eb) of the row whose source is global row `src_row` (a whole row, or one
-// wave's slice of a long row).  `softmax`: [ea, eb) is a whole row of <= 64 edges -- normalise it
-// before storing.  Must be called by all 64 lanes.
+// wave's slice of a long row).  `softmax`: [ea, eb) is a WHOLE row -- normalise it (in registers when it
+// fits one 64-edge chunk, else with a running max / sum and a second pass over the stored scores).
+// Must be called by all 64 lanes.
 template <typename T, int VEC, int LPR, int U>
 __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ colidx, int64_t ea, int64_t eb,
                                                  int64_t src_row, const T *__restrict__ Z, int64_t ldz, int d,
@@ -74,6 +75,7 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
     const A nsrc = mode == kScorePerEdge ? sqrt(sq[src_row]) : A(0);
     Pack<T, VEC> s0{};
     if (single && sl * VEC < d) s0 = load_pack<T, VEC>(zsrc + sl * VEC);
+    A run_m = -A(INFINITY), run_s = A(0);
 
     for (int64_t e = ea; e < eb; e += kWave) {
         const int64_t left = eb - e;
@@ -141,15 +143,20 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
             const A got = lane_get(serve, src);
             if (take) mine = got;
         }
-        if (softmax) {  // whole row in this chunk (graph.py:122-123)
+        if (softmax) {  // graph.py:122-123; running max / sum over the row's chunks (online softmax)
             const bool in = lane < n;
             const A v = in ? mine : -A(INFINITY);
-            const A m = group_max<kWave>(v);
-            const A ex = in ? exp_acc<A>(v - m) : A(0);
-            const A ssum = group_sum<kWave>(ex);
-            mine = ex / ssum;
+            const A new_m = fmax(run_m, group_max<kWave>(v));
+            const A ex = in ? exp_acc<A>(v - new_m) : A(0);
+            const A cs = group_sum<kWave>(ex);
+            run_s = run_s * exp_acc<A>(run_m - new_m) + cs;
+            run_m = new_m;
+            if (eb - ea <= kWave) mine = ex / cs;  // the whole row is in this chunk: finished in registers
         }
         if (lane < n) scores[e + lane] = mine;
+    }
+    if (softmax && eb - ea > kWave) {  // second pass over this wave's own stores (each lane re-reads what it wrote)
+        for (int64_t e = ea + lane; e < eb; e += kWave) scores[e] = exp_acc<A>(scores[e] - run_m) / run_s;
     }
 }
 
@@ -174,8 +181,93 @@ __global__ __launch_bounds__(kBlock) void edge_score_kernel(
         const int64_t e0 = rowptr[r];
         const int64_t e1 = rowptr[r + 1];
         if (e0 == e1 || (long_threshold > 0 && e1 - e0 > long_threshold)) continue;
-        score_edge_range<T, VEC, LPR, U>(colidx, e0, e1, row0 + r, Z, ldz, d, mode, D, sq, scores,
-                                         fuse_softmax && e1 - e0 <= kWave);
+        score_edge_range<T, VEC, LPR, U>(colidx, e0, e1, row0 + r, Z, ldz, d, mode, D, sq, scores, fuse_softmax);
+    }
+}
+
+// Narrow rows (LPR < 64): one SUB-WAVE per source row, 64/LPR rows per wave in flight -- the K1 counterpart
+// of spmm_update_subrow_kernel.  Each sub-wave keeps its source pack in registers, walks its row LPR edges
+// per refill and 8 neighbour rows per group (branch-free gathers), reduces the 8 partial dots with the
+// transposed butterfly over its LPR lanes, and soft-maxes its row (running max / sum, second pass).
+template <typename T, int VEC, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void edge_score_subrow_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows, int64_t row0,
+    const T *__restrict__ Z, int64_t ldz, int d, int mode, const double *__restrict__ sums2,
+    const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores,
+    int64_t long_threshold, bool fuse_softmax, int rows_per_block) {
+    using A = typename Elem<T>::acc_t;
+    static_assert(LPR < kWave && LPR >= 8 && U == 8, "sub-wave layout");
+    constexpr int RPW = kWave / LPR;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int sub = lane / LPR, sl = lane % LPR, sub_base = sub * LPR;
+    const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
+    const int64_t row_end = row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows;
+    const A D = global_denominator<A>(mode, sums2);
+    const int c0 = sl * VEC;
+    const bool col_ok = c0 < d;
+    const int c0s = col_ok ? c0 : 0;
+
+    for (int64_t base = row_begin + wave * RPW; base < row_end; base += kWavesPerBlock * RPW) {
+        const int64_t r = base + sub;
+        int64_t e0 = 0;
+        int deg = 0;
+        if (r < row_end) {
+            e0 = rowptr[r];
+            const int64_t dg = rowptr[r + 1] - e0;
+            deg = (long_threshold > 0 && dg > long_threshold) ? 0 : int(dg);
+        }
+        const int64_t gsrc = row0 + (r < row_end ? r : row_begin);
+        Pack<T, VEC> s0 = load_pack<T, VEC>(Z + gsrc * ldz + c0s);
+        if (!col_ok) s0 = Pack<T, VEC>{};
+        const A nsrc = mode == kScorePerEdge ? sqrt(sq[gsrc]) : A(0);
+        A run_m = -A(INFINITY), run_s = A(0);
+        for (int eb = 0; __any(eb < deg); eb += LPR) {
+            const int n = deg - eb < LPR ? (deg - eb > 0 ? deg - eb : 0) : LPR;
+            int c = sl < n ? colidx[e0 + eb + sl] : 0;
+            c = sl < n ? c : lane_get(c, sub_base);      // lanes past the row: the chunk's first column (row 0 if none)
+            A mine = A(0);
+            for (int j = 0; __any(j < n); j += U) {
+                A part[U];
+                Pack<T, VEC> z[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = j + u;
+                    const int cj = lane_get(c, sub_base + (idx < LPR ? idx : LPR - 1));
+                    z[u] = load_pack<T, VEC>(Z + int64_t(cj) * ldz + c0s);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    part[u] = A(0);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        part[u] = fma(Elem<T>::to_acc(s0.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
+                }
+                A serve = transpose_reduce8<LPR>(part, sl);
+                const int idx_serve = j + sl / (LPR / 8);
+                int col_serve = 0;
+                if (mode == kScorePerEdge) col_serve = lane_get(c, sub_base + (idx_serve < LPR ? idx_serve : LPR - 1));
+                serve = finalize_score<A>(serve, mode, D, nsrc, sq, col_serve);
+                const int rel = sl - j;                      // lane sl of the sub-wave takes edge eb + sl
+                const bool take = rel >= 0 && rel < U;
+                const A got = lane_get(serve, take ? sub_base + rel * (LPR / 8) : lane);
+                if (take) mine = got;
+            }
+            const bool in = sl < n;
+            if (fuse_softmax) {
+                const A v = in ? mine : -A(INFINITY);
+                const A new_m = fmax(run_m, group_max<LPR>(v));
+                const A ex = in ? exp_acc<A>(v - new_m) : A(0);
+                const A cs = group_sum<LPR>(ex);
+                run_s = run_s * exp_acc<A>(run_m - new_m) + cs;
+                run_m = new_m;
+                if (deg <= LPR) mine = ex / cs;
+            }
+            if (in) scores[e0 + eb + sl] = mine;
+        }
+        if (fuse_softmax && deg > LPR) {
+            for (int e = sl; e < deg; e += LPR) scores[e0 + e] = exp_acc<A>(scores[e0 + e] - run_m) / run_s;
+        }
     }
 }
 

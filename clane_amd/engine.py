@@ -29,7 +29,7 @@ import torch
 
 from . import _hip
 from .comm import TorchComm
-from .halo import HaloLayout, build_halo_layout
+from .halo import build_halo_layout
 from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
 
 # Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md):
@@ -266,10 +266,10 @@ class SweepEngine:
                 rp = self.rowptr[b.local_start:]
                 k.edge_score(rp, self.colidx, b.nrows, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
                              self.long_threshold, self.long_rows[i], fuse_softmax=True)
-                # rows of <= 64 edges were normalised by K1; the rest: one wave (<= T) or one workgroup per row
-                if self.max_degree > _hip.FUSED_SOFTMAX_MAX_DEGREE:
-                    k.segment_softmax(rp, b.nrows, self.P, _hip.FUSED_SOFTMAX_MAX_DEGREE, self.long_threshold,
-                                      self.long_rows[i])
+                # K1 soft-maxed every row it scored with one wave; listed rows of > 64 edges: one workgroup each
+                if self.long_rows[i] is not None and self.max_degree > _hip.FUSED_SOFTMAX_MAX_DEGREE:
+                    k.segment_softmax(rp, b.nrows, self.P, _hip.FUSED_SOFTMAX_MAX_DEGREE,
+                                      _hip.FUSED_SOFTMAX_MAX_DEGREE, self.long_rows[i])
         self.P_valid = True
 
     def P_global(self) -> torch.Tensor:

@@ -26,8 +26,8 @@
  *    Suffix _f64: T = double, accumulate double, P/scores double (C.npy may be float64 and
  *                 the reference keeps that dtype: graph.py:51).
  *    Suffix _bf16: T = bf16 storage for Z/X, accumulate float, P/scores float.
- *  - Reductions that feed control flow (the L1 delta) are deterministic: fixed grid,
- *    fixed-order partials, no float atomics.
+ *  - Reductions that feed control flow (the L1 delta) are deterministic: one partial per workgroup /
+ *    listed row, summed in index order, no float atomics -- two launches give bitwise equal results.
  */
 #ifndef CLANE_HIP_H_
 #define CLANE_HIP_H_
@@ -87,8 +87,9 @@ int clane_degree_weighted_sums_f64(const double *sq, const int64_t *rowptr, cons
  * Rows with more than `long_threshold` edges (0 = never) are cut into per-wave slices by a
  * second launch over `long_rows` (local row ids, n_long of them; one 16-wave workgroup per row);
  * pass n_long = 0 to have every row walked by a single wave.
- * flags & CLANE_SCORE_FUSE_SOFTMAX: rows of <= 64 edges are soft-maxed in registers before they are
- * stored (graph.py:122-123 for those rows); follow with clane_segment_softmax_*(min_degree = 64). */
+ * flags & CLANE_SCORE_FUSE_SOFTMAX: every row scored by a single wave -- all rows of <= long_threshold
+ * edges and listed rows of <= 64 edges -- is soft-maxed by this call (graph.py:122-123); the remaining
+ * listed rows are finished by clane_segment_softmax_*(min_degree = 64, max_degree = 64, long_rows). */
 int clane_edge_score_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const float *Z,
                          int64_t ldz, int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
                          int32_t flags, int64_t long_threshold, const int32_t *long_rows, int64_t n_long, void *stream);
@@ -103,8 +104,8 @@ int clane_edge_score_bf16(const int64_t *rowptr, const int32_t *colidx, int64_t 
 /* ---- K2: in-place softmax of vals within each CSR row.  Replaces the per-row boolean-mask
  * loop of graph.py:122-123.  Rows with min_degree < deg <= max_degree (max_degree 0 = no upper
  * limit) are normalised by one wave each; the rows listed in `long_rows` (deg > min_degree) by one
- * 16-wave workgroup each.  Empty rows are skipped.  After clane_edge_score_* with
- * CLANE_SCORE_FUSE_SOFTMAX pass min_degree = 64. */
+ * 16-wave workgroup each.  Empty rows are skipped; max_degree <= min_degree (both > 0) disables the
+ * one-wave pass.  After clane_edge_score_* with CLANE_SCORE_FUSE_SOFTMAX pass min_degree = max_degree = 64. */
 int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, int64_t min_degree,
                               int64_t max_degree, const int32_t *long_rows, int64_t n_long, void *stream);
 int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals, int64_t min_degree,

@@ -44,9 +44,10 @@ class OracleKernels:
         elif mode == 1:
             dots = dots / (sq[rows].sqrt() * sq[cols].sqrt())
         scores[rp[0]:rp[-1]] = dots
-        if fuse_softmax:
+        if fuse_softmax:      # every row scored by one wave: <= long_threshold, and listed rows of <= 64 edges
             for r in range(nrows):
-                if 0 < rp[r + 1] - rp[r] <= 64:
+                dg = rp[r + 1] - rp[r]
+                if dg > 0 and (dg <= 64 or long_threshold == 0 or dg <= long_threshold):
                     scores[rp[r]:rp[r + 1]] = torch.softmax(scores[rp[r]:rp[r + 1]], 0)
 
     def segment_softmax(self, rowptr, nrows, vals, min_degree=0, max_degree=0, long_rows=None):

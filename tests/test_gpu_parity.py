@@ -418,10 +418,10 @@ def test_edge_score_fused_softmax(dev, k, dtype, d, pad):
         k.segment_softmax(rowptr, V, two_pass)
         fused = torch.zeros_like(two_pass)
         k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_PER_EDGE, None, sq, fused, lt, lr, fuse_softmax=True)
-        k.segment_softmax(rowptr, V, fused, _hip.FUSED_SOFTMAX_MAX_DEGREE, lt, lr)     # long rows: workgroup per row
-        short = torch.from_numpy(np.repeat(deg <= 64, deg)).to(dev)
-        assert torch.equal(fused[short], two_pass[short])
+        k.segment_softmax(rowptr, V, fused, 64, 64, lr)     # one-wave pass off; listed rows > 64: workgroup per row
+        # same scores, same softmax up to the reduction order (in-register / running max-sum / K2's three passes)
         assert rel(fused, two_pass) < (1e-14 if dtype == torch.float64 else 3e-7)
+        assert float((fused - two_pass).abs().max()) < (1e-14 if dtype == torch.float64 else 2e-7)
     ref = O.build_P_values(csr.rowptr, csr.colidx, Zc.to(acc).double(), mode="per_edge")
     assert rel(fused, ref) < (1e-13 if dtype == torch.float64 else 5e-6)
 
