@@ -9,6 +9,7 @@ runs on the GPU; ``--gpu`` only selects where ``Embedder.device`` points, as ups
 from __future__ import annotations
 
 import argparse
+import os
 from pathlib import Path
 
 import numpy as np
@@ -20,8 +21,24 @@ from .embedder import Embedder, IterativeEmbedder
 from .graph import Graph
 
 
+def _distributed_setup():
+    """Under `torchrun --nproc-per-node N` (WORLD_SIZE > 1): one process per GPU, RCCL process group.
+    Returns (rank, world).  A plain `python -m clane_amd` run is (0, 1) and touches nothing."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1
+    import torch.distributed as dist
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return dist.get_rank(), world
+
+
 def embedding(args):
-    print('[Embedding]', end='\n')
+    rank, world = _distributed_setup()
+    say = print if rank == 0 else (lambda *a, **k: None)      # every rank computes; rank 0 talks and writes
+    say('[Embedding]', end='\n')
 
     if args.config_file.absolute().exists():
         with open(args.config_file.absolute(), 'r') as config_io:
@@ -32,13 +49,19 @@ def embedding(args):
     device = torch.device('cuda') if args.gpu else torch.device('cpu')
     g = Graph(data_root=args.data_root, **hparams["graph"])
 
-    print("Graph Loaded.")
-    print(f" - {len(g)} vertices")
-    print(f" - {len(g.E)} edges")
-    print(" - Content Embeddings:")
-    print(f"     - dim : {g.d:3d}")
-    print(f"     - mean: {g.X.mean():5.2f}")
-    print(f"     - std : {g.X.std():5.2f}")
+    if world > 1:                                   # unseeded N(0,1) content (no C.npy) must agree across ranks
+        import torch.distributed as dist
+        Xd = g.X.cuda()
+        dist.broadcast(Xd, 0)
+        g.X = Xd.cpu()
+
+    say("Graph Loaded.")
+    say(f" - {len(g)} vertices")
+    say(f" - {len(g.E)} edges")
+    say(" - Content Embeddings:")
+    say(f"     - dim : {g.d:3d}")
+    say(f"     - mean: {g.X.mean():5.2f}")
+    say(f"     - std : {g.X.std():5.2f}")
 
     try:
         similarity_measure = getattr(similarity, hparams["similarity"]["method"])
@@ -51,9 +74,14 @@ def embedding(args):
     extra = {"num_workers": args.num_workers} if embedder_cls is IterativeEmbedder else {}
     embedder = embedder_cls(graph=g, similarity_measure=similarity_measure, device=device,
                             save_history=args.save_history, **extra, **hparams["embedder"])
+    if rank != 0:
+        embedder.verbose = False
     embedder.iterate()
+    final_Z = g.Z                                   # collective when world > 1: every rank takes part
+    if rank != 0:
+        return
 
-    print("Saving the results.")
+    say("Saving the results.")
     if not args.output_root.exists():
         args.output_root.mkdir(parents=True, exist_ok=True)
 
@@ -62,9 +90,9 @@ def embedding(args):
             args.output_root.joinpath(f'{outer}').mkdir(parents=True, exist_ok=True)
             for sweep, Z in enumerate(history_Z):
                 np.save(args.output_root.joinpath(f'{outer}/Z_{sweep}.npy'), _to_numpy(Z))
-    np.save(args.output_root.joinpath('Z.npy'), _to_numpy(g.Z))
+    np.save(args.output_root.joinpath('Z.npy'), _to_numpy(final_Z))
 
-    print(f"The embeddings are stored in {args.output_root.joinpath('Z.npy').absolute()}.")
+    say(f"The embeddings are stored in {args.output_root.joinpath('Z.npy').absolute()}.")
 
 
 def _to_numpy(Z: torch.Tensor) -> np.ndarray:

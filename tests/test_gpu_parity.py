@@ -582,3 +582,49 @@ def test_custom_similarity_plugin_on_gpu(tmp_path):
     emb = Embedder(g, dot_sim, torch.device("cuda"), gamma=0.3, tolerence=3, verbose=False, max_sweeps=50)
     emb.propagate()
     assert torch.isfinite(g.Z).all() and (g.Z - g.X).abs().sum() > 0
+
+
+def test_config2_full_iterate_vs_c_oracle(tmp_path):
+    """BASELINE config 2 shape (R-MAT 200k / 4M / d=128 fp32), the WHOLE algorithm: Embedder.iterate() on the GPU
+    vs the plain-C oracle driven by the same tolerance machine (embedder.py:56-108).  Sweep counts may differ by
+    a few (last-ulp noise near the fixed point); the embeddings may not."""
+    from oracle import clane_oracle_c as OC
+    V, E, d, gamma, tol = 200_000, 4_000_000, 128, 0.76, 3
+    csr = synth.rmat_csr(V, E, seed=1)
+    X = synth.gaussian_X(V, d, seed=2)
+    # oracle
+    Z, sweeps_or, min_outer, outer_tol = X.clone(), [], float("inf"), tol
+    buf = torch.empty_like(Z)
+    while True:
+        prev = Z.clone()
+        P, _ = OC.build_P(csr.rowptr, csr.colidx, Z)
+        best, left, n = float("inf"), tol, 0
+        while True:
+            Zn, delta = OC.sweep(csr.rowptr, csr.colidx, P, X, Z, gamma, out=buf)
+            Z, buf = Zn.clone(), buf
+            n += 1
+            if best > delta:
+                best, left = delta, tol
+            else:
+                left -= 1
+            if left == 0 or n >= 400:
+                break
+        sweeps_or.append(n)
+        outer = float((Z - prev).abs().sum())
+        if min_outer > outer:
+            min_outer, outer_tol = outer, tol
+        else:
+            outer_tol -= 1
+        if outer_tol == 0 or len(sweeps_or) >= 40:
+            break
+    # product path
+    g = Graph.__new__(Graph)
+    torch.utils.data.Dataset.__init__(g)
+    g.d, g.vertex_ids, g.X, g.csr = d, None, X, csr
+    g._Z_host, g._dirty, g._engine, g._raw_order = None, False, None, {}
+    emb = Embedder(g, CosineSimilarity(), torch.device("cuda"), gamma=gamma, tolerence=tol, verbose=False,
+                   max_sweeps=400)
+    emb.iterate()
+    Zg = g._engine.get_Z()
+    assert O.rel_l2(Zg, Z) < 1e-5                                  # north-star bar: 1e-4
+    assert abs(len(emb.sweep_counts) - len(sweeps_or)) <= 3 and abs(sum(emb.sweep_counts) - sum(sweeps_or)) <= 40
