@@ -43,11 +43,12 @@ for _s in ("f32", "f64", "bf16"):
         C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _i64, _p, _i64, _p])
     _g = C.c_double if _s == "f64" else C.c_float
     SIGNATURES[f"clane_spmm_update_{_s}"] = (
-        C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _i32, _p, _p])
+        C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _i32, _p, _p, _p])
     SIGNATURES[f"clane_spmm_update_long_{_s}"] = (
-        C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p])
+        C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p])
     SIGNATURES[f"clane_spmm_update_split_{_s}"] = (
-        C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p])
+        C.c_int,
+        [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 for _s in ("f32", "f64"):
@@ -62,6 +63,31 @@ VEC_ELEMS = {torch.float32: 4, torch.float64: 2, torch.bfloat16: 8}  # elements 
 
 class ClaneHipError(RuntimeError):
     pass
+
+
+class _MirrorStruct(C.Structure):       # clane_mirror_t
+    _fields_ = [("row_ptr", _p), ("slot", _p), ("buf", _p), ("ld", _i64)]
+
+
+class Mirror:
+    """Second destination of the rows an spmm_update* call finishes (``clane_mirror_t``): row r of the call is
+    also stored at rows ``slot[row_ptr[r]:row_ptr[r+1]]`` of ``buf``.  Holds the tensors alive."""
+
+    def __init__(self, row_ptr: torch.Tensor, slot: torch.Tensor, buf: torch.Tensor):
+        if row_ptr.dtype != torch.int64 or slot.dtype != torch.int32 or not (row_ptr.is_contiguous()
+                                                                             and slot.is_contiguous()):
+            raise ValueError("Mirror: row_ptr must be contiguous int64 and slot contiguous int32")
+        self.row_ptr, self.slot, self.buf = row_ptr, slot, buf
+        bp, ld = _mat(buf, "mirror.buf")
+        self.c = _MirrorStruct(row_ptr.data_ptr(), slot.data_ptr(), bp, ld)
+
+
+def _mirror_arg(mirror: Optional["Mirror"], dtype: torch.dtype):
+    if mirror is None:
+        return None
+    if mirror.buf.dtype != dtype:
+        raise ValueError("mirror.buf must have the dtype of Z_new")
+    return C.cast(C.pointer(mirror.c), _p)
 
 
 def load_library(path: Optional[Path] = None) -> C.CDLL:
@@ -192,7 +218,7 @@ class HipKernels:
 
     # -- K3 -----------------------------------------------------------------------------
     def spmm_update(self, rowptr, colidx, P, nrows: int, row0: int, Z_old, X, gamma: float, Z_new, d: int,
-                    long_threshold: int, partials, sinks_untouched: bool = False):
+                    long_threshold: int, partials, sinks_untouched: bool = False, mirror: Optional[Mirror] = None):
         """Main pass: every row of <= long_threshold edges (0 = all rows).  With `sinks_untouched` rows
         without out-edges are neither read nor written (caller keeps Z_new == Z_old there)."""
         zo, ldz = _mat(Z_old, "Z_old")
@@ -204,10 +230,11 @@ class HipKernels:
                      _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
                      _vec(P, acc_dtype(Z_old.dtype), "P"), nrows, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
                      long_threshold, SPMM_SINKS_UNTOUCHED if sinks_untouched else 0,
-                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+                     _mirror_arg(mirror, Z_new.dtype), _vec(partials, torch.float64, "partials"),
+                     self._stream(Z_old))
 
     def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row: int, row0: int, Z_old, X, gamma: float,
-                         Z_new, d: int, partials):
+                         Z_new, d: int, partials, mirror: Optional[Mirror] = None):
         """Row-split pass: one workgroup of `waves_per_row` (4 | 16) waves per listed row; writes
         long_rows.numel() partials."""
         zo, ldz = _mat(Z_old, "Z_old")
@@ -219,13 +246,14 @@ class HipKernels:
                      _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
                      _vec(P, acc_dtype(Z_old.dtype), "P"), _vec(long_rows, torch.int32, "long_rows"),
                      long_rows.numel(), waves_per_row, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
-                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+                     _mirror_arg(mirror, Z_new.dtype), _vec(partials, torch.float64, "partials"),
+                     self._stream(Z_old))
 
     def spmm_split_slab_len(self, n_segments: int, d: int) -> int:
         return int(self.lib.clane_spmm_split_slab_len(n_segments, d))
 
     def spmm_update_split(self, rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment: int, row0: int,
-                          Z_old, X, gamma: float, Z_new, d: int, slab, partials):
+                          Z_old, X, gamma: float, Z_new, d: int, slab, partials, mirror: Optional[Mirror] = None):
         """Hub rows cut into segments over several workgroups + fixed-order combine; writes split_rows.numel()
         partials."""
         zo, ldz = _mat(Z_old, "Z_old")
@@ -236,8 +264,8 @@ class HipKernels:
                      _vec(P, acc_dtype(Z_old.dtype), "P"), _vec(split_rows, torch.int32, "split_rows"),
                      _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(seg_row, torch.int32, "seg_row"),
                      split_rows.numel(), seg_row.numel(), edges_per_segment, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
-                     _vec(slab, acc_dtype(Z_old.dtype), "slab"), _vec(partials, torch.float64, "partials"),
-                     self._stream(Z_old))
+                     _vec(slab, acc_dtype(Z_old.dtype), "slab"), _mirror_arg(mirror, Z_new.dtype),
+                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 
     def reduce_partials(self, partials, n: int, ws, out):
         self._invoke(self.lib.clane_reduce_partials, "clane_reduce_partials",

@@ -100,6 +100,15 @@ void dispatch_layout(const Layout &L, F &&f) {
     }
 }
 
+template <typename T>
+Mirror<T> make_mirror(const clane_mirror_t *m) {
+    if (m == nullptr || m->row_ptr == nullptr) return Mirror<T>{nullptr, nullptr, nullptr, 0};
+    return Mirror<T>{m->row_ptr, m->slot, reinterpret_cast<T *>(m->buf), m->ld};
+}
+inline bool mirror_ok(const clane_mirror_t *m, int d) {
+    return m == nullptr || m->row_ptr == nullptr || (m->slot != nullptr && m->buf != nullptr && m->ld >= d);
+}
+
 #define REQUIRE(cond, ...) \
     do {                   \
         if (!(cond)) return fail(CLANE_ERR_INVALID_ARGUMENT, __VA_ARGS__); \
@@ -189,27 +198,31 @@ inline int64_t spmm_main_grid(int64_t nrows) { return row_grid(nrows); }
 template <typename T, typename PT>
 int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows, int64_t row0,
                 const T *Z_old, int64_t ldz, const T *X, int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new,
-                int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, double *delta_partials, void *stream) {
+                int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, const clane_mirror_t *mirror,
+                double *delta_partials, void *stream) {
     REQUIRE(nrows >= 0 && row0 >= 0 && d > 0, "spmm_update: bad shape nrows=%lld row0=%lld d=%d", (long long)nrows,
             (long long)row0, d);
+    REQUIRE(mirror_ok(mirror, d), "spmm_update: incomplete mirror descriptor");
     REQUIRE(ldz >= d && ldx >= d && ldo >= d, "spmm_update: leading dimension < d");
     REQUIRE(long_threshold >= 0, "spmm_update: negative long_threshold");
     REQUIRE(delta_partials, "spmm_update: null delta_partials");
     if (nrows == 0) return CLANE_OK;
     REQUIRE(rowptr && colidx && P && Z_old && X && Z_new, "spmm_update: null pointer");
     REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update: Z_new must not alias Z_old (Jacobi sweep)");
-    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new}, {ldz, ldx, ldo});
+    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror && mirror->row_ptr ? mirror->buf : Z_new},
+                                    {ldz, ldx, ldo, mirror && mirror->row_ptr ? mirror->ld : ldo});
     const int grid = int(spmm_main_grid(nrows));
+    const Mirror<T> mir = make_mirror<T>(mirror);
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
         if constexpr (LPR < kWave && VEC > 1)      // short rows of narrow matrices: one sub-wave per row
             spmm_update_subrow_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                 rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), delta_partials);
+                (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, delta_partials);
         else
             spmm_update_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                 rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), delta_partials);
+                (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, delta_partials);
     });
     return check_launch("spmm_update");
 }
@@ -217,25 +230,28 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
 template <typename T, typename PT>
 int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, const int32_t *long_rows,
                      int64_t n_long, int32_t waves_per_row, int64_t row0, const T *Z_old, int64_t ldz, const T *X, int64_t ldx,
-                     typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d, double *delta_partials,
-                     void *stream) {
+                     typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d, const clane_mirror_t *mirror,
+                     double *delta_partials, void *stream) {
     REQUIRE(n_long >= 0 && n_long <= INT32_MAX && row0 >= 0 && d > 0, "spmm_update_long: bad shape");
+    REQUIRE(mirror_ok(mirror, d), "spmm_update_long: incomplete mirror descriptor");
     REQUIRE(ldz >= d && ldx >= d && ldo >= d, "spmm_update_long: leading dimension < d");
     if (n_long == 0) return CLANE_OK;
     REQUIRE(rowptr && colidx && P && long_rows && Z_old && X && Z_new && delta_partials,
             "spmm_update_long: null pointer");
     REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update_long: Z_new must not alias Z_old");
-    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new}, {ldz, ldx, ldo});
+    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror && mirror->row_ptr ? mirror->buf : Z_new},
+                                    {ldz, ldx, ldo, mirror && mirror->row_ptr ? mirror->ld : ldo});
     REQUIRE(waves_per_row == 4 || waves_per_row == kLongWaves, "spmm_update_long: waves_per_row must be 4 or 16");
+    const Mirror<T> mir = make_mirror<T>(mirror);
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
         if (waves_per_row == 4)
             spmm_long_kernel<T, PT, VEC, LPR, U, 4><<<int(n_long), 4 * kWave, 0, (hipStream_t)stream>>>(
-                rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, delta_partials);
+                rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
         else
             spmm_long_kernel<T, PT, VEC, LPR, U, kLongWaves>
                 <<<int(n_long), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
-                    rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, delta_partials);
+                    rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
     });
     return check_launch("spmm_update_long");
 }
@@ -245,7 +261,9 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
                       const int64_t *seg_ptr, const int32_t *seg_row, int64_t n_split, int64_t n_segments,
                       int64_t edges_per_segment, int64_t row0, const T *Z_old, int64_t ldz, const T *X, int64_t ldx,
                       typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d,
-                      typename Elem<T>::acc_t *slab, double *delta_partials, void *stream) {
+                      typename Elem<T>::acc_t *slab, const clane_mirror_t *mirror, double *delta_partials,
+                      void *stream) {
+    REQUIRE(mirror_ok(mirror, d), "spmm_update_split: incomplete mirror descriptor");
     REQUIRE(n_split >= 0 && n_split <= INT32_MAX && n_segments >= n_split && n_segments <= INT32_MAX && row0 >= 0 &&
                 d > 0 && edges_per_segment >= kWave && edges_per_segment % kWave == 0,
             "spmm_update_split: bad shape (edges_per_segment must be a positive multiple of 64)");
@@ -263,7 +281,8 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
                 rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, Z_old, ldz, d, slab, ld_slab);
     });
     spmm_split_combine_kernel<T><<<unsigned(n_split), kWave, 0, (hipStream_t)stream>>>(
-        split_rows, seg_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, delta_partials);
+        split_rows, seg_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, make_mirror<T>(mirror),
+        delta_partials);
     return check_launch("spmm_update_split");
 }
 
@@ -376,30 +395,30 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
     int clane_spmm_update_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows,             \
                                 int64_t row0, const CT *Z_old, int64_t ldz, const CT *X, int64_t ldx, GT gamma,       \
                                 CT *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags,             \
-                                double *delta_partials,                                                               \
-                                void *stream) {                                                                       \
+                                const clane_mirror_t *mirror, double *delta_partials, void *stream) {                 \
         return spmm_update<T, PT>(rowptr, colidx, P, nrows, row0, reinterpret_cast<const T *>(Z_old), ldz,            \
                                   reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new), ldo, d,   \
-                                  long_threshold, flags, delta_partials, stream);                                     \
+                                  long_threshold, flags, mirror, delta_partials, stream);                             \
     }                                                                                                                 \
     int clane_spmm_update_long_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P,                       \
                                      const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const CT *Z_old,         \
                                      int64_t ldz, const CT *X, int64_t ldx, GT gamma, CT *Z_new, int64_t ldo,         \
-                                     int32_t d, double *delta_partials, void *stream) {                               \
+                                     int32_t d, const clane_mirror_t *mirror, double *delta_partials, void *stream) { \
         return spmm_update_long<T, PT>(rowptr, colidx, P, long_rows, n_long, waves_per_row, row0,                     \
                                        reinterpret_cast<const T *>(Z_old), ldz, reinterpret_cast<const T *>(X), ldx,  \
-                                       gamma, reinterpret_cast<T *>(Z_new), ldo, d, delta_partials, stream);          \
+                                       gamma, reinterpret_cast<T *>(Z_new), ldo, d, mirror, delta_partials, stream);  \
     }
 #define CLANE_SPLIT_WRAPPER(SUF, CT, T, PT, GT)                                                                         \
     int clane_spmm_update_split_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P,                      \
                                       const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,      \
                                       int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,   \
                                       const CT *Z_old, int64_t ldz, const CT *X, int64_t ldx, GT gamma, CT *Z_new,    \
-                                      int64_t ldo, int32_t d, GT *slab, double *delta_partials, void *stream) {       \
+                                      int64_t ldo, int32_t d, GT *slab, const clane_mirror_t *mirror,                 \
+                                      double *delta_partials, void *stream) {                                         \
         return spmm_update_split<T, PT>(rowptr, colidx, P, split_rows, seg_ptr, seg_row, n_split, n_segments,         \
                                         edges_per_segment, row0, reinterpret_cast<const T *>(Z_old), ldz,             \
                                         reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new),     \
-                                        ldo, d, slab, delta_partials, stream);                                        \
+                                        ldo, d, slab, mirror, delta_partials, stream);                                \
     }
 CLANE_SPLIT_WRAPPER(f32, float, float, float, float)
 CLANE_SPLIT_WRAPPER(f64, double, double, double, double)

@@ -147,12 +147,24 @@ __device__ __forceinline__ void fold_subwaves(A (&acc)[VEC]) {
     }
 }
 
+// Optional second destination of finished rows: row r (relative to the call's first row) is also stored at
+// rows slot[row_ptr[r] .. row_ptr[r+1]) of `buf` -- the send buffer of the multi-GPU halo exchange, packed
+// by the kernel that produces the row instead of by a separate gather pass.  row_ptr == nullptr: none.
+template <typename T>
+struct Mirror {
+    const int64_t *row_ptr;
+    const int32_t *slot;
+    T *buf;
+    int64_t ld;
+};
+
 // Epilogue of one row's column tile; returns this lane's share of sum|z_new - z_old|.
 template <typename T, int VEC>
 __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC> &x, const Pack<T, VEC> &zo,
                                                                const typename Elem<T>::acc_t (&acc)[VEC],
                                                                typename Elem<T>::acc_t gamma, bool has_edges,
-                                                               T *__restrict__ dst) {
+                                                               T *__restrict__ dst, const Mirror<T> &mirror,
+                                                               int64_t row, int col) {
     using A = typename Elem<T>::acc_t;
     Pack<T, VEC> out;
     A rsum = A(0);
@@ -164,6 +176,10 @@ __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC
         rsum += fabs(Elem<T>::to_acc(out.v[k]) - zold);
     }
     store_pack<T, VEC>(dst, out);
+    if (mirror.row_ptr != nullptr) {
+        for (int64_t s = mirror.row_ptr[row]; s < mirror.row_ptr[row + 1]; ++s)
+            store_pack<T, VEC>(mirror.buf + int64_t(mirror.slot[s]) * mirror.ld + col, out);
+    }
     return rsum;
 }
 
@@ -178,7 +194,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    bool skip_sinks, int rows_per_block, double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
     __shared__ double s_rowsum[kMaxRowsPerBlock];
@@ -247,7 +263,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
                 for (int k = 0; k < VEC; ++k) acc[k] = A(0);
                 gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
                 fold_subwaves<LPR>(acc);
-                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0);
+                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, mirror, r, c0);
             }
             rsum = group_sum<kWave>(rsum);
             if (lane == 0) s_rowsum[cur] = double(rsum);
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    bool skip_sinks, int rows_per_block, double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     static_assert(LPR < kWave, "use spmm_update_kernel for rows that fill a wave");
     constexpr int RPW = kWave / LPR;  // rows per wave
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
             }
         }
         A rsum = A(0);
-        if (work && col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, deg > 0, Znew + r * ldo + c0);
+        if (work && col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, deg > 0, Znew + r * ldo + c0, mirror, r, c0);
         rsum = group_sum<LPR>(rsum);
         if (work && sl == 0) s_rowsum[mine] = double(rsum);
         int v = 0;
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P,
     const int32_t *__restrict__ long_rows, int64_t row0, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
-    double *__restrict__ partials) {
+    Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ A red[WAVES][kWave][VEC];
     const int lane = lane_id();
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
             }
-            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0);
+            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, mirror, r, c0);
         }
         if (t0 + LPR * VEC < d) __syncthreads();  // red[] is reused by the next column tile
     }
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(kWave) void spmm_split_combine_kernel(
     const int32_t *__restrict__ split_rows, const int64_t *__restrict__ seg_ptr, int64_t row0,
     const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
-    double *__restrict__ partials) {
+    Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     const int i = blockIdx.x;
     const int64_t r = split_rows[i];
@@ -526,6 +542,10 @@ __global__ __launch_bounds__(kWave) void spmm_split_combine_kernel(
         const A zold = Elem<T>::to_acc(Zold[(row0 + r) * ldz + c]);
         const T out = Elem<T>::from_acc(Elem<T>::to_acc(X[r * ldx + c]) + gamma * tot);
         Znew[r * ldo + c] = out;
+        if (mirror.row_ptr != nullptr) {
+            for (int64_t m = mirror.row_ptr[r]; m < mirror.row_ptr[r + 1]; ++m)
+                mirror.buf[int64_t(mirror.slot[m]) * mirror.ld + c] = out;
+        }
         rsum += fabs(Elem<T>::to_acc(out) - zold);
     }
     rsum = group_sum<kWave>(rsum);

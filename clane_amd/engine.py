@@ -43,9 +43,12 @@ from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
 # A 4-wave bin (T < deg <= hub_threshold) exists in the ABI; it did not pay.
 LONG_THRESHOLD_BY_ROWS_PER_WAVE = {1: 32, 2: 64, 4: 384, 8: 512}
 HUB_FACTOR = 1
-# Rows above this many edges are cut into segments of that size, one 16-wave workgroup each (256 edges per wave):
-# a 70k-edge hub done by ONE workgroup is a ~0.25 ms tail on every launch.
+# Rows above SPLIT_EDGES edges are cut into segments, one 16-wave workgroup each: a 70k-edge hub done by ONE
+# workgroup is a ~0.25 ms tail on every launch.  Segments are 4096 edges (256 per wave) when there are plenty of
+# hub edges, down to 1024 when a rank holds few (8 GPUs: ~30 hub rows per rank would give < 100 workgroups).
 SPLIT_EDGES = 4096
+MIN_SEGMENT_EDGES = 1024
+TARGET_SEGMENTS = 512                   # two workgroups per CU
 
 
 def lanes_per_row(d: int, dtype: torch.dtype) -> int:
@@ -63,7 +66,7 @@ class SweepEngine:
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
                  exchange: str = "halo", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
-                 overlap_chunks: bool = True):
+                 overlap_chunks: bool = True, fused_pack: bool = True):
         """``exchange`` (N > 1 only): "halo" -- a compact per-rank table, rows sent only to the ranks that read
         them (halo.py); "allgather" -- full-size Z on every rank, in-place all-gather of the live rows
         (partition.py); "allgather_all" -- the same without the live/quiet split."""
@@ -121,6 +124,8 @@ class SweepEngine:
         self.hub_rows: List[Optional[torch.Tensor]] = []      # hub_threshold < deg <= SPLIT_EDGES: 16 waves/row
         self.split_rows: List[Optional[tuple]] = []           # deg > SPLIT_EDGES: (rows, seg_ptr, seg_row) on device
         self.split_edges = SPLIT_EDGES if split_hubs else 0
+        hub_edges = int(deg[deg > SPLIT_EDGES].sum()) // max(1, len(self.blocks))
+        self.segment_edges = int(min(SPLIT_EDGES, max(MIN_SEGMENT_EDGES, hub_edges // TARGET_SEGMENTS // 1024 * 1024)))
         max_segments = 0
         self.partial_off = [0]
         to_dev = lambda a: torch.from_numpy(a.astype(np.int32)).to(dev) if a.size else None  # noqa: E731
@@ -134,7 +139,7 @@ class SweepEngine:
             self.hub_rows.append(to_dev(np.nonzero(is_hub)[0]))
             rows_s = np.nonzero(is_split)[0]
             if rows_s.size:
-                nseg = -(-db[rows_s] // self.split_edges)
+                nseg = -(-db[rows_s] // self.segment_edges)
                 seg_ptr = np.zeros(rows_s.size + 1, dtype=np.int64)
                 np.cumsum(nseg, out=seg_ptr[1:])
                 seg_row = np.repeat(np.arange(rows_s.size, dtype=np.int32), nseg)
@@ -150,14 +155,29 @@ class SweepEngine:
                                   device=dev) for _ in range(2)]
 
         # ---- halo exchange: send lists and send buffers (one per own chunk) -----------------
+        # The kernel that finishes a row also stores it to its slots of the send buffer (`mirrors`: row -> slots,
+        # the inverse of send_rows), so no separate packing pass runs between the kernels and the exchange.
         self.send_rows: List[Optional[torch.Tensor]] = []
         self.send_buf: List[Optional[torch.Tensor]] = []
+        self.mirrors: List[Optional[object]] = []
+        self.fused_pack = bool(fused_pack) and hasattr(_hip, "Mirror")
         for b in self.blocks:
             ex = b.exchange
             has = ex is not None and ex.send_rows.size > 0
             self.send_rows.append(torch.from_numpy(ex.send_rows).to(dev) if has else None)
             self.send_buf.append(torch.zeros(ex.send_rows.size, self.ld, dtype=self.dtype, device=dev) if has
                                  else (torch.zeros(0, self.ld, dtype=self.dtype, device=dev) if ex is not None else None))
+            mirror = None
+            if has and self.fused_pack:
+                rel = ex.send_rows.astype(np.int64) - b.local_start
+                if rel.min() < 0 or rel.max() >= b.nrows or (deg[ex.send_rows] == 0).any():
+                    raise AssertionError("halo send list holds a row outside its chunk or a row that never changes")
+                row_ptr = np.zeros(b.nrows + 1, dtype=np.int64)
+                np.cumsum(np.bincount(rel, minlength=b.nrows), out=row_ptr[1:])
+                slot = np.argsort(rel, kind="stable").astype(np.int32)
+                mirror = self._make_mirror(torch.from_numpy(row_ptr).to(dev), torch.from_numpy(slot).to(dev),
+                                           self.send_buf[-1])
+            self.mirrors.append(mirror)
 
         # ---- embeddings ---------------------------------------------------------------
         if self.halo:
@@ -193,6 +213,10 @@ class SweepEngine:
             self.side_streams = [torch.cuda.Stream(self.device) for _ in range(2)]
         self.time_kernels = False
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
+
+    def _make_mirror(self, row_ptr, slot, buf):
+        make = getattr(self.k, "make_mirror", None)          # substitute kernels (tests) bring their own
+        return make(row_ptr, slot, buf) if make is not None else _hip.Mirror(row_ptr, slot, buf)
 
     # ---- views of one block -------------------------------------------------------------
     def _rows(self, b: Block):
@@ -298,7 +322,7 @@ class SweepEngine:
             ctx = torch.cuda.stream(self.side_streams[i % 2]) if self.side_streams else contextlib.nullcontext()
             with ctx:            # bound calls capture the current stream
                 rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
-                po = self.partial_off[i]
+                po, mir = self.partial_off[i], self.mirrors[i]
                 po_mid = po + k.spmm_partials_len(b.nrows, 0)
                 po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
                 po_split = po_hub + (0 if self.hub_rows[i] is None else self.hub_rows[i].numel())
@@ -307,26 +331,28 @@ class SweepEngine:
                 if self.split_rows[i] is not None:
                     rows_s, seg_ptr, seg_row = self.split_rows[i]
                     steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
-                                                     seg_row, self.split_edges, b.row0, Zold, Xb, gamma, Zn, self.d,
-                                                     self.slabs[i % 2], self.partials[po_split:])))
+                                                     seg_row, self.segment_edges, b.row0, Zold, Xb, gamma, Zn, self.d,
+                                                     self.slabs[i % 2], self.partials[po_split:], mirror=mir)))
                 steps.append(("event", i, 4))
                 if self.hub_rows[i] is not None:
                     steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
-                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:])))
+                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:],
+                                                     mirror=mir)))
                 steps.append(("event", i, 1))
                 if self.mid_rows[i] is not None:
                     steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.mid_rows[i], 4,
-                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:])))
+                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:],
+                                                     mirror=mir)))
                 steps.append(("event", i, 2))
                 steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb,
                                                  gamma, Zn, self.d, self.long_threshold, self.partials[po:],
-                                                 sinks_untouched=True)))
+                                                 sinks_untouched=True, mirror=mir)))
                 steps.append(("event", i, 3))
                 if b.span is not None:
                     steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))
                 elif b.exchange is not None:  # halo: pack the rows of this chunk that others read, swap, no unpack
                     ex = b.exchange
-                    if self.send_rows[i] is not None:
+                    if self.send_rows[i] is not None and mir is None:
                         steps.append(("call", self._bind("gather_rows", Znew, self.send_rows[i], self.d,
                                                          self.send_buf[i])))
                     steps.append(("alltoall", Znew[ex.recv_start:ex.recv_start + ex.recv_rows], self.send_buf[i],

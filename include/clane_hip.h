@@ -55,6 +55,17 @@ extern "C" {
 /* flags of clane_spmm_update_* */
 #define CLANE_SPMM_SINKS_UNTOUCHED 1
 
+/* Optional second destination of the rows a clane_spmm_update* call finishes: row r (relative to the call's
+ * first row) is also stored at rows slot[row_ptr[r] .. row_ptr[r+1]) of `buf` (leading dimension ld, same
+ * element type as Z_new).  This is how the send buffer of the multi-GPU halo exchange gets packed by the kernel
+ * that produces a row instead of by a separate gather pass.  NULL, or row_ptr == NULL: no mirror. */
+typedef struct {
+    const int64_t *row_ptr; /* [rows of the call + 1] */
+    const int32_t *slot;
+    void *buf;
+    int64_t ld;
+} clane_mirror_t;
+
 int clane_abi_version(void);
 const char *clane_last_error(void);
 
@@ -130,26 +141,30 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
  * Calls touch disjoint rows of Z_new and may run on different streams. */
 int clane_spmm_update_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
                           const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
-                          int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, double *delta_partials, void *stream);
+                          int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, const clane_mirror_t *mirror,
+                          double *delta_partials, void *stream);
 int clane_spmm_update_f64(const int64_t *rowptr, const int32_t *colidx, const double *P, int64_t nrows, int64_t row0,
                           const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma, double *Z_new,
-                          int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, double *delta_partials, void *stream);
+                          int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, const clane_mirror_t *mirror,
+                          double *delta_partials, void *stream);
 int clane_spmm_update_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
                            const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
-                           uint16_t *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, double *delta_partials,
+                           uint16_t *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, const clane_mirror_t *mirror,
+                          double *delta_partials,
                            void *stream);
 int clane_spmm_update_long_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, const int32_t *long_rows,
                                int64_t n_long, int32_t waves_per_row, int64_t row0, const float *Z_old, int64_t ldz, const float *X,
-                               int64_t ldx, float gamma, float *Z_new, int64_t ldo, int32_t d, double *delta_partials,
-                               void *stream);
+                               int64_t ldx, float gamma, float *Z_new, int64_t ldo, int32_t d,
+                               const clane_mirror_t *mirror, double *delta_partials, void *stream);
 int clane_spmm_update_long_f64(const int64_t *rowptr, const int32_t *colidx, const double *P,
                                const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const double *Z_old,
                                int64_t ldz, const double *X, int64_t ldx, double gamma, double *Z_new, int64_t ldo,
-                               int32_t d, double *delta_partials, void *stream);
+                               int32_t d, const clane_mirror_t *mirror, double *delta_partials, void *stream);
 int clane_spmm_update_long_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P,
                                 const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const uint16_t *Z_old,
                                 int64_t ldz, const uint16_t *X, int64_t ldx, float gamma, uint16_t *Z_new,
-                                int64_t ldo, int32_t d, double *delta_partials, void *stream);
+                                int64_t ldo, int32_t d, const clane_mirror_t *mirror, double *delta_partials,
+                                void *stream);
 
 /*  clane_spmm_update_split_* : hub rows, each cut into segments of `edges_per_segment` edges (a multiple of 64)
  *                             that are gathered by separate 16-wave workgroups; segment sums go to `slab`
@@ -163,19 +178,19 @@ int clane_spmm_update_split_f32(const int64_t *rowptr, const int32_t *colidx, co
                                 const int64_t *seg_ptr, const int32_t *seg_row, int64_t n_split, int64_t n_segments,
                                 int64_t edges_per_segment, int64_t row0, const float *Z_old, int64_t ldz,
                                 const float *X, int64_t ldx, float gamma, float *Z_new, int64_t ldo, int32_t d,
-                                float *slab, double *delta_partials, void *stream);
+                                float *slab, const clane_mirror_t *mirror, double *delta_partials, void *stream);
 int clane_spmm_update_split_f64(const int64_t *rowptr, const int32_t *colidx, const double *P,
                                 const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,
                                 int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,
                                 const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma,
-                                double *Z_new, int64_t ldo, int32_t d, double *slab, double *delta_partials,
-                                void *stream);
+                                double *Z_new, int64_t ldo, int32_t d, double *slab, const clane_mirror_t *mirror,
+                                double *delta_partials, void *stream);
 int clane_spmm_update_split_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P,
                                  const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,
                                  int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,
                                  const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
-                                 uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, double *delta_partials,
-                                 void *stream);
+                                 uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
+                                 double *delta_partials, void *stream);
 
 /* out[0] = sum of partials[0..n) in a fixed order (bitwise reproducible).  Finishes embedder.py:94 / :60.
  * ws: clane_reduce_ws_len() doubles. */

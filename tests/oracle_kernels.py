@@ -56,7 +56,10 @@ class OracleKernels:
             if rp[r + 1] - rp[r] > min_degree:
                 vals[rp[r]:rp[r + 1]] = torch.softmax(vals[rp[r]:rp[r + 1]], 0)
 
-    def _spmm_rows(self, rowptr, colidx, P, rows_sel, row0, Z_old, X, gamma, Z_new, d):
+    def make_mirror(self, row_ptr, slot, buf):
+        return (row_ptr, slot, buf)
+
+    def _spmm_rows(self, rowptr, colidx, P, rows_sel, row0, Z_old, X, gamma, Z_new, d, mirror=None):
         rp = _np(rowptr)
         acc = P.dtype
         total = 0.0
@@ -69,33 +72,37 @@ class OracleKernels:
             else:
                 new = own.clone()
             Z_new[r, :d] = new
+            if mirror is not None:
+                mp, ms, mb = mirror
+                for s in ms[int(mp[r]):int(mp[r + 1])].tolist():
+                    mb[s, :d] = new
             total += float((new.to(acc) - own.to(acc)).abs().sum())
         return total
 
     def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials,
-                    sinks_untouched=False):
+                    sinks_untouched=False, mirror=None):
         rp = _np(rowptr[:nrows + 1])
         deg = np.diff(rp)
         sel = [r for r in range(nrows) if not (long_threshold > 0 and deg[r] > long_threshold)
                and not (sinks_untouched and deg[r] == 0)]
         n = self.spmm_partials_len(nrows, 0)
         partials[:n] = 0
-        partials[0] = self._spmm_rows(rowptr, colidx, P, sel, row0, Z_old, X, gamma, Z_new, d)
+        partials[0] = self._spmm_rows(rowptr, colidx, P, sel, row0, Z_old, X, gamma, Z_new, d, mirror)
 
     def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row, row0, Z_old, X, gamma, Z_new, d,
-                         partials):
+                         partials, mirror=None):
         assert waves_per_row in (4, 16)
         for i, r in enumerate(long_rows.tolist()):
-            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d)
+            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d, mirror)
 
     def spmm_split_slab_len(self, n_segments, d):
         return n_segments * d
 
     def spmm_update_split(self, rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, row0, Z_old, X,
-                          gamma, Z_new, d, slab, partials):
+                          gamma, Z_new, d, slab, partials, mirror=None):
         assert edges_per_segment % 64 == 0 and seg_row.numel() == int(seg_ptr[-1])
         for i, r in enumerate(split_rows.tolist()):
-            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d)
+            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d, mirror)
 
     def reduce_partials(self, partials, n, ws, out):
         out[0] = partials[:n].sum()

@@ -35,6 +35,17 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert lib.clane_reduce_ws_len() >= 2 * 1024 + 2
 
 
+def test_bound_argument_counts_match_the_header():
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "clane_hip.h").read_text(), flags=re.S)
+    seen = 0
+    for name, params in re.findall(r"\b(clane_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text):
+        params = params.strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert len(_hip.SIGNATURES[name][1]) == n, name
+        seen += 1
+    assert seen == len(_hip.SIGNATURES)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_hip.ClaneHipError, match="no CPU fallback"):
         _hip.load_library(tmp_path / "libclane_hip.so")
@@ -43,7 +54,7 @@ def test_missing_library_fails_loudly(tmp_path):
 def test_argument_validation_reaches_last_error():
     # invalid arguments are rejected on the host before any launch: safe without a GPU
     lib = _hip.load_library()
-    rc = lib.clane_spmm_update_f32(None, None, None, 4, 0, None, 8, None, 8, 0.5, None, 8, 8, 0, 0, None, None)
+    rc = lib.clane_spmm_update_f32(None, None, None, 4, 0, None, 8, None, 8, 0.5, None, 8, 8, 0, 0, None, None, None)
     assert rc == -1 and b"delta_partials" in lib.clane_last_error()
     rc = lib.clane_row_sqnorm_f32(None, 4, 0, 0, None, None)
     assert rc == -1 and b"bad shape" in lib.clane_last_error()

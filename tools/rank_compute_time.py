@@ -34,6 +34,7 @@ ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--natural-order", action="store_true")
 ap.add_argument("--no-split-hubs", action="store_true")
 ap.add_argument("--no-overlap", action="store_true")
+ap.add_argument("--no-fused-pack", action="store_true")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
 gen, V, E, d, dname, gseed, xseed = bench.WORKLOADS[args.workload]
@@ -41,7 +42,8 @@ csr = synth.rmat_csr(V, E, seed=gseed) if gen == "rmat" else synth.powerlaw_csr(
 X = synth.gaussian_X(V, d, seed=xseed).to(bench.DTYPES[dname])
 for W in args.world:
     eng = SweepEngine(csr, X, dev, comm=NullComm(W), chunks=args.chunks, exchange=args.exchange,
-                      hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs, overlap_chunks=not args.no_overlap)
+                      hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs, overlap_chunks=not args.no_overlap,
+                      fused_pack=not args.no_fused_pack)
     eng.build_P()
     for _ in range(5):
         eng.sweep(0.76)
@@ -53,6 +55,7 @@ for W in args.world:
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     print(json.dumps({"world": W, "exchange": args.exchange, "rank0_compute_ms_per_sweep": round(ms, 3),
                       "recv_MB_per_sweep": round(eng.exchange_bytes_per_sweep() / 1e6), "table_rows": eng.part.padded_vertices,
-                      "n_local": eng.part.n_local, "E_loc": eng.E_loc, "hot_rows_first": not args.natural_order}), flush=True)
+                      "n_local": eng.part.n_local, "E_loc": eng.E_loc, "hot_rows_first": not args.natural_order,
+                      "fused_pack": eng.fused_pack, "segment_edges": eng.segment_edges}), flush=True)
     del eng
     torch.cuda.empty_cache()
