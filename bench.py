@@ -80,8 +80,9 @@ def main():
     ap.add_argument("--hub-threshold", type=int, default=None)
     ap.add_argument("--no-split-hubs", action="store_true", help="hub rows by one workgroup each (no segment split)")
     ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
-    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather", "allgather_all"],
-                    help="N > 1: how updated rows travel (see clane_amd/halo.py, partition.py)")
+    ap.add_argument("--exchange", default="columns", choices=["columns", "halo", "allgather", "allgather_all"],
+                    help="N > 1: columns = every GPU holds d/N columns of every row, no exchange per sweep; the others "
+                         "divide the rows and say how updated rows travel (clane_amd/halo.py, partition.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch l1_distance over two [V,d] matrices (known bytes) -- PMC calibration")
@@ -192,6 +193,15 @@ def main():
     if tfile.exists():
         traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}", {}).get(dom, {}).get("bytes_per_launch")
 
+    if world == 1:
+        parallelism = f"1 GPU, {chunks} launch block(s)/sweep"
+    elif eng.columns:
+        parallelism = (f"column split x{world}: every GPU holds the whole graph and columns [{eng.col0}:{eng.col1}) "
+                       f"(rank 0) of X and Z; no exchange per sweep, one scalar all-reduce (RCCL); build_P all-reduces "
+                       f"the {E} partial dot products")
+    else:
+        parallelism = (f"row split x{world}, {chunks} launch block(s)/sweep, exchange={args.exchange} over RCCL per "
+                       f"chunk ({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep) + scalar all-reduce")
     result = {
         "metric": "embedding-update iters/sec (Jacobi sweeps of Z <- X + gamma*P*Z, P frozen)",
         "value": args.steps / elapsed, "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
@@ -200,10 +210,7 @@ def main():
         "config": {"workload": f"{'R-MAT' if gen == 'rmat' else 'power-law'} |V|={V} |E|={E} d={d} {dname}, "
                                f"gamma={args.gamma}, CosineSimilarity "
                                f"(reference mode), seeds {gseed}/{xseed}",
-                   "parallelism": f"row-partition x{world}, {chunks} launch block(s)/sweep"
-                                  + (f", exchange={args.exchange} over RCCL per chunk "
-                                     f"({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep) + scalar "
-                                     f"all-reduce" if world > 1 else "")},
+                   "parallelism": parallelism},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic,
                      "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],

@@ -53,6 +53,7 @@ for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 for _s in ("f32", "f64"):
     SIGNATURES[f"clane_degree_weighted_sums_{_s}"] = (C.c_int, [_p, _p, _p, _i64, _p, _p, _p])
+    SIGNATURES[f"clane_edge_score_finalize_{_s}"] = (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_segment_softmax_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _p, _i64, _p])
     SIGNATURES[f"clane_pair_cosine_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 
@@ -208,6 +209,12 @@ class HipKernels:
             SCORE_FUSE_SOFTMAX if fuse_softmax else 0, long_threshold,
             None if n_long == 0 else _vec(long_rows, torch.int32, "long_rows"), n_long,
             self._stream(Z)), "clane_edge_score")
+
+    def edge_score_finalize(self, rowptr, colidx, nrows: int, row0: int, mode: int, sums2, sq, scores):
+        """RAW_DOT scores summed over the GPUs of a column-split run -> scores of `mode`, in place."""
+        self._check(self._fn("clane_edge_score_finalize", scores.dtype)(
+            _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"), nrows, row0, mode,
+            _ptr(sums2), _ptr(sq), scores.data_ptr(), self._stream(scores)), "clane_edge_score_finalize")
 
     def segment_softmax(self, rowptr, nrows: int, vals, min_degree: int = 0, max_degree: int = 0, long_rows=None):
         n_long = 0 if long_rows is None else long_rows.numel()

@@ -273,4 +273,30 @@ __global__ __launch_bounds__(kBlock) void pair_scale_kernel(A *__restrict__ out,
         out[i] = out[i] / D;
 }
 
+// Column-split runs (each GPU holds d/N columns of every row): clane_edge_score_* in RAW_DOT mode leaves the
+// partial dot products of this GPU's columns; after they are summed over the GPUs this pass divides by the
+// denominators exactly as finalize_score() in edge_score.h does (similarity.py:37).
+template <typename A>
+__global__ __launch_bounds__(kBlock) void edge_score_finalize_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows, int64_t row0, int mode,
+    const double *__restrict__ sums2, const A *__restrict__ sq, A *__restrict__ scores, int rows_per_block) {
+    if (mode == 0) {  // reference: one global denominator
+        const A D = sqrt(A(sums2[0])) * sqrt(A(sums2[1]));
+        const int64_t e_end = rowptr[nrows];
+        for (int64_t e = rowptr[0] + int64_t(blockIdx.x) * kBlock + threadIdx.x; e < e_end;
+             e += int64_t(gridDim.x) * kBlock)
+            scores[e] = scores[e] / D;
+        return;
+    }
+    const int wave = threadIdx.x / kWave, lane = lane_id();
+    const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
+    const int64_t row_end = row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows;
+    for (int64_t r = row_begin + wave; r < row_end; r += kWavesPerBlock) {
+        const int64_t e0 = rowptr[r], e1 = rowptr[r + 1];
+        if (e0 == e1) continue;
+        const A nsrc = sqrt(sq[row0 + r]);
+        for (int64_t e = e0 + lane; e < e1; e += kWave) scores[e] = scores[e] / (nsrc * sqrt(sq[colidx[e]]));
+    }
+}
+
 }  // namespace clane

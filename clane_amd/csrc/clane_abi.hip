@@ -193,6 +193,21 @@ int segment_softmax(const int64_t *rowptr, int64_t nrows, A *vals, int64_t min_d
     return check_launch("segment_softmax");
 }
 
+template <typename A>
+int edge_score_finalize(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, int32_t mode,
+                        const double *sums2, const A *sq, A *scores, void *stream) {
+    REQUIRE(nrows >= 0 && row0 >= 0, "edge_score_finalize: bad shape");
+    REQUIRE(mode == CLANE_SCORE_REFERENCE || mode == CLANE_SCORE_PER_EDGE || mode == CLANE_SCORE_RAW_DOT,
+            "edge_score_finalize: unknown mode %d", mode);
+    if (nrows == 0 || mode == CLANE_SCORE_RAW_DOT) return CLANE_OK;
+    REQUIRE(rowptr && colidx && scores, "edge_score_finalize: null pointer");
+    REQUIRE(mode != CLANE_SCORE_REFERENCE || sums2, "edge_score_finalize: reference mode needs sums2");
+    REQUIRE(mode != CLANE_SCORE_PER_EDGE || sq, "edge_score_finalize: per_edge mode needs sq");
+    edge_score_finalize_kernel<A><<<row_grid(nrows), kBlock, 0, (hipStream_t)stream>>>(
+        rowptr, colidx, nrows, row0, mode, sums2, sq, scores, rows_per_block(nrows));
+    return check_launch("edge_score_finalize");
+}
+
 inline int64_t spmm_main_grid(int64_t nrows) { return row_grid(nrows); }
 
 template <typename T, typename PT>
@@ -382,6 +397,14 @@ CLANE_EDGE_SCORE_WRAPPER(f64, double, double, double)
 CLANE_EDGE_SCORE_WRAPPER(bf16, uint16_t, bf16_t, float)
 #undef CLANE_EDGE_SCORE_WRAPPER
 
+int clane_edge_score_finalize_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
+                                  int32_t mode, const double *sums2, const float *sq, float *scores, void *stream) {
+    return edge_score_finalize<float>(rowptr, colidx, nrows, row0, mode, sums2, sq, scores, stream);
+}
+int clane_edge_score_finalize_f64(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
+                                  int32_t mode, const double *sums2, const double *sq, double *scores, void *stream) {
+    return edge_score_finalize<double>(rowptr, colidx, nrows, row0, mode, sums2, sq, scores, stream);
+}
 int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, int64_t min_degree,
                               int64_t max_degree, const int32_t *long_rows, int64_t n_long, void *stream) {
     return segment_softmax<float>(rowptr, nrows, vals, min_degree, max_degree, long_rows, n_long, stream);

@@ -61,14 +61,29 @@ def _round_up(a: int, b: int) -> int:
     return -(-a // b) * b
 
 
+def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
+    """Columns [c0, c1) of the embedding matrix held by `rank` in a column-split run: contiguous, in whole
+    16-byte packs, as even as the pack count allows (a rank may hold none when d is tiny)."""
+    vec = _hip.VEC_ELEMS[dtype]
+    packs = -(-d // vec)
+    base, rem = divmod(packs, world)
+    p0 = rank * base + min(rank, rem)
+    p1 = p0 + base + (1 if rank < rem else 0)
+    return min(d, p0 * vec), min(d, p1 * vec)
+
+
 class SweepEngine:
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
-                 exchange: str = "halo", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
+                 exchange: str = "columns", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
                  overlap_chunks: bool = True, fused_pack: bool = True):
-        """``exchange`` (N > 1 only): "halo" -- a compact per-rank table, rows sent only to the ranks that read
-        them (halo.py); "allgather" -- full-size Z on every rank, in-place all-gather of the live rows
+        """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
+        "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
+        is independent per column, so a sweep needs no exchange at all (only the delta scalar is all-reduced);
+        build_P all-reduces the partial dot products (E values, once per outer iteration).
+        "halo" -- rows are divided; a compact per-rank table, rows sent only to the ranks that read them (halo.py);
+        "allgather" -- rows divided, full-size Z on every rank, in-place all-gather of the live rows
         (partition.py); "allgather_all" -- the same without the live/quiet split."""
         if X.dim() != 2 or X.shape[0] != csr.num_vertices:
             raise ValueError(f"X must be [V, d] with V={csr.num_vertices}, got {tuple(X.shape)}")
@@ -83,23 +98,33 @@ class SweepEngine:
         self.comm = comm if comm is not None else (TorchComm(process_group) if process_group is not None else None)
         self.world = self.comm.world if self.comm is not None else 1
         rank = self.comm.rank if self.comm is not None else 0
-        if chunks is None:
-            chunks = 1 if self.world == 1 else 4
-        self.V, self.d = csr.num_vertices, int(X.shape[1])
+        if exchange not in ("columns", "halo", "allgather", "allgather_all"):
+            raise ValueError(f"exchange must be 'columns', 'halo', 'allgather' or 'allgather_all', got {exchange!r}")
+        self.exchange = exchange if self.world > 1 else "none"
+        self.columns = self.world > 1 and exchange == "columns"
+        self.V, self.d_full = csr.num_vertices, int(X.shape[1])
+        self.col0, self.col1 = column_slice(self.d_full, X.dtype, self.world, rank) if self.columns else (0, self.d_full)
+        X_all = X
+        if self.columns:
+            X = X[:, self.col0:self.col1]
+            self.ld_max = _round_up(column_slice(self.d_full, X.dtype, self.world, 0)[1], _hip.VEC_ELEMS[X.dtype])
+        self.d = self.col1 - self.col0                 # columns this rank computes (0: an idle rank, d < N packs)
         self.ld = _round_up(self.d, _hip.VEC_ELEMS[X.dtype])
-        if exchange not in ("halo", "allgather", "allgather_all"):
-            raise ValueError(f"exchange must be 'halo', 'allgather' or 'allgather_all', got {exchange!r}")
-        self.halo = self.world > 1 and exchange == "halo"
+        # rows are divided over `row_world` ranks; a column-split rank owns every row
+        row_world, row_rank = (1, 0) if self.columns else (self.world, rank)
+        if chunks is None:
+            chunks = 1 if row_world == 1 else 4
+        self.halo = row_world > 1 and exchange == "halo"
         if self.halo:
             self.part = build_halo_layout(csr, self.world, rank, chunks, shuffle=shuffle is not False, seed=seed,
                                           hot_rows_first=hot_rows_first)
             self.blocks: List[Block] = self.part.blocks
             self.local: LocalCSR = self.part.local
         else:
-            live = csr.live_mask() if (self.world > 1 and exchange == "allgather") else None
-            # one GPU: lay Z out by descending in-degree, so the rows gathered most often are contiguous
-            hot = csr.indeg() if (self.world == 1 and hot_rows_first and not shuffle) else None
-            self.part = RowPartition.create(self.V, self.world, rank, chunks, live_mask=live, shuffle=shuffle,
+            live = csr.live_mask() if (row_world > 1 and exchange == "allgather") else None
+            # all rows on this GPU: lay Z out by descending in-degree, so the rows gathered most often are contiguous
+            hot = csr.indeg() if (row_world == 1 and hot_rows_first and not shuffle) else None
+            self.part = RowPartition.create(self.V, row_world, row_rank, chunks, live_mask=live, shuffle=shuffle,
                                             seed=seed, priority=hot)
             self.blocks = self.part.blocks()
             self.local = localize(csr, self.part)
@@ -193,7 +218,7 @@ class SweepEngine:
         Xl[ok, :self.d] = X[verts[ok]]
         self.X_loc = Xl.to(dev)
         self.quiet_stale = False          # other ranks' quiet rows are only refreshed when Z is read out
-        self.set_Z(X)
+        self.set_Z(X_all)
 
         # ---- scalars / scratch --------------------------------------------------------
         self.ws = torch.zeros(self.k.reduce_ws_len(), dtype=torch.float64, device=dev)
@@ -232,10 +257,10 @@ class SweepEngine:
 
     def set_Z(self, Z: torch.Tensor) -> None:
         """Load a [V, d] matrix (vertex order) into the full-Z buffers."""
-        if tuple(Z.shape) != (self.V, self.d):
-            raise ValueError(f"set_Z: expected {(self.V, self.d)}, got {tuple(Z.shape)}")
+        if tuple(Z.shape) != (self.V, self.d_full):
+            raise ValueError(f"set_Z: expected {(self.V, self.d_full)}, got {tuple(Z.shape)}")
         full = torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype)
-        Zc = Z.detach().to("cpu", self.dtype)
+        Zc = Z.detach()[:, self.col0:self.col1].to("cpu", self.dtype)
         if self.halo:       # own rows, every remote row this rank reads, and the constant (sink) halo rows
             held = self.table_vertex >= 0
             full[held, :self.d] = Zc[self.table_vertex[held]]
@@ -255,6 +280,17 @@ class SweepEngine:
             everyone = torch.empty(self.world * n, self.ld, dtype=self.dtype, device=self.device)
             self.comm.all_gather_into(everyone, self.Zcur[:n].contiguous())
             return everyone.to("cpu")[self.slot, :self.d].clone()
+        if self.columns:    # column slices of every rank, padded to the widest one
+            mine = torch.zeros(self.part.padded_vertices, self.ld_max, dtype=self.dtype, device=self.device)
+            mine[:, :self.ld] = self.Zcur
+            everyone = torch.empty(self.world * mine.shape[0], self.ld_max, dtype=self.dtype, device=self.device)
+            self.comm.all_gather_into(everyone, mine)
+            host = everyone.to("cpu").view(self.world, mine.shape[0], self.ld_max)
+            out = torch.empty(self.V, self.d_full, dtype=self.dtype)
+            for r in range(self.world):
+                c0, c1 = column_slice(self.d_full, self.dtype, self.world, r)
+                out[:, c0:c1] = host[r][self.pos, :c1 - c0]
+            return out
         self._sync_quiet_rows()
         return self.Zcur.to("cpu")[self.pos, :self.d].clone()
 
@@ -274,18 +310,23 @@ class SweepEngine:
         k, part = self.k, self.part
         Z = self.Zcur
         mode = _hip.SCORE_MODES[self.cosine_mode]
+        busy = self.d > 0                   # a column-split rank without columns only joins the collectives
         sq = None
         if self.cosine_mode == "reference":
-            for b in self.blocks:
-                k.row_sqnorm(self._zrows(Z, b), self.d, self.sq_loc[self._rows(b)])
+            if busy:
+                for b in self.blocks:
+                    k.row_sqnorm(self._zrows(Z, b), self.d, self.sq_loc[self._rows(b)])
             k.degree_weighted_sums(self.sq_loc, self.rowptr, self.indeg, part.n_local, self.ws, self.sums2)
-            self._all_reduce(self.sums2)
+            self._all_reduce(self.sums2)    # partial over the owned rows, or over the owned columns: a sum either way
         else:
             if self.sq_full is None:
                 self.sq_full = torch.zeros(part.padded_vertices, dtype=self.acc_dtype, device=self.device)
-            k.row_sqnorm(Z, self.d, self.sq_full)       # every rank holds valid copies of all rows that are read
+            if busy:
+                k.row_sqnorm(Z, self.d, self.sq_full)   # row split: every rank holds valid copies of all rows it reads
+            if self.columns:
+                self._all_reduce(self.sq_full)
             sq = self.sq_full
-        if self.E_loc > 0:
+        if self.E_loc > 0 and not self.columns:
             for i, b in enumerate(self.blocks):
                 rp = self.rowptr[b.local_start:]
                 k.edge_score(rp, self.colidx, b.nrows, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
@@ -294,6 +335,20 @@ class SweepEngine:
                 if self.long_rows[i] is not None and self.max_degree > _hip.FUSED_SOFTMAX_MAX_DEGREE:
                     k.segment_softmax(rp, b.nrows, self.P, _hip.FUSED_SOFTMAX_MAX_DEGREE,
                                       _hip.FUSED_SOFTMAX_MAX_DEGREE, self.long_rows[i])
+        elif self.E_loc > 0:
+            # column split: dot products of the owned columns, summed over the GPUs, then denominators + softmax
+            if busy:
+                for i, b in enumerate(self.blocks):
+                    k.edge_score(self.rowptr[b.local_start:], self.colidx, b.nrows, b.row0, Z, self.d,
+                                 _hip.SCORE_RAW_DOT, None, None, self.P, self.long_threshold, self.long_rows[i])
+            else:
+                self.P.zero_()
+            self._all_reduce(self.P)
+            for i, b in enumerate(self.blocks):
+                rp = self.rowptr[b.local_start:]
+                k.edge_score_finalize(rp, self.colidx, b.nrows, b.row0, mode, self.sums2, sq, self.P)
+                k.segment_softmax(rp, b.nrows, self.P, 0, self.long_threshold if self.long_rows[i] is not None else 0,
+                                  self.long_rows[i])
         self.P_valid = True
 
     def P_global(self) -> torch.Tensor:
@@ -328,6 +383,9 @@ class SweepEngine:
                 po_split = po_hub + (0 if self.hub_rows[i] is None else self.hub_rows[i].numel())
                 # biggest rows first: split hubs, 16-wave rows, (4-wave rows), then the one-(sub-)wave-per-row pass
                 steps.append(("event", i, 0))
+                if self.d == 0:              # column-split rank without columns: nothing to launch, delta stays 0
+                    per_block.append(steps + [("event", i, e) for e in (4, 1, 2, 3)])
+                    continue
                 if self.split_rows[i] is not None:
                     rows_s, seg_ptr, seg_row = self.split_rows[i]
                     steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
@@ -438,6 +496,8 @@ class SweepEngine:
     def exchange_bytes_per_sweep(self) -> int:
         """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""
         s = self.Zcur.element_size()
+        if self.columns:
+            return 0
         if self.halo:
             return self.part.recv_rows_per_sweep() * self.ld * s
         return sum((b.span[1] - b.span[0] - b.nrows) * self.ld * s for b in self.blocks if b.span is not None)
@@ -453,8 +513,9 @@ class SweepEngine:
         if self.snap is None:
             raise RuntimeError("distance_from_snapshot() before snapshot()")
         for i, b in enumerate(self.blocks):
-            self.k.l1_distance(self._zrows(self.Zcur, b), self.snap[self._rows(b)], self.d, self.ws,
-                               self.block_out[i:i + 1])
+            if self.d > 0:
+                self.k.l1_distance(self._zrows(self.Zcur, b), self.snap[self._rows(b)], self.d, self.ws,
+                                   self.block_out[i:i + 1])
         self.k.reduce_partials(self.block_out, len(self.blocks), self.ws, self.delta)
         self._all_reduce(self.delta)
         return float(self.delta.item())

@@ -112,6 +112,14 @@ int clane_edge_score_bf16(const int64_t *rowptr, const int32_t *colidx, int64_t 
                           const float *sq, float *scores, int32_t flags, int64_t long_threshold,
                           const int32_t *long_rows, int64_t n_long, void *stream);
 
+/* ---- K1b (column-split multi-GPU runs): scores holds RAW_DOT results summed over the GPUs (each GPU scored
+ * its own columns); divide them by the denominators of `mode` exactly as clane_edge_score_* would have
+ * (similarity.py:37).  sums2 / sq as for clane_edge_score_*, already summed over the GPUs.  RAW_DOT: no-op. */
+int clane_edge_score_finalize_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
+                                  int32_t mode, const double *sums2, const float *sq, float *scores, void *stream);
+int clane_edge_score_finalize_f64(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
+                                  int32_t mode, const double *sums2, const double *sq, double *scores, void *stream);
+
 /* ---- K2: in-place softmax of vals within each CSR row.  Replaces the per-row boolean-mask
  * loop of graph.py:122-123.  Rows with min_degree < deg <= max_degree (max_degree 0 = no upper
  * limit) are normalised by one wave each; the rows listed in `long_rows` (deg > min_degree) by one

@@ -50,6 +50,17 @@ class OracleKernels:
                 if dg > 0 and (dg <= 64 or long_threshold == 0 or dg <= long_threshold):
                     scores[rp[r]:rp[r + 1]] = torch.softmax(scores[rp[r]:rp[r + 1]], 0)
 
+    def edge_score_finalize(self, rowptr, colidx, nrows, row0, mode, sums2, sq, scores):
+        rp = _np(rowptr[:nrows + 1])
+        if rp[-1] == rp[0] or mode == 2:
+            return
+        view = scores[rp[0]:rp[-1]]
+        if mode == 0:
+            view /= sums2[0].to(scores.dtype).sqrt() * sums2[1].to(scores.dtype).sqrt()
+        else:
+            rows = torch.from_numpy(np.repeat(np.arange(nrows), np.diff(rp))) + row0
+            view /= sq[rows].sqrt() * sq[colidx[rp[0]:rp[-1]].long()].sqrt()
+
     def segment_softmax(self, rowptr, nrows, vals, min_degree=0, max_degree=0, long_rows=None):
         rp = _np(rowptr[:nrows + 1])
         for r in range(nrows):

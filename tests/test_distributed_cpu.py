@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: two `gloo` ranks run the row-partitioned SweepEngine (chunk-major layout,
-in-place all-gather per chunk, scalar all-reduce) with the oracle-backed test double as kernels,
-and every rank must reproduce the single-process oracle."""
+"""N > 1 path on CPU: `gloo` ranks run the SweepEngine in each of its multi-GPU divisions -- column split (the
+default: no exchange per sweep, partial dot products all-reduced in build_P) and the row splits (halo table /
+chunk-major in-place all-gather per chunk) -- with the oracle-backed test double as kernels, and every rank
+must reproduce the single-process oracle."""
 import os
 import socket
 import sys
@@ -47,7 +48,15 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         if exchange == "allgather":                                        # live / quiet split
             n_quiet = int((~g.csr.live_mask()).sum())
             assert eng.part.quiet_per_rank == -(-n_quiet // world)
-        assert 0 < eng.exchange_bytes_per_sweep() <= full + 4 * eng.ld * 4 * world
+        if exchange == "columns":
+            from clane_amd.engine import column_slice
+            assert eng.columns and eng.exchange_bytes_per_sweep() == 0 and eng.part.n_local >= len(g)
+            assert (eng.col0, eng.col1) == column_slice(g.X.shape[1], g.X.dtype, world, rank)
+            widths = [None] * world
+            dist.all_gather_object(widths, eng.d)
+            assert sum(widths) == g.X.shape[1]                                # every column exactly once
+        else:
+            assert 0 < eng.exchange_bytes_per_sweep() <= full + 4 * eng.ld * 4 * world
 
         # build_P: every rank assembles the full P in the reference's (row, col) order
         P = g.build_P(CosineSimilarity())
@@ -85,7 +94,7 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["halo", "allgather", "allgather_all"])
+@pytest.mark.parametrize("exchange", ["columns", "halo", "allgather", "allgather_all"])
 @pytest.mark.parametrize("name,chunks", [("g5_symkarate_d16_g0.76.npz", 1), ("g5_symkarate_d16_g0.76.npz", 3),
                                          ("g4_karate_d2.npz", 2)])
 def test_two_rank_gloo_matches_reference(tmp_path, name, chunks, exchange):
@@ -94,9 +103,11 @@ def test_two_rank_gloo_matches_reference(tmp_path, name, chunks, exchange):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
-def test_three_rank_gloo_halo(tmp_path):
-    """Odd world size: every (source, destination, chunk) list of the halo exchange is exercised."""
+@pytest.mark.parametrize("exchange", ["halo", "columns"])
+def test_three_rank_gloo(tmp_path, exchange):
+    """Odd world size: every (source, destination, chunk) list of the halo exchange is exercised; the column
+    split is uneven (4 packs of d=16 over 3 ranks)."""
     world = 3
-    mp.spawn(_worker, args=(world, _free_port(), 2, "g5_symkarate_d16_g0.5.npz", str(tmp_path), "halo"), nprocs=world,
+    mp.spawn(_worker, args=(world, _free_port(), 2, "g5_symkarate_d16_g0.5.npz", str(tmp_path), exchange), nprocs=world,
              join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))

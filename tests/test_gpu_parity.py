@@ -139,12 +139,20 @@ def test_edge_score_and_softmax_stages(dev, k, dtype, d, pad):
     assert float(sums2[0].sqrt() * sums2[1].sqrt()) == pytest.approx(D, rel=1e-6)
     k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_REFERENCE, sums2, None, scores)
     assert rel(scores, dots / D) < max(tol, 3e-7)
+    # K1b (column-split runs): raw dots, denominators applied afterwards -- the same arithmetic, bit for bit
+    late = torch.empty_like(scores)
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, late)
+    k.edge_score_finalize(rowptr, colidx, V, 0, _hip.SCORE_REFERENCE, sums2, None, late)
+    assert torch.equal(late, scores)
     k.segment_softmax(rowptr, V, scores)
     P_ref = O.build_P_values(csr.rowptr, csr.colidx, Zf.double())
     assert rel(scores, P_ref) < max(tol, 3e-7)
 
     # per-edge (true cosine) mode
     k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_PER_EDGE, None, sq, scores)
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, late)
+    k.edge_score_finalize(rowptr, colidx, V, 0, _hip.SCORE_PER_EDGE, None, sq, late)
+    assert torch.equal(late, scores)
     k.segment_softmax(rowptr, V, scores)
     assert rel(scores, O.build_P_values(csr.rowptr, csr.colidx, Zf.double(), mode="per_edge")) < max(tol, 1e-6)
 
@@ -457,17 +465,19 @@ def test_powerlaw_generator_and_bf16_sweep(dev):
     assert O.rel_l2(eng.get_Z().float(), Z1) < 8e-3 and delta == pytest.approx(float(d_or), rel=2e-2)
 
 
-@pytest.mark.parametrize("exchange,world,fused", [("halo", 4, True), ("halo", 3, True), ("halo", 4, False),
-                                                  ("allgather", 4, True)])
-def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, fused):
-    """W ranks as threads of this process, all on cuda:0, collectives through tests/thread_comm.py: the halo /
-    all-gather layouts, chunking, relabelled CSR and send-buffer packing run with the real HIP kernels."""
+@pytest.mark.parametrize("exchange,world,fused,d", [
+    ("columns", 4, True, 256), ("columns", 3, True, 256), ("columns", 4, True, 6), ("columns", 2, True, 100),
+    ("halo", 4, True, 256), ("halo", 3, True, 256), ("halo", 4, False, 256), ("allgather", 4, True, 256)])
+def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, fused, d):
+    """W ranks as threads of this process, all on cuda:0, collectives through tests/thread_comm.py: the column
+    split (even, uneven 64 packs / 3, ranks without columns at d=6, ragged d=100) and the halo / all-gather row
+    layouts, chunking, relabelled CSR and send-buffer packing run with the real HIP kernels."""
     import threading
     from .thread_comm import ThreadWorld
-    V, E, d, gamma = 20_000, 300_000, 256, 0.76
+    V, E, gamma = 20_000, 300_000, 0.76
     csr = synth.rmat_csr(V, E, seed=9)
     X = synth.gaussian_X(V, d, seed=10)
-    P_or = O.build_P_values(csr.rowptr, csr.colidx, X)
+    P_or = O.build_P_values(csr.rowptr, csr.colidx, X, mode="per_edge" if d == 100 else "reference")
     Z_or, deltas_or = X.clone(), []
     Ps = O.as_sparse(csr.rowptr, csr.colidx, P_or)
     for _ in range(3):
@@ -479,7 +489,7 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
         try:
             with torch.cuda.device(dev):
                 eng = SweepEngine(csr, X, dev, comm=shared.comm(rank), chunks=3, exchange=exchange, seed=4,
-                                  fused_pack=fused)
+                                  fused_pack=fused, cosine_mode=("per_edge" if d == 100 else "reference"))
                 assert any(m is not None for m in eng.mirrors) == (fused and exchange == "halo")
                 eng.build_P()
                 P_local = eng.P[:eng.E_loc].cpu()
@@ -501,7 +511,7 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
         for a, b in zip(deltas, deltas_or):
             assert a == pytest.approx(b, rel=1e-4)
         P_all[torch.from_numpy(origin)] = P_local
-        assert 0 < nbytes < (world - 1) * -(-V // world) * d * 4 + 1
+        assert (nbytes == 0) if exchange == "columns" else (0 < nbytes < (world - 1) * -(-V // world) * d * 4 + 1)
     assert rel(P_all, P_or) < 1e-5
     if exchange == "halo":                                          # the point of the halo: fewer bytes than all rows
         assert results[0][4] < 0.8 * (world - 1) * (V // world) * d * 4
