@@ -5,10 +5,11 @@
 
 One "step" = one Jacobi sweep  Z <- X + gamma * P Z  over the whole graph, P frozen: the K3
 kernels, the deterministic L1-delta reduction, the host read-back of that scalar (the
-reference decides after every sweep, embedder.py:94-105) and, for N > 1, the all-gather of
-the updated rows + the scalar all-reduce.  Inputs are resident in HBM before the timed region.
-N > 1 is launched by torchrun (one rank per GPU, RCCL); rows are partitioned over the ranks
-with the graph fixed, so scaling is STRONG.  Rank 0 prints one JSON line.
+reference decides after every sweep, embedder.py:94-105) and, for N > 1, the all-reduce of that
+scalar.  Inputs are resident in HBM before the timed region.
+N > 1 is launched by torchrun (one rank per GPU, RCCL).  The graph is fixed and divided, so scaling
+is STRONG: by default every GPU sweeps d/N columns of all rows (no exchange per sweep, DESIGN.md 6.1);
+--exchange halo|allgather divides the rows instead.  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
@@ -83,6 +84,10 @@ def main():
     ap.add_argument("--exchange", default="columns", choices=["columns", "halo", "allgather", "allgather_all"],
                     help="N > 1: columns = every GPU holds d/N columns of every row, no exchange per sweep; the others "
                          "divide the rows and say how updated rows travel (clane_amd/halo.py, partition.py)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (RCCL refuses that: use --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch l1_distance over two [V,d] matrices (known bytes) -- PMC calibration")
@@ -97,11 +102,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
-    dev = _hip.require_gpu(f"cuda:{local_rank}")
+    dev = _hip.require_gpu("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     pg = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         pg = dist.group.WORLD
 
     gen, V, E, d, dname, gseed, xseed = WORKLOADS[args.workload]
@@ -144,10 +152,11 @@ def main():
         eng.snapshot()
         eng.distance_from_snapshot()
     Z1 = None
-    for i in range(args.warmup):
+    if world == 1 and not args.no_cpu_baseline:     # the sweep the oracle is checked against (Z = X before it)
         eng.sweep(args.gamma)
-        if i == 0 and world == 1 and not args.no_cpu_baseline:
-            Z1 = eng.get_Z()
+        Z1 = eng.get_Z()
+    for _ in range(args.warmup):
+        eng.sweep(args.gamma)
 
     def barrier():
         if world > 1:
