@@ -72,6 +72,19 @@ def embedding(args):
 
     embedder_cls = IterativeEmbedder if hasattr(similarity_measure, 'parameters') else Embedder
     extra = {"num_workers": args.num_workers} if embedder_cls is IterativeEmbedder else {}
+    if args.init_Z is not None:                     # resume: start from saved embeddings instead of Z = X
+        Z0 = torch.from_numpy(np.load(args.init_Z))
+        if tuple(Z0.shape) != tuple(g.X.shape):
+            raise ValueError(f"--init_Z holds shape {tuple(Z0.shape)}, the graph needs {tuple(g.X.shape)}")
+        g.set_Z(Z0.to(g.X.dtype))
+    if args.save_history and embedder_cls is Embedder:
+        # write output_root/{outer}/Z_{sweep}.npy (the reference's layout, __main__.py:73-86) WHILE the sweeps run
+        def write_sweep(outer, sweep, Z):
+            if rank == 0:
+                folder = args.output_root.joinpath(f'{outer}')
+                folder.mkdir(parents=True, exist_ok=True)
+                np.save(folder.joinpath(f'Z_{sweep}.npy'), _to_numpy(Z))
+        extra["history_sink"] = write_sweep
     embedder = embedder_cls(graph=g, similarity_measure=similarity_measure, device=device,
                             save_history=args.save_history, **extra, **hparams["embedder"])
     if rank != 0:
@@ -85,11 +98,6 @@ def embedding(args):
     if not args.output_root.exists():
         args.output_root.mkdir(parents=True, exist_ok=True)
 
-    if args.save_history:
-        for outer, history_Z in enumerate(embedder.history["Z"]):
-            args.output_root.joinpath(f'{outer}').mkdir(parents=True, exist_ok=True)
-            for sweep, Z in enumerate(history_Z):
-                np.save(args.output_root.joinpath(f'{outer}/Z_{sweep}.npy'), _to_numpy(Z))
     np.save(args.output_root.joinpath('Z.npy'), _to_numpy(final_Z))
 
     say(f"The embeddings are stored in {args.output_root.joinpath('Z.npy').absolute()}.")
@@ -110,6 +118,9 @@ def get_parser():
     parser.add_argument("--save_history", action='store_true',
                         help="If true, it saves the embeddings for every iteration.")
     parser.add_argument("--num_workers", type=int, default=0)
+    parser.add_argument("--init_Z", type=Path, default=None,
+                        help="(extension) .npy of shape [V, d]: start from these embeddings instead of the content "
+                             "embeddings, e.g. the Z.npy of an interrupted run.")
     parser.add_argument("--gpu", action='store_true')
     return parser
 

@@ -8,8 +8,11 @@ reads back one scalar per sweep to drive exactly the reference's stopping rule.
 """
 from __future__ import annotations
 
+import collections
 import math
-from typing import Optional
+import queue
+import threading
+from typing import Callable, Optional
 
 import torch
 
@@ -31,6 +34,7 @@ class Embedder(object):
         save_history:       bool = False,
         verbose:            bool = True,
         max_sweeps:         Optional[int] = None,
+        history_sink:       Optional[Callable[[int, int, torch.Tensor], None]] = None,
     ) -> None:
         self.graph = graph
         self.similarity_measure = similarity_measure
@@ -53,6 +57,10 @@ class Embedder(object):
         self.max_sweeps = max_sweeps          # safety cap per propagate(); None = reference (uncapped)
         self.sweep_counts = []
         self.outer_deltas = []
+        # history_sink(outer, sweep, Z): with save_history, every sweep's embeddings are handed to it from a
+        # writer thread, in order, instead of being kept in `history["Z"]` -- the copy to the host overlaps the
+        # following sweeps (SweepEngine.stage_Z).  Call flush_history() (iterate() does) before relying on it.
+        self._writer = _HistoryWriter(history_sink) if (save_history and history_sink is not None) else None
 
     class Tolerence:
         """Countdown of consecutive non-improving steps (reference embedder.py:45-54)."""
@@ -97,6 +105,12 @@ class Embedder(object):
 
             if self.tolerences['global'].value == 0:  # embeddings are no more updated
                 break
+        self.flush_history()
+
+    def flush_history(self) -> None:
+        """Wait until the history sink has received everything handed to it so far."""
+        if self._writer is not None:
+            self._writer.flush()
 
     @torch.no_grad()
     def propagate(self):
@@ -107,13 +121,25 @@ class Embedder(object):
         minimum_amount_updated = math.inf
         self.tolerences['propagation'].reset()
         history_Z = []
+        in_flight = collections.deque()         # StagedZ not yet resolved (save_history without a sink)
+        outer = len(self.sweep_counts)
         n_sweeps = 0
 
         while True:
             amount_updated = engine.sweep(self.gamma)
             n_sweeps += 1
             if self.save_history:
-                history_Z.append(engine.get_Z())
+                staged = engine.stage_Z() if hasattr(engine, "stage_Z") else None
+                if staged is None:
+                    history_Z.append(engine.get_Z())
+                elif self._writer is not None:
+                    self._writer.submit(outer, n_sweeps - 1, staged)
+                else:                           # reference behaviour: keep every Z; resolve copies as slots run out
+                    in_flight.append((len(history_Z), staged))
+                    history_Z.append(None)
+                    while len(in_flight) >= engine.STAGE_SLOTS:
+                        i, st = in_flight.popleft()
+                        history_Z[i] = st.result()
 
             if minimum_amount_updated > amount_updated:
                 self.tolerences['propagation'].reset()
@@ -125,9 +151,43 @@ class Embedder(object):
                 print(f"{amount_updated:.4f} {self.tolerences['propagation'].value}")
             if self.tolerences['propagation'].value == 0 or (self.max_sweeps and n_sweeps >= self.max_sweeps):
                 if self.save_history:
+                    for i, st in in_flight:
+                        history_Z[i] = st.result()
                     self.history['Z'].append(history_Z)
                 self.sweep_counts.append(n_sweeps)
                 return
+
+
+class _HistoryWriter:
+    """One thread that resolves staged copies in order and hands them to the sink."""
+
+    def __init__(self, sink):
+        self.sink, self.q, self.error = sink, queue.Queue(), None
+        self.thread = threading.Thread(target=self._run, name="clane-history", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            outer, sweep, staged = self.q.get()
+            try:
+                Z = staged.result()             # always resolve: frees the staging slot even after an error
+                if self.error is None:
+                    self.sink(outer, sweep, Z)
+            except BaseException as exc:        # surfaced by flush()
+                self.error = self.error or exc
+            finally:
+                self.q.task_done()
+
+    def submit(self, outer, sweep, staged):
+        if self.error is not None:
+            self.flush()
+        self.q.put((outer, sweep, staged))
+
+    def flush(self):
+        self.q.join()
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise RuntimeError("history sink failed") from err
 
 
 class IterativeEmbedder(Embedder):

@@ -22,6 +22,7 @@ scalar delta is all-reduced.  On one GPU no collective is issued.
 from __future__ import annotations
 
 import contextlib
+import threading
 from typing import List, Optional
 
 import numpy as np
@@ -72,7 +73,26 @@ def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
     return min(d, p0 * vec), min(d, p1 * vec)
 
 
+class StagedZ:
+    """The embeddings of one moment on their way to the host (``SweepEngine.stage_Z``): the sweeps go on while
+    the copy drains over PCIe; ``result()`` waits for it and returns a fresh ``[V, d]`` CPU tensor in vertex order."""
+
+    def __init__(self, engine=None, slot=None, ready: Optional[torch.Tensor] = None):
+        self._engine, self._slot, self._ready = engine, slot, ready
+
+    def result(self) -> torch.Tensor:
+        if self._ready is None:
+            eng, slot = self._engine, self._slot
+            slot["done"].synchronize()
+            self._ready = slot["host"][eng.pos, :eng.d].clone()
+            eng._release_stage_slot(slot)
+            self._engine = self._slot = None
+        return self._ready
+
+
 class SweepEngine:
+    STAGE_SLOTS = 3          # copies of Z that may be in flight to the host at once (stage_Z)
+
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
@@ -237,6 +257,7 @@ class SweepEngine:
         if overlap_chunks and len(self.blocks) > 1 and self.device.type == "cuda" and hasattr(self.k, "bind"):
             self.side_streams = [torch.cuda.Stream(self.device) for _ in range(2)]
         self.time_kernels = False
+        self._stage_cv, self._stage_free = threading.Condition(), None      # stage_Z: slots made on first use
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
 
     def _make_mirror(self, row_ptr, slot, buf):
@@ -293,6 +314,42 @@ class SweepEngine:
             return out
         self._sync_quiet_rows()
         return self.Zcur.to("cpu")[self.pos, :self.d].clone()
+
+    def stage_Z(self) -> StagedZ:
+        """Start copying the current embeddings to the host WITHOUT stalling the sweeps (``--save_history`` at
+        scale): a device-to-device copy on the sweep stream (the ping-pong buffer is overwritten two
+        sweeps later, long before 2 GB have crossed PCIe), then an asynchronous D2H into pinned memory on a copy
+        stream.  At most STAGE_SLOTS copies are in flight; with none free this call waits for ``result()`` of an
+        earlier one (possibly on another thread).  Multi-GPU runs gather synchronously (collective)."""
+        if self.world > 1 or self.device.type != "cuda":
+            return StagedZ(ready=self.get_Z())
+        with self._stage_cv:
+            if self._stage_free is None:
+                self._stage_free, self._stage_made = [], 0
+                self._copy_stream = torch.cuda.Stream(self.device)
+            while not self._stage_free and self._stage_made >= self.STAGE_SLOTS:
+                self._stage_cv.wait()
+            if self._stage_free:
+                slot = self._stage_free.pop()
+            else:
+                self._stage_made += 1
+                slot = {"dev": torch.empty_like(self.Zcur),
+                        "host": torch.empty(self.Zcur.shape, dtype=self.dtype, pin_memory=True),
+                        "done": torch.cuda.Event()}
+        main = torch.cuda.current_stream(self.device)
+        slot["dev"].copy_(self.Zcur)
+        copied = torch.cuda.Event()
+        copied.record(main)
+        self._copy_stream.wait_event(copied)
+        with torch.cuda.stream(self._copy_stream):
+            slot["host"].copy_(slot["dev"], non_blocking=True)
+            slot["done"].record(self._copy_stream)
+        return StagedZ(self, slot)
+
+    def _release_stage_slot(self, slot) -> None:
+        with self._stage_cv:
+            self._stage_free.append(slot)
+            self._stage_cv.notify()
 
     def _sync_quiet_rows(self) -> None:
         """Quiet rows (no out-edges, or never read) are not exchanged during sweeps; bring the other

@@ -242,6 +242,25 @@ class Graph(torch.utils.data.Dataset):
         self._engine = None
         self._raw_order = {}
 
+    @classmethod
+    def from_csr(cls, csr: HostCSR, X: torch.Tensor, vertex_ids=None) -> "Graph":
+        """A Graph over an adjacency that already is a CSR in memory (synthetic inputs of bench.py and the
+        tests; extension -- upstream only reads ``data_root``).  ``E`` then lists the CSR's edges."""
+        if X.dim() != 2 or X.shape[0] != csr.num_vertices:
+            raise ValueError(f"content embeddings have shape {tuple(X.shape)}, expected [{csr.num_vertices}, d]")
+        g = cls.__new__(cls)
+        torch.utils.data.Dataset.__init__(g)
+        n = csr.num_vertices
+        g.d, g.X, g.csr = int(X.shape[1]), X, csr
+        g.vertex_ids = vertex_ids if vertex_ids is not None else _LazySeq(n, str)
+        g._raw_src = np.repeat(np.arange(n, dtype=np.int64), csr.outdeg())
+        g._raw_dst = csr.colidx.astype(np.int64)
+        g.V = _LazySeq(n, lambda i: Vertex(g, i, g.vertex_ids[i]))
+        g.E = _LazySeq(csr.num_edges, lambda k: Edge(g.V[int(g._raw_src[k])], g.V[int(g._raw_dst[k])]))
+        g.dispense_pair = False
+        g._Z_host, g._dirty, g._engine, g._raw_order = None, False, None, {}
+        return g
+
     # ---- Dataset protocol ---------------------------------------------------------------
     def __len__(self):
         return len(self.vertex_ids)

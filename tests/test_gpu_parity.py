@@ -335,10 +335,34 @@ def test_cli_end_to_end(tmp_path, karate_root, monkeypatch):
         assert Z.shape == (34, 2) and np.load(out / "0" / "Z_0.npy").shape == (34, 2)   # reference test_cli.py:31-36
         listing = sorted(str(p.relative_to(out)) for p in out.rglob("*.npy"))
         assert "Z.npy" in listing and "0/Z_0.npy" in listing
+        # streamed while the sweeps ran: every sweep of every outer round is there, the last one is the result
+        rounds = sorted(int(p.name) for p in out.iterdir() if p.is_dir())
+        assert rounds == list(range(len(rounds))) and len(rounds) >= 3
+        last = max((out / str(rounds[-1])).glob("Z_*.npy"), key=lambda p: int(p.stem.split("_")[1]))
+        np.testing.assert_array_equal(np.load(last), Z)
         text = buf.getvalue()
         for line in ("[Embedding]", "Graph Loaded.", " - 34 vertices", " - 78 edges", "Saving the results."):
             assert line in text
         assert set(gold["parser_dests"]) <= {a.dest for a in get_parser()._actions}
+    # --init_Z (extension): resuming from the converged embeddings (content stored in C.npy this time, so both
+    # runs see the same X) reproduces them and stops after the minimum number of rounds
+    k4 = load_golden("g4_karate_d2.npz")
+    kc = load_golden("g2_karate_csr.npz")
+    root_c = write_data_root(tmp_path / "with_content", kc["vertex_ids"], kc["edge_src"], kc["edge_dst"], k4["X"])
+    out1, out2 = tmp_path / "first", tmp_path / "resumed"
+    with contextlib.redirect_stdout(io.StringIO()):
+        embedding(get_parser().parse_args(["--data_root", str(root_c), "--output_root", str(out1), "--config_file",
+                                           str(cfg), "--save_history"]))
+        embedding(get_parser().parse_args(["--data_root", str(root_c), "--output_root", str(out2), "--config_file",
+                                           str(cfg), "--init_Z", str(out1 / "Z.npy"), "--save_history"]))
+    Z1 = np.load(out1 / "Z.npy")
+    assert np.linalg.norm(Z1 - k4["Z_final"]) <= 1e-5 * np.linalg.norm(Z1)
+    assert np.linalg.norm(np.load(out2 / "Z.npy") - Z1) <= 1e-5 * np.linalg.norm(Z1)
+    assert len([p for p in out2.iterdir() if p.is_dir()]) <= len([p for p in out1.iterdir() if p.is_dir()])
+    with pytest.raises(ValueError, match="--init_Z"):
+        np.save(tmp_path / "wrong.npy", np.zeros((3, 2), dtype=np.float32))
+        embedding(get_parser().parse_args(["--data_root", str(karate_root), "--output_root", str(out2), "--config_file",
+                                           str(cfg), "--init_Z", str(tmp_path / "wrong.npy")]))
     with pytest.raises(FileNotFoundError):
         embedding(get_parser().parse_args(["--data_root", str(karate_root), "--output_root", str(out),
                                            "--config_file", str(tmp_path / "missing.yaml")]))
@@ -631,6 +655,37 @@ def test_spmm_mirror_packs_send_buffer(dev, k, dtype, d, pad):
         k.spmm_update(rowptr, colidx, P, V, 0, Zo, Xd, gamma, Zn, d, T, partials, mirror=bad)
 
 
+def test_stage_Z_overlaps_sweeps_and_keeps_each_moment(dev):
+    """stage_Z(): copies taken between sweeps (more of them than staging slots, resolved late and from another
+    thread) hold exactly the embeddings of their moment, although the ping-pong buffers were overwritten since."""
+    import threading
+    V, E, d = 50_000, 600_000, 64
+    csr = synth.rmat_csr(V, E, seed=11)
+    X = synth.gaussian_X(V, d, seed=12)
+    eng = SweepEngine(csr, X, dev)
+    eng.build_P()
+    truth, staged = [], []
+    for _ in range(eng.STAGE_SLOTS):                   # as many as there are slots without resolving any
+        eng.sweep(0.76)
+        staged.append(eng.stage_Z())
+        truth.append(None)
+    eng2 = SweepEngine(csr, X, dev)
+    eng2.build_P()
+    for i in range(eng.STAGE_SLOTS):
+        eng2.sweep(0.76)
+        truth[i] = eng2.get_Z()
+    got = [None] * len(staged)
+    resolver = threading.Thread(target=lambda: [got.__setitem__(i, st.result()) for i, st in enumerate(staged)])
+    resolver.start()
+    eng.sweep(0.76)
+    late = eng.stage_Z()                                # waits for a slot the other thread frees
+    resolver.join(timeout=60)
+    for a, b in zip(got, truth):
+        assert torch.equal(a, b)
+    eng2.sweep(0.76)
+    assert torch.equal(late.result(), eng2.get_Z()) and late.result() is late.result()
+
+
 def test_custom_similarity_plugin_on_gpu(tmp_path):
     """A user-defined similarity callable (plugin protocol, reference __main__.py:39-48 / graph.py:121): called
     once with the gathered GPU batches, normalised by the HIP segmented softmax."""
@@ -685,10 +740,7 @@ def test_config2_full_iterate_vs_c_oracle(tmp_path):
         if outer_tol == 0 or len(sweeps_or) >= 40:
             break
     # product path
-    g = Graph.__new__(Graph)
-    torch.utils.data.Dataset.__init__(g)
-    g.d, g.vertex_ids, g.X, g.csr = d, None, X, csr
-    g._Z_host, g._dirty, g._engine, g._raw_order = None, False, None, {}
+    g = Graph.from_csr(csr, X)
     emb = Embedder(g, CosineSimilarity(), torch.device("cuda"), gamma=gamma, tolerence=tol, verbose=False,
                    max_sweeps=400)
     emb.iterate()

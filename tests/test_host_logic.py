@@ -241,6 +241,35 @@ def test_embedder_iterate_matches_reference_final_Z(tmp_path, name):
     assert emb.minimum_amount_updated_Z == min(emb.outer_deltas)
 
 
+def test_history_sink_receives_every_sweep_in_order(tmp_path):
+    """Embedder(history_sink=...): the same embeddings as history["Z"], streamed (outer, sweep, Z) in order from
+    the writer thread and not retained; a failing sink surfaces at flush."""
+    gold, g = graph_from_golden(tmp_path, "g5_symkarate_d16_g0.5.npz")
+    attach_cpu_engine(g)
+    kept = Embedder(g, CosineSimilarity(), torch.device("cpu"), gamma=0.5, tolerence=3, save_history=True,
+                    verbose=False)
+    kept.iterate()
+    gold, g2 = graph_from_golden(tmp_path / "b", "g5_symkarate_d16_g0.5.npz")
+    attach_cpu_engine(g2)
+    got = []
+    emb = Embedder(g2, CosineSimilarity(), torch.device("cpu"), gamma=0.5, tolerence=3, save_history=True,
+                   verbose=False, history_sink=lambda o, s, Z: got.append((o, s, Z)))
+    emb.iterate()
+    assert emb.sweep_counts == kept.sweep_counts and emb.history["Z"] == [[] for _ in emb.sweep_counts]
+    assert [(o, s) for o, s, _ in got] == [(o, s) for o, n in enumerate(kept.sweep_counts) for s in range(n)]
+    for o, s, Z in got:
+        assert torch.equal(Z, kept.history["Z"][o][s])
+
+    def broken(o, s, Z):
+        raise OSError("disk full")
+    gold, g3 = graph_from_golden(tmp_path / "c", "g7_readme5.npz")
+    attach_cpu_engine(g3)
+    emb = Embedder(g3, CosineSimilarity(), torch.device("cpu"), tolerence=2, save_history=True, verbose=False,
+                   history_sink=broken)
+    with pytest.raises(RuntimeError, match="history sink failed"):
+        emb.iterate()
+
+
 def test_embedder_prints_delta_and_tolerance_per_sweep(tmp_path):
     gold, g = graph_from_golden(tmp_path, "g7_readme5.npz")
     attach_cpu_engine(g)
