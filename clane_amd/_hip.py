@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from pathlib import Path
 from typing import Optional
 
@@ -140,13 +141,14 @@ class HipKernels:
 
     def __init__(self, lib: Optional[C.CDLL] = None):
         self.lib = lib if lib is not None else load_library()
-        self._recording = None
+        self._tls = threading.local()          # bind() records per thread: one instance serves every thread
 
     # -- helpers ------------------------------------------------------------------------
     def _invoke(self, fn, what: str, *cargs):
         """Call an ABI function now -- or, inside bind(), only record the bound call."""
-        if self._recording is not None:
-            self._recording.append((fn, cargs, what))
+        rec = getattr(self._tls, "recording", None)
+        if rec is not None:
+            rec.append((fn, cargs, what))
         else:
             self._check(fn(*cargs), what)
 
@@ -154,12 +156,12 @@ class HipKernels:
         """The ABI call `method(*args, **kwargs)` would make, pre-marshalled: returns a zero-argument callable.
         Pointers, sizes and the CURRENT stream are captured now, so a sweep can replay a flat list of such
         calls without re-slicing tensors or re-checking arguments (host time per launch: ~3 us instead of ~25)."""
-        self._recording = []
+        self._tls.recording = []
         try:
             getattr(self, method)(*args, **kwargs)
-            (fn, cargs, what), = self._recording
+            (fn, cargs, what), = self._tls.recording
         finally:
-            self._recording = None
+            self._tls.recording = None
         check = self._check
         return lambda: check(fn(*cargs), what)
 

@@ -291,14 +291,17 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     if (lane == 0) partials[blockIdx.x] = dsum;
 }
 
-// Rows that need fewer than 64 lanes (LPR < 64; e.g. d=128 bf16: 16 lanes x 16 B): one SUB-WAVE per
-// destination row, so a wave keeps 64/LPR rows in flight and nothing has to be folded across
-// sub-waves.  (Splitting ONE short row's edges over the sub-waves, as the long-row kernel does,
-// leaves most lanes of a 5-edge row idle: 3.5 TB/s on the 10M-vertex power-law graph.)
-// Same workgroup structure as spmm_update_kernel: consecutive rows, rowptr slice in LDS, waves
-// claim GROUPS of 64/LPR consecutive rows, per-row deltas summed in row order by the last wave.
-// Gathers are branch-free (see accumulate_chunk): a sub-wave that has run out of edges re-reads
-// its last neighbour row (an L1 hit) with weight zero until the longest row of the group is done.
+// Rows that need fewer than 64 lanes (LPR < 64; e.g. d=128 bf16: 16 lanes x 16 B, or the column slices of a
+// multi-GPU run): one SUB-WAVE per destination row, so a wave keeps 64/LPR rows in flight and nothing has to
+// be folded across sub-waves.  (Splitting ONE short row's edges over the sub-waves, as the long-row kernel
+// does, leaves most lanes of a 5-edge row idle: 3.5 TB/s on the 10M-vertex power-law graph.)
+// Same workgroup structure as spmm_update_kernel: consecutive rows, rowptr slice in LDS, per-row deltas summed
+// in row order by the last wave.  Every SUB-WAVE claims its rows on its own from the LDS counter and the wave
+// advances all of them by one group of U edges per iteration: a sub-wave whose row is finished writes it and
+// claims the next one while its neighbours carry on, so a wave's time is the SUM of its rows' groups / (64/LPR)
+// instead of the maximum over a fixed group of rows (out-degrees are skewed: the maximum of 8 power-law rows
+// is several times their mean).  Gathers are branch-free (see accumulate_chunk): a sub-wave with fewer than U
+// edges left re-reads its last neighbour row (an L1 hit) with weight zero.
 template <typename T, typename PT, int VEC, int LPR, int U>
 __global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
@@ -307,14 +310,13 @@ __global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
     bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     static_assert(LPR < kWave, "use spmm_update_kernel for rows that fill a wave");
-    constexpr int RPW = kWave / LPR;  // rows per wave
+    static_assert(LPR % U == 0, "a sub-wave's edge buffer is consumed in whole groups of U");
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
     __shared__ double s_rowsum[kMaxRowsPerBlock];
     __shared__ int s_next;
     __shared__ int s_done;
 
     const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sub = lane / LPR;
     const int sl = lane % LPR;
     const int sub_base = sub * LPR;
@@ -327,70 +329,104 @@ __global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
     for (int i = threadIdx.x; i <= nb; i += kBlock) s_rowptr[i] = rowptr[row_begin + i];
     for (int i = threadIdx.x; i < nb; i += kBlock) s_rowsum[i] = 0.0;
     if (threadIdx.x == 0) {
-        s_next = kWavesPerBlock * RPW;
+        s_next = 0;
         s_done = 0;
     }
     __syncthreads();
 
-    for (int base = wave * RPW; base < nb;) {
-        const int mine = base + sub;
-        int64_t e0 = 0;
-        int deg = 0;
-        bool work = false;
-        if (mine < nb) {
-            e0 = s_rowptr[mine];
-            const int64_t dg = s_rowptr[mine + 1] - e0;
-            const bool is_long = long_threshold > 0 && dg > long_threshold;
-            work = !is_long && !(skip_sinks && dg == 0);
-            deg = work ? int(dg) : 0;
-        }
-        const int64_t r = row_begin + mine;
-        Pack<T, VEC> x{}, zo{};
-        if (work && col_ok) {
-            x = load_pack<T, VEC>(X + r * ldx + c0);
-            zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
-        }
-        A acc[VEC];
+    // per sub-wave (uniform over its LPR lanes): the row it is walking and the LPR edges it has buffered
+    int mine = 0;              // row within the block
+    bool have = false;         // a row is open: x / zo / acc are live
+    bool done = false;         // no rows left in this block
+    int64_t e_next = 0;        // first edge of the row not yet buffered
+    int64_t e_end = 0;
+    int nbuf = 0, pos = 0;     // buffered edges (one per lane: c, p) and how many of them are consumed
+    int c = 0;
+    A p = A(0);
+    Pack<T, VEC> x{}, zo{};
+    A acc[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = A(0);
-        // each sub-wave walks ITS row: LPR edges of colidx / P per refill, U neighbour rows in flight
-        for (int eb = 0; __any(eb < deg); eb += LPR) {
-            const int n = deg - eb < LPR ? (deg - eb > 0 ? deg - eb : 0) : LPR;
-            int c = 0;
-            A p = A(0);
-            if (sl < n) {
-                c = colidx[e0 + eb + sl];
-                p = A(P[e0 + eb + sl]);
-            }
-            for (int j = 0; __any(j < n); j += U) {
-                Pack<T, VEC> z[U];
-                A pj[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = j + u;                                   // < LPR + U
-                    const int src = sub_base + (idx < LPR ? idx : LPR - 1);  // lanes >= n hold c = 0: row 0 is valid
-                    const int cj = lane_get(c, src);
-                    pj[u] = idx < n ? lane_get(p, src) : A(0);
-                    z[u] = load_pack<T, VEC>(Zold + int64_t(cj) * ldz + c0s);
+    for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+
+    for (;;) {
+        if (pos >= nbuf && !done) {          // divergent between sub-waves, uniform inside one
+            if (e_next == e_end) {           // row finished (or none yet): write it, claim the next one with work
+                if (have) {
+                    const int64_t r = row_begin + mine;
+                    A rsum = A(0);
+                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0);
+                    rsum = group_sum<LPR>(rsum);
+                    if (sl == 0) s_rowsum[mine] = double(rsum);
+                    have = false;
                 }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        A zv = Elem<T>::to_acc(z[u].v[k]);
-                        zv = pj[u] != A(0) ? zv : A(0);   // keeps 0 * inf (and the zero-weight re-reads) out of the sum
-                        acc[k] = fma(pj[u], zv, acc[k]);
+                for (;;) {
+                    int v = 0;
+                    if (sl == 0) v = atomicAdd(&s_next, 1);
+                    mine = lane_get(v, sub_base);
+                    if (mine >= nb) {
+                        done = true;
+                        break;
                     }
+                    const int64_t e0 = s_rowptr[mine];
+                    const int64_t dg = s_rowptr[mine + 1] - e0;
+                    if (long_threshold > 0 && dg > long_threshold) continue;      // the row-split kernels own it
+                    if (dg == 0 && skip_sinks) continue;
+                    const int64_t r = row_begin + mine;
+                    if (dg == 0) {           // row without out-edges, sinks not skipped: z stays (embedder.py:88-89)
+                        if (col_ok) {
+                            const Pack<T, VEC> z0 = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
+                            store_pack<T, VEC>(Znew + r * ldo + c0, z0);
+                        }
+                        continue;
+                    }
+                    e_next = e0;
+                    e_end = e0 + dg;
+                    if (col_ok) {
+                        x = load_pack<T, VEC>(X + r * ldx + c0);
+                        zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+                    have = true;
+                    break;
                 }
             }
+            pos = 0;
+            nbuf = 0;
+            c = 0;
+            p = A(0);
+            if (!done) {                     // refill: the next LPR edges of the row, one per lane
+                const int64_t left = e_end - e_next;
+                nbuf = left < LPR ? int(left) : LPR;
+                if (sl < nbuf) {
+                    c = colidx[e_next + sl];
+                    p = A(P[e_next + sl]);
+                }
+                e_next += nbuf;
+            }
         }
-        A rsum = A(0);
-        if (work && col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, deg > 0, Znew + r * ldo + c0, mirror, r, c0);
-        rsum = group_sum<LPR>(rsum);
-        if (work && sl == 0) s_rowsum[mine] = double(rsum);
-        int v = 0;
-        if (lane == 0) v = atomicAdd(&s_next, RPW);
-        base = __builtin_amdgcn_readfirstlane(v);
+        if (__all(done)) break;
+        // one group of U edges per sub-wave; lanes past the buffered edges hold c = 0 (row 0 is valid), weight 0
+        Pack<T, VEC> z[U];
+        A pj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // pos is a multiple of U and below LPR while a row is open; lanes past nbuf hold c = 0, p = 0
+            const int src = sub_base + ((pos + u) & (LPR - 1));
+            const int cj = lane_get(c, src);
+            pj[u] = lane_get(p, src);
+            z[u] = load_pack<T, VEC>(Zold + int64_t(cj) * ldz + c0s);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                A zv = Elem<T>::to_acc(z[u].v[k]);
+                zv = pj[u] != A(0) ? zv : A(0);   // keeps 0 * inf (and the zero-weight re-reads) out of the sum
+                acc[k] = fma(pj[u], zv, acc[k]);
+            }
+        }
+        pos += U;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's s_rowsum stores have landed
     int ticket = 0;

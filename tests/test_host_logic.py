@@ -241,6 +241,25 @@ def test_embedder_iterate_matches_reference_final_Z(tmp_path, name):
     assert emb.minimum_amount_updated_Z == min(emb.outer_deltas)
 
 
+def test_column_slices_and_auto_exchange():
+    from clane_amd.engine import column_slice, pick_exchange
+    for d, dtype, W in [(256, torch.float32, 8), (128, torch.bfloat16, 8), (100, torch.float32, 3), (2, torch.float32, 4),
+                        (1433, torch.float32, 8), (64, torch.float64, 5)]:
+        vec = {torch.float32: 4, torch.float64: 2, torch.bfloat16: 8}[dtype]
+        cuts = [column_slice(d, dtype, W, r) for r in range(W)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == d and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert all(c0 % vec == 0 for c0, c1 in cuts if c1 > c0)                       # whole 16-byte packs
+        widths = [c1 - c0 for c0, c1 in cuts]
+        assert sum(widths) == d and max(widths) - min(widths) < 2 * vec                  # even up to one pack
+    # config 3: 1 KiB rows -> 128-byte slices at 8 GPUs: columns; config 4: 256-byte bf16 rows -> halo from 8 GPUs on
+    assert pick_exchange(256, torch.float32, 8) == "columns" and pick_exchange(256, torch.float32, 16) == "columns"
+    assert pick_exchange(128, torch.bfloat16, 4) == "columns" and pick_exchange(128, torch.bfloat16, 8) == "halo"
+    assert pick_exchange(2, torch.float32, 2) == "halo"
+    with pytest.raises(ValueError, match="exchange must be"):
+        SweepEngine(HostCSR(2, np.array([0, 1, 1]), np.array([1], dtype=np.int32)), torch.zeros(2, 4), "cpu",
+                    OracleKernels(), exchange="rows")
+
+
 def test_history_sink_receives_every_sweep_in_order(tmp_path):
     """Embedder(history_sink=...): the same embeddings as history["Z"], streamed (outer, sweep, Z) in order from
     the writer thread and not retained; a failing sink surfaces at flush."""
