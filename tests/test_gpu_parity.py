@@ -750,3 +750,34 @@ def test_config2_full_iterate_vs_c_oracle(tmp_path):
     # many outer rounds) is decided by last-ulp noise in the deltas and differs with any change of summation order
     assert abs(emb.sweep_counts[0] - sweeps_or[0]) <= 8 and abs(emb.sweep_counts[1] - sweeps_or[1]) <= 8
     assert tol <= len(emb.sweep_counts) <= 40 and tol <= len(sweeps_or) <= 40
+
+
+def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
+    """bench.py's N > 1 flow end to end -- torchrun, process group, input checksum, column-split engine,
+    collectives on device tensors, barrier + MAX timing, one JSON line from rank 0 -- with two real processes
+    sharing this box's one GPU (gloo instead of RCCL, which refuses two ranks on one device).  The delta of the
+    last sweep must be the 1-process run's: same arithmetic, only the dot products of build_P are summed in
+    another order."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    common = ["--workload", "tiny", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"] + common, capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", "2",
+                          "--backend", "gloo", "--share-gpu"] + common, capture_output=True, text=True, timeout=600,
+                         cwd=root)
+    assert two.returncode == 0, two.stderr[-2000:]
+    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r2["n_gpus"] == 2 and "column split x2" in r2["config"]["parallelism"] and r2["scaling"] == "strong"
+    assert r2["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
+    for r in (r1, r2):
+        assert r["steps"] == 4 and r["warmup"] == 2 and r["value"] > 0 and r["roofline"]["bound"] == "hbm"

@@ -16,6 +16,8 @@ ap.add_argument("--world", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--long-threshold", type=int, default=None)
 ap.add_argument("--chunks", type=int, default=1)
+ap.add_argument("--calibrate", action="store_true",
+                help="also launch l1_distance over two [V, d/N] matrices (known bytes) -- PMC calibration")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
 gen, V, E, d, dname, gseed, xseed = bench.WORKLOADS[args.workload]
@@ -26,6 +28,9 @@ for W in args.world:
     eng = SweepEngine(csr, X[:, :dl].contiguous(), dev, chunks=args.chunks, long_threshold=args.long_threshold)
     eng.P.copy_(torch.rand(eng.P.numel(), device=dev) / 20)       # any frozen weights: traffic is what is timed
     eng.P_valid = True
+    if args.calibrate:
+        eng.snapshot()
+        eng.distance_from_snapshot()
     for _ in range(5):
         eng.sweep(0.76)
     torch.cuda.synchronize()
@@ -39,9 +44,11 @@ for W in args.world:
         eng.sweep(0.76)
     torch.cuda.synchronize()
     kt = eng.kernel_times_ms()
-    nbytes = sum(eng.kernel_bytes().values())
+    kb = eng.kernel_bytes()
+    nbytes = sum(kb.values())
     print(json.dumps({"world": W, "d_local": dl, "ms_per_sweep": round(ms, 3), "long_threshold": eng.long_threshold,
                       "algorithmic_GB": round(nbytes / 1e9, 2), "TBps": round(nbytes / ms / 1e9, 2),
-                      "kernels_ms": {k: round(v, 3) for k, v in kt.items()}}), flush=True)
+                      "kernels_ms": {k: round(v, 3) for k, v in kt.items()},
+                      "kernels_GB": {k: round(v / 1e9, 2) for k, v in kb.items()}}), flush=True)
     del eng
     torch.cuda.empty_cache()
