@@ -40,9 +40,12 @@ from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
 # Measured on MI355X: a single wave walking a 65..1024-edge row of 1-KiB rows streams at a fraction of
 # what the multi-wave kernel reaches, so T is small when a row fills a wave (d=256 fp32: T=32); with
 # narrow rows (d=128 bf16: 4 rows per wave-instruction) the sub-wave kernel is the efficient one and a
-# workgroup per 100-edge row is not, so T grows with the rows a wave covers per instruction.
+# workgroup per 100-edge row is not, so T grows with the rows a wave covers per instruction.  Since every
+# sub-wave claims its own rows the optimum is ~1024 (R-MAT 2M/40M: 2 rows/wave 2.82 ms at T=64 -> 2.58 at 1024;
+# 4 rows/wave 1.40 at 384 -> 1.31 at 1024; the 10M-vertex power-law graph prefers 384..1024 and loses 5-19 % at
+# 2048: a 2000-edge row walked by 8 lanes is the tail of its launch).
 # A 4-wave bin (T < deg <= hub_threshold) exists in the ABI; it did not pay.
-LONG_THRESHOLD_BY_ROWS_PER_WAVE = {1: 32, 2: 64, 4: 384, 8: 512}
+LONG_THRESHOLD_BY_ROWS_PER_WAVE = {1: 32, 2: 1024, 4: 1024, 8: 512}
 HUB_FACTOR = 1
 # Rows above SPLIT_EDGES edges are cut into segments, one 16-wave workgroup each: a 70k-edge hub done by ONE
 # workgroup is a ~0.25 ms tail on every launch.  Segments are 4096 edges (256 per wave) when there are plenty of
