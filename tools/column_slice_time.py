@@ -26,6 +26,12 @@ X = synth.gaussian_X(V, d, seed=xseed).to(bench.DTYPES[dname])
 for W in args.world:
     dl = d // W
     eng = SweepEngine(csr, X[:, :dl].contiguous(), dev, chunks=args.chunks, long_threshold=args.long_threshold)
+    eng.build_P()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.build_P()
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
     eng.P.copy_(torch.rand(eng.P.numel(), device=dev) / 20)       # any frozen weights: traffic is what is timed
     eng.P_valid = True
     if args.calibrate:
@@ -47,6 +53,7 @@ for W in args.world:
     kb = eng.kernel_bytes()
     nbytes = sum(kb.values())
     print(json.dumps({"world": W, "d_local": dl, "ms_per_sweep": round(ms, 3), "long_threshold": eng.long_threshold,
+                      "build_P_ms": round(build_ms, 3),
                       "algorithmic_GB": round(nbytes / 1e9, 2), "TBps": round(nbytes / ms / 1e9, 2),
                       "kernels_ms": {k: round(v, 3) for k, v in kt.items()},
                       "kernels_GB": {k: round(v / 1e9, 2) for k, v in kb.items()}}), flush=True)
