@@ -253,10 +253,13 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         result["iterate"] = {"wall_s": wall, "outer_rounds": len(emb.sweep_counts), "sweeps": sum(emb.sweep_counts),
+                             "sweeps_launched": emb.sweeps_launched,
                              "sweeps_per_round": emb.sweep_counts, "tolerence": args.tolerence,
                              "last_outer_delta": emb.outer_deltas[-1],
                              "note": "Embedder.iterate() from Z = X: build_P + propagate per round, reference "
-                                     "stopping rule (embedder.py:56-108); not part of the headline value"}
+                                     "stopping rule (embedder.py:56-108); sweeps whose delta is provably 0 (after an "
+                                     "exactly-zero delta with P frozen) are counted, not launched; not part of the "
+                                     "headline value"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

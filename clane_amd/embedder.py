@@ -35,6 +35,7 @@ class Embedder(object):
         verbose:            bool = True,
         max_sweeps:         Optional[int] = None,
         history_sink:       Optional[Callable[[int, int, torch.Tensor], None]] = None,
+        skip_idle_sweeps:   bool = True,
     ) -> None:
         self.graph = graph
         self.similarity_measure = similarity_measure
@@ -57,6 +58,12 @@ class Embedder(object):
         self.max_sweeps = max_sweeps          # safety cap per propagate(); None = reference (uncapped)
         self.sweep_counts = []
         self.outer_deltas = []
+        # A sweep whose delta is exactly 0 reproduced its input bit for bit; with P frozen every further sweep of
+        # the propagate is the same computation on the same data (the kernels are deterministic), so its delta is
+        # 0 too.  Such sweeps are accounted (tolerance countdown, printout, history) without being launched -- at
+        # the fp32 fixed point the reference's rule still asks for `tolerence` sweeps in each of `tolerence` rounds.
+        self.skip_idle_sweeps = skip_idle_sweeps
+        self.sweeps_launched = 0
         # history_sink(outer, sweep, Z): with save_history, every sweep's embeddings are handed to it from a
         # writer thread, in order, instead of being kept in `history["Z"]` -- the copy to the host overlaps the
         # following sweeps (SweepEngine.stage_Z).  Call flush_history() (iterate() does) before relying on it.
@@ -125,11 +132,18 @@ class Embedder(object):
         outer = len(self.sweep_counts)
         n_sweeps = 0
 
+        idle = False
+        staged = None
         while True:
-            amount_updated = engine.sweep(self.gamma)
+            if idle:
+                amount_updated = 0.0
+            else:
+                amount_updated = engine.sweep(self.gamma)
+                self.sweeps_launched += 1
             n_sweeps += 1
             if self.save_history:
-                staged = engine.stage_Z() if hasattr(engine, "stage_Z") else None
+                if not idle or staged is None:      # an idle sweep leaves the embeddings as they are: same copy
+                    staged = engine.stage_Z() if hasattr(engine, "stage_Z") else None
                 if staged is None:
                     history_Z.append(engine.get_Z())
                 elif self._writer is not None:
@@ -147,6 +161,8 @@ class Embedder(object):
             else:
                 self.tolerences['propagation'].endure()
 
+            if self.skip_idle_sweeps and amount_updated == 0.0:
+                idle = True
             if self.verbose:
                 print(f"{amount_updated:.4f} {self.tolerences['propagation'].value}")
             if self.tolerences['propagation'].value == 0 or (self.max_sweeps and n_sweeps >= self.max_sweeps):

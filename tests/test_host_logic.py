@@ -260,6 +260,31 @@ def test_column_slices_and_auto_exchange():
                     OracleKernels(), exchange="rows")
 
 
+def test_idle_sweeps_are_accounted_but_not_launched(tmp_path):
+    """At the fp32 fixed point a sweep's delta is exactly 0 and stays 0 while P is frozen: Embedder runs the
+    reference's countdown over those sweeps without launching them.  Decisions, counts, printout, history and
+    result are the same as with every sweep launched."""
+    runs = {}
+    for skip in (True, False):
+        root = write_data_root(tmp_path / f"one{skip}", ["a"], ["a"], ["a"], np.array([[1.0, -2.0, 0.5]], dtype=np.float32))
+        g = Graph(root)
+        attach_cpu_engine(g)
+        emb = Embedder(g, CosineSimilarity(), torch.device("cpu"), gamma=0.5, tolerence=4, save_history=True,
+                       skip_idle_sweeps=skip)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            emb.iterate()
+        runs[skip] = (emb, g.Z, buf.getvalue())
+    (a, Za, out_a), (b, Zb, out_b) = runs[True], runs[False]
+    assert a.sweep_counts == b.sweep_counts and a.outer_deltas == b.outer_deltas and out_a == out_b
+    assert torch.equal(Za, Zb) and torch.equal(Za, torch.tensor([[2.0, -4.0, 1.0]]))
+    # every round ends with `tolerence` sweeps of exactly-zero delta that need no launch
+    assert b.sweeps_launched == sum(b.sweep_counts) and a.sweeps_launched == sum(a.sweep_counts) - 4 * len(a.sweep_counts)
+    assert a.outer_deltas[-1] == 0.0 and a.sweep_counts[-1] == 4 + 1      # one launched sweep + the countdown
+    for ha, hb in zip(a.history["Z"], b.history["Z"]):
+        assert len(ha) == len(hb) and all(torch.equal(x, y) for x, y in zip(ha, hb))
+
+
 def test_history_sink_receives_every_sweep_in_order(tmp_path):
     """Embedder(history_sink=...): the same embeddings as history["Z"], streamed (outer, sweep, Z) in order from
     the writer thread and not retained; a failing sink surfaces at flush."""
