@@ -23,15 +23,19 @@ from .graph import Graph
 
 def _distributed_setup():
     """Under `torchrun --nproc-per-node N` (WORLD_SIZE > 1): one process per GPU, RCCL process group.
-    Returns (rank, world).  A plain `python -m clane_amd` run is (0, 1) and touches nothing."""
+    Returns (rank, world).  A plain `python -m clane_amd` run is (0, 1) and touches nothing.
+    Rehearsal on a one-GPU box: CLANE_DIST_BACKEND=gloo CLANE_SHARE_GPU=1 (RCCL refuses two ranks on one device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
         return 0, 1
     import torch.distributed as dist
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("CLANE_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("CLANE_DIST_BACKEND", "nccl") == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     return dist.get_rank(), world
 
 

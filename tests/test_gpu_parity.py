@@ -9,6 +9,7 @@ Tolerances (north_star: embeddings within 1e-4 relative L2 of the CPU reference)
 """
 import contextlib
 import io
+import os
 from pathlib import Path
 
 import numpy as np
@@ -781,3 +782,85 @@ def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
     assert r2["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
     for r in (r1, r2):
         assert r["steps"] == 4 and r["warmup"] == 2 and r["value"] > 0 and r["roofline"]["bound"] == "hbm"
+
+
+def test_cli_two_processes_on_one_gpu_match_one_process(tmp_path):
+    """`torchrun ... -m clane_amd` with two real processes (gloo, both on this box's GPU): per-rank engine on its
+    column slice, broadcast content, collective decisions, rank 0 writes -- the same Z.npy as one process."""
+    import socket
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    kc = load_golden("g2_karate_csr.npz")
+    Xc = np.random.default_rng(5).standard_normal((34, 64)).astype(np.float32)
+    data = write_data_root(tmp_path / "karate64", kc["vertex_ids"], kc["edge_src"], kc["edge_dst"], Xc)
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text("graph:\n  embedding_dim: 64\n\nsimilarity:\n  method: \"CosineSimilarity\"\n  kwargs: {}\n\n"
+                   "embedder:\n  gamma: 0.76\n  tolerence: 5\n")
+    common = ["--data_root", str(data), "--config_file", str(cfg)]
+    one = subprocess.run([sys.executable, "-m", "clane_amd"] + common + ["--output_root", str(tmp_path / "o1")],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CLANE_DIST_BACKEND="gloo", CLANE_SHARE_GPU="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "clane_amd"] + common +
+                         ["--output_root", str(tmp_path / "o2")], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    Z1, Z2 = np.load(tmp_path / "o1" / "Z.npy"), np.load(tmp_path / "o2" / "Z.npy")
+    assert Z1.shape == (34, 64) and np.linalg.norm(Z1 - Z2) <= 1e-5 * np.linalg.norm(Z1)
+    assert two.stdout.count("Graph Loaded.") == 1                      # rank 0 talks, the other rank is silent
+
+
+def test_config3_full_size_properties(dev):
+    """BASELINE config 3 at full size (R-MAT 2M / 40M / d=256 fp32), checked through what does not need the whole
+    oracle: (1) every row of P with edges sums to 1 (graph.py:122-123); (2) 2 000 sampled rows of the first sweep
+    against a float64 restatement of embedder.py:88-92 on those rows; (3) rows without out-edges keep z;
+    (4) the reported delta is sum|Z_new - Z_old|; (5) two engines give bit-identical results; (6) with P frozen
+    the sweep is affine in Z:  F(Za) - F(Zb) = F(Za - Zb) - X."""
+    V, E, d, gamma = 2_000_000, 40_000_000, 256, 0.76
+    csr = synth.rmat_csr(V, E, seed=3, device=str(dev))
+    X = synth.gaussian_X(V, d, seed=4)
+    eng = SweepEngine(csr, X, dev)
+    eng.build_P()
+    P = eng.P_global()                                         # CPU, global (row, col) order
+    deg = np.diff(csr.rowptr)
+    cs = torch.cat([torch.zeros(1, dtype=torch.float64), P.double().cumsum(0)])
+    sums = (cs[torch.from_numpy(csr.rowptr[1:])] - cs[torch.from_numpy(csr.rowptr[:-1])]).numpy()
+    assert np.abs(sums[deg > 0] - 1).max() < 1e-4 and np.abs(sums[deg == 0]).max() == 0
+    delta = eng.sweep(gamma)
+    Z1 = eng.get_Z()
+    rows = np.random.default_rng(0).choice(V, size=2000, replace=False)
+    rows = np.concatenate([rows, np.argsort(deg)[-3:]])        # and the three heaviest hubs
+    Pn, Xn = P.numpy().astype(np.float64), X.numpy()
+    for r in rows:
+        a, b = csr.rowptr[r], csr.rowptr[r + 1]
+        want = Xn[r].astype(np.float64) if a == b else \
+            Xn[r] + gamma * (Pn[a:b, None] * Xn[csr.colidx[a:b]].astype(np.float64)).sum(0)
+        got = Z1[r].numpy().astype(np.float64)
+        assert np.linalg.norm(got - want) <= 2e-6 * max(np.linalg.norm(want), 1e-30), r
+    sink = torch.from_numpy(deg == 0)
+    assert torch.equal(Z1[sink], X[sink])
+    assert delta == pytest.approx(float((Z1.double() - X.double()).abs().sum()), rel=1e-6)
+    eng_b = SweepEngine(csr, X, dev)
+    eng_b.build_P()
+    assert torch.equal(eng_b.P, eng.P) and eng_b.sweep(gamma) == delta and torch.equal(eng_b.Zcur, eng.Zcur)
+    del eng_b
+    # affine in Z with P frozen (set_Z drops P: put the flag back, P itself is untouched)
+    g = torch.Generator().manual_seed(1)
+    Za = torch.randn(V, d, generator=g)
+    Zb = torch.randn(V, d, generator=g)
+
+    def F(Z):
+        eng.set_Z(Z)
+        eng.P_valid = True
+        eng.sweep(gamma)
+        return eng.get_Z()
+    lhs = F(Za) - F(Zb)
+    rhs = F(Za - Zb) - X
+    live = ~sink                                               # rows without out-edges return z itself: F(z) = z
+    assert O.rel_l2(lhs[live], rhs[live]) < 1e-5
+    assert torch.equal(lhs[sink], (Za - Zb)[sink])
