@@ -167,7 +167,14 @@ class SweepEngine:
             self.blocks = self.part.blocks()
             self.local = localize(csr, self.part)
         if long_threshold is None:
-            long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[64 // lanes_per_row(self.d, X.dtype)]
+            rows_per_wave = 64 // lanes_per_row(self.d, X.dtype)
+            long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
+            if rows_per_wave > 1:
+                # A T-edge row walked by one sub-wave takes T/8 gather groups in sequence -- the tail of its launch.
+                # That is nothing next to a 40M-edge pass and a third of a 4M-edge one (R-MAT 200k/4M/d=128:
+                # 3 545 sweeps/s at T=128, 2 013 at T=1024), so T also scales with the edges of the pass.
+                by_size = 1 << max(7, int(self.local.colidx.shape[0] // 32768).bit_length() - 1)
+                long_threshold = min(long_threshold, by_size)
         self.long_threshold = int(long_threshold)
         self.hub_threshold = int(hub_threshold) if hub_threshold is not None else HUB_FACTOR * self.long_threshold
         dev = self.device
