@@ -165,7 +165,7 @@ class SweepEngine:
             self.part = RowPartition.create(self.V, row_world, row_rank, chunks, live_mask=live, shuffle=shuffle,
                                             seed=seed, priority=hot)
             self.blocks = self.part.blocks()
-            self.local = localize(csr, self.part)
+            self.local = localize(csr, self.part, self.device)
         if long_threshold is None:
             rows_per_wave = 64 // lanes_per_row(self.d, X.dtype)
             long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]

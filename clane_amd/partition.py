@@ -175,8 +175,10 @@ class LocalCSR:
     edge_origin: np.ndarray     # int64 [E_local]  index of each local edge in the global CSR order
 
 
-def localize(csr: HostCSR, part: RowPartition) -> LocalCSR:
-    """Slice + relabel the global CSR for one rank."""
+def localize(csr: HostCSR, part: RowPartition, device=None) -> LocalCSR:
+    """Slice + relabel the global CSR for one rank.  The one heavy step -- re-sorting every row's edges by their
+    new column -- is a single sort of unique (row, column) keys; with ``device`` = a GPU it runs there (40M edges:
+    seconds on the host, milliseconds on the card)."""
     V = csr.num_vertices
     if V != part.num_vertices:
         raise ValueError("partition built for a different vertex count")
@@ -189,13 +191,18 @@ def localize(csr: HostCSR, part: RowPartition) -> LocalCSR:
     deg = np.where(valid, csr.outdeg()[safe], 0).astype(np.int64)
     rowptr = np.zeros(part.n_local + 1, dtype=np.int64)
     np.cumsum(deg, out=rowptr[1:])
-    # original edge id of every local edge: start-of-row + offset within the row
-    row_of = np.repeat(np.arange(part.n_local, dtype=np.int64), deg)
-    origin = csr.rowptr[safe][row_of] + (np.arange(rowptr[-1], dtype=np.int64) - rowptr[:-1][row_of])
-    cols = pos[csr.colidx[origin]]
-    identity = part.world_size == 1 and part.chunks == 1 and np.array_equal(pos, np.arange(V))
-    if not identity:
-        order = np.lexsort((cols, row_of))      # stable: by row, then by new column
-        cols, origin = cols[order], origin[order]
     indeg = np.where(valid, csr.indeg()[safe], 0).astype(np.int32)
-    return LocalCSR(rowptr, cols.astype(np.int32), indeg, verts, origin)
+    identity = part.world_size == 1 and part.chunks == 1 and np.array_equal(pos, np.arange(V))
+    if identity:
+        return LocalCSR(rowptr, csr.colidx.astype(np.int32), indeg, verts, np.arange(csr.num_edges, dtype=np.int64))
+    import torch
+    dev = torch.device(device) if device is not None and torch.device(device).type == "cuda" else torch.device("cpu")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    deg_t, rowptr_t = t(deg), t(rowptr)
+    row_of = torch.repeat_interleave(torch.arange(part.n_local, device=dev), deg_t)
+    # original edge id of every local edge: start-of-row + offset within the row
+    origin = t(csr.rowptr[safe])[row_of] + (torch.arange(int(rowptr[-1]), device=dev) - rowptr_t[:-1][row_of])
+    cols = t(pos)[t(csr.colidx.astype(np.int64))[origin]]
+    order = torch.argsort(row_of * part.padded_vertices + cols)          # keys are unique: any sort is THE order
+    cols, origin = cols[order], origin[order]
+    return LocalCSR(rowptr, cols.to(torch.int32).cpu().numpy(), indeg, verts, origin.cpu().numpy())
