@@ -9,8 +9,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -33,6 +35,7 @@ bool read_file(const char *path, std::string &out, char *err, int errlen) {
         return false;
     }
     // Python opens the files in text mode: universal newlines, "\r\n" and a lone "\r" both read as "\n".
+    if (std::memchr(out.data(), '\r', out.size()) == nullptr) return true;
     size_t w = 0;
     for (size_t r = 0; r < out.size(); ++r) {
         if (out[r] == '\r') {
@@ -69,6 +72,55 @@ void for_each_line(std::string_view body, F &&f) {  // Python's str.split('\n'):
     }
 }
 
+// Cut `body` into pieces that start right after a '\n' (piece 0 at 0), about equal in bytes.
+std::vector<size_t> piece_starts(std::string_view body, int pieces) {
+    std::vector<size_t> start{0};
+    for (int t = 1; t < pieces; ++t) {
+        size_t p = body.size() / size_t(pieces) * size_t(t);
+        if (p <= start.back()) continue;
+        const size_t nl = body.find('\n', p);
+        if (nl == std::string_view::npos) break;
+        if (nl + 1 > start.back()) start.push_back(nl + 1);
+    }
+    start.push_back(body.size());
+    return start;
+}
+
+int worker_count(size_t bytes) {
+    if (bytes < (size_t(1) << 22)) return 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    return int(std::min<unsigned>(hw ? hw : 1, 16));
+}
+
+template <typename F>
+void run_pieces(int n, F &&f) {
+    if (n == 1) {
+        f(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n; ++t) th.emplace_back([&f, t] { f(t); });
+    for (auto &x : th) x.join();
+}
+
+// Fields per piece under Python's split('\n') (n separators -> n+1 fields: the last piece owns the +1).
+std::vector<int64_t> count_fields(std::string_view body, const std::vector<size_t> &start) {
+    const int n = int(start.size()) - 1;
+    std::vector<int64_t> cnt(size_t(n), 0);
+    run_pieces(n, [&](int t) {
+        const char *p = body.data() + start[t], *end = body.data() + start[t + 1];
+        int64_t c = 0;
+        while (p < end) {
+            const char *q = static_cast<const char *>(std::memchr(p, '\n', size_t(end - p)));
+            if (!q) break;
+            ++c;
+            p = q + 1;
+        }
+        cnt[size_t(t)] = c + (t == n - 1 ? 1 : 0);
+    });
+    return cnt;
+}
+
 }  // namespace
 
 extern "C" {
@@ -77,13 +129,16 @@ extern "C" {
 int64_t clane_count_lines(const char *path, char *err, int errlen) {
     std::string buf;
     if (!read_file(path, buf, err, errlen)) return -1;
+    const std::string_view body = stripped(buf);
+    const auto start = piece_starts(body, worker_count(body.size()));
     int64_t n = 0;
-    for_each_line(stripped(buf), [&](std::string_view) { ++n; });
+    for (int64_t c : count_fields(body, start)) n += c;
     return n;
 }
 
 // src[k], dst[k] <- vertex indices of line k of E.  Returns the number of edges, or -1 (file error),
-// -2 (malformed line), -3 (unknown vertex id); err holds the message.
+// -2 (malformed line), -3 (unknown vertex id); err holds the message of the FIRST offending line.
+// The E file is cut at line boundaries and parsed by up to 16 threads (the id -> index map is read-only by then).
 int64_t clane_parse_edges(const char *v_path, const char *e_path, int64_t *src, int64_t *dst, int64_t capacity,
                           char *err, int errlen) {
     std::string vbuf, ebuf;
@@ -96,33 +151,57 @@ int64_t clane_parse_edges(const char *v_path, const char *e_path, int64_t *src, 
         int64_t i = 0;
         for_each_line(stripped(vbuf), [&](std::string_view id) { first.emplace(id, i++); });  // emplace keeps the first
     }
-    int64_t k = 0, status = 0;
-    for_each_line(stripped(ebuf), [&](std::string_view line) {
-        if (status) return;
-        const size_t tab = line.find('\t');
-        if (tab == std::string_view::npos || line.find('\t', tab + 1) != std::string_view::npos) {
-            std::snprintf(err, errlen, "E line %lld: expected 'src\\tdst', got '%.*s'", (long long)(k + 1),
-                          int(line.size() < 80 ? line.size() : 80), line.data());
-            status = -2;
-            return;
-        }
-        const auto s = first.find(line.substr(0, tab)), d = first.find(line.substr(tab + 1));
-        if (s == first.end() || d == first.end()) {
-            const std::string_view bad = s == first.end() ? line.substr(0, tab) : line.substr(tab + 1);
-            std::snprintf(err, errlen, "'%.*s' is not in list", int(bad.size() < 80 ? bad.size() : 80), bad.data());
-            status = -3;
-            return;
-        }
-        if (k >= capacity) {
-            std::snprintf(err, errlen, "output buffers too small (%lld)", (long long)capacity);
-            status = -1;
-            return;
-        }
-        src[k] = s->second;
-        dst[k] = d->second;
-        ++k;
+    const std::string_view body = stripped(ebuf);
+    const auto start = piece_starts(body, worker_count(body.size()));
+    const int pieces = int(start.size()) - 1;
+    const auto cnt = count_fields(body, start);
+    std::vector<int64_t> off(size_t(pieces) + 1, 0);
+    for (int t = 0; t < pieces; ++t) off[size_t(t) + 1] = off[size_t(t)] + cnt[size_t(t)];
+    if (off.back() > capacity) {
+        std::snprintf(err, errlen, "output buffers too small (%lld)", (long long)capacity);
+        return -1;
+    }
+    struct Fail {
+        int64_t line = -1;
+        int status = 0;
+        std::string msg;
+    };
+    std::vector<Fail> fails;
+    fails.resize(size_t(pieces));
+    run_pieces(pieces, [&](int t) {
+        int64_t k = off[size_t(t)];
+        Fail &fail = fails[size_t(t)];
+        std::string_view part = body.substr(start[t], start[t + 1] - start[t]);
+        if (t < pieces - 1) part.remove_suffix(1);           // the '\n' that ends the piece's last line
+        for_each_line(part, [&](std::string_view line) {
+            if (fail.status) return;
+            char buf[160];
+            const size_t tab = line.find('\t');
+            if (tab == std::string_view::npos || line.find('\t', tab + 1) != std::string_view::npos) {
+                std::snprintf(buf, sizeof buf, "E line %lld: expected 'src\\tdst', got '%.*s'", (long long)(k + 1),
+                              int(line.size() < 80 ? line.size() : 80), line.data());
+                fail = Fail{k, -2, buf};
+                return;
+            }
+            const auto s = first.find(line.substr(0, tab)), d = first.find(line.substr(tab + 1));
+            if (s == first.end() || d == first.end()) {
+                const std::string_view bad = s == first.end() ? line.substr(0, tab) : line.substr(tab + 1);
+                std::snprintf(buf, sizeof buf, "'%.*s' is not in list", int(bad.size() < 80 ? bad.size() : 80), bad.data());
+                fail = Fail{k, -3, buf};
+                return;
+            }
+            src[k] = s->second;
+            dst[k] = d->second;
+            ++k;
+        });
     });
-    return status ? status : k;
+    for (const Fail &f : fails) {                              // pieces are in file order: the first failure wins
+        if (f.status) {
+            std::snprintf(err, errlen, "%s", f.msg.c_str());
+            return f.status;
+        }
+    }
+    return off.back();
 }
 
 }  // extern "C"

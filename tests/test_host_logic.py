@@ -378,6 +378,37 @@ def test_native_loader_matches_python_loader(tmp_path, karate_root):
             G._python_parse_edges(root, ["1", "2"])
 
 
+def test_native_loader_multithreaded_pieces(tmp_path):
+    """An E file above 4 MiB is cut at line boundaries and parsed by several threads: same indices as line-by-line
+    parsing, and of several bad lines the FIRST one in the file is the one reported."""
+    from clane_amd import graph as G
+    if G._host_lib() is None:
+        pytest.skip("libclane_host.so not built")
+    rng = np.random.default_rng(3)
+    n_v, n_e = 5000, 150_000
+    ids = [f"vertex-with-a-long-name-{i:07d}" for i in range(n_v)]
+    src, dst = rng.integers(0, n_v, n_e), rng.integers(0, n_v, n_e)
+    lines = [f"{ids[a]}\t{ids[b]}" for a, b in zip(src, dst)]
+    root = tmp_path / "big"
+    root.mkdir()
+    (root / "V").write_text("\n".join(ids) + "\n")
+    (root / "E").write_text("\n".join(lines) + "\n\n")
+    assert (root / "E").stat().st_size > (1 << 22)
+    s2, d2 = G._native_parse_edges(root)
+    assert np.array_equal(s2, src) and np.array_equal(d2, dst)
+    bad = list(lines)
+    bad[140_000] = "no-tab-here"
+    bad[90_000] = f"{ids[1]}\tnobody"
+    bad[120_000] = "a\tb\tc"
+    (root / "E").write_text("\n".join(bad))
+    with pytest.raises(ValueError, match="'nobody' is not in list"):
+        G._native_parse_edges(root)
+    bad[20_000] = "a\tb\tc"
+    (root / "E").write_text("\n".join(bad))
+    with pytest.raises(ValueError, match="E line 20001"):
+        G._native_parse_edges(root)
+
+
 def test_clane_import_shim():
     import clane.graph, clane.similarity, clane.embedder                    # noqa: E401
     from clane.__main__ import get_parser
