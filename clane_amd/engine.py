@@ -98,7 +98,7 @@ class StagedZ:
         if self._ready is None:
             eng, slot = self._engine, self._slot
             slot["done"].synchronize()
-            self._ready = slot["host"][eng.pos, :eng.d].clone()
+            self._ready = slot["host"][:, :eng.d].clone()
             eng._release_stage_slot(slot)
             self._engine = self._slot = None
         return self._ready
@@ -250,20 +250,23 @@ class SweepEngine:
             self.mirrors.append(mirror)
 
         # ---- embeddings ---------------------------------------------------------------
+        # Vertex order <-> engine order is applied ON THE DEVICE (an upload / download plus one indexed copy):
+        # a 2 GB matrix permuted with host fancy-indexing costs more than a whole iterate() at config 3.
         if self.halo:
-            self.table_vertex = torch.from_numpy(self.part.table_vertex)      # host, int64 [table_rows]
-            self.slot = torch.from_numpy(self.part.vertex_slot)               # host, int64 [V]
+            self.table_vertex = torch.from_numpy(self.part.table_vertex).to(dev)   # int64 [table_rows]
+            self.slot = torch.from_numpy(self.part.vertex_slot).to(dev)            # int64 [V]
         else:
-            self.pos = torch.from_numpy(self.part.position_of_vertex())       # host, int64 [V]
+            self.pos = torch.from_numpy(self.part.position_of_vertex()).to(dev)    # int64 [V]
         self.Zbuf = [torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype, device=dev) for _ in range(2)]
         self.cur = 0
-        verts = torch.from_numpy(self.local.vertex)
-        Xl = torch.zeros(self.part.n_local, self.ld, dtype=self.dtype)
+        Xd = X.to(dev)                                                             # this rank's columns, [V, d]
+        verts = torch.from_numpy(self.local.vertex).to(dev)
         ok = verts >= 0
-        Xl[ok, :self.d] = X[verts[ok]]
-        self.X_loc = Xl.to(dev)
+        self.X_loc = torch.zeros(self.part.n_local, self.ld, dtype=self.dtype, device=dev)
+        self.X_loc[ok, :self.d] = Xd[verts[ok]]
         self.quiet_stale = False          # other ranks' quiet rows are only refreshed when Z is read out
-        self.set_Z(X_all)
+        self._load_Z(Xd)
+        del Xd
 
         # ---- scalars / scratch --------------------------------------------------------
         self.ws = torch.zeros(self.k.reduce_ws_len(), dtype=torch.float64, device=dev)
@@ -305,17 +308,20 @@ class SweepEngine:
         """Load a [V, d] matrix (vertex order) into the full-Z buffers."""
         if tuple(Z.shape) != (self.V, self.d_full):
             raise ValueError(f"set_Z: expected {(self.V, self.d_full)}, got {tuple(Z.shape)}")
-        full = torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype)
-        Zc = Z.detach()[:, self.col0:self.col1].to("cpu", self.dtype)
+        self._load_Z(Z.detach()[:, self.col0:self.col1].to(self.device, self.dtype))
+
+    def _load_Z(self, Zd: torch.Tensor) -> None:
+        """`Zd`: this rank's columns of the matrix, on the device, vertex order."""
+        first = self.Zbuf[0]
+        first.zero_()
         if self.halo:       # own rows, every remote row this rank reads, and the constant (sink) halo rows
             held = self.table_vertex >= 0
-            full[held, :self.d] = Zc[self.table_vertex[held]]
+            first[held, :self.d] = Zd[self.table_vertex[held]]
         else:
-            full[self.pos, :self.d] = Zc
+            first[self.pos, :self.d] = Zd
         # BOTH ping-pong buffers: rows without out-edges never change (embedder.py:88-89), so the sweep
         # kernel leaves them alone (CLANE_SPMM_SINKS_UNTOUCHED) and relies on the two copies agreeing.
-        for buf in self.Zbuf:
-            buf.copy_(full)
+        self.Zbuf[1].copy_(first)
         self.P_valid = False
         self.quiet_stale = False
 
@@ -325,24 +331,25 @@ class SweepEngine:
             n = self.part.n_local
             everyone = torch.empty(self.world * n, self.ld, dtype=self.dtype, device=self.device)
             self.comm.all_gather_into(everyone, self.Zcur[:n].contiguous())
-            return everyone.to("cpu")[self.slot, :self.d].clone()
+            return everyone[self.slot, :self.d].cpu()
         if self.columns:    # column slices of every rank, padded to the widest one
             mine = torch.zeros(self.part.padded_vertices, self.ld_max, dtype=self.dtype, device=self.device)
             mine[:, :self.ld] = self.Zcur
             everyone = torch.empty(self.world * mine.shape[0], self.ld_max, dtype=self.dtype, device=self.device)
             self.comm.all_gather_into(everyone, mine)
-            host = everyone.to("cpu").view(self.world, mine.shape[0], self.ld_max)
-            out = torch.empty(self.V, self.d_full, dtype=self.dtype)
+            everyone = everyone.view(self.world, mine.shape[0], self.ld_max)
+            out = torch.empty(self.V, self.d_full, dtype=self.dtype, device=self.device)
             for r in range(self.world):
                 c0, c1 = column_slice(self.d_full, self.dtype, self.world, r)
-                out[:, c0:c1] = host[r][self.pos, :c1 - c0]
-            return out
+                if c1 > c0:
+                    out[:, c0:c1] = everyone[r][self.pos, :c1 - c0]
+            return out.cpu()
         self._sync_quiet_rows()
-        return self.Zcur.to("cpu")[self.pos, :self.d].clone()
+        return self.Zcur[self.pos, :self.d].cpu()
 
     def stage_Z(self) -> StagedZ:
         """Start copying the current embeddings to the host WITHOUT stalling the sweeps (``--save_history`` at
-        scale): a device-to-device copy on the sweep stream (the ping-pong buffer is overwritten two
+        scale): a device-to-device copy (into vertex order) on the sweep stream (the ping-pong buffer is overwritten two
         sweeps later, long before 2 GB have crossed PCIe), then an asynchronous D2H into pinned memory on a copy
         stream.  At most STAGE_SLOTS copies are in flight; with none free this call waits for ``result()`` of an
         earlier one (possibly on another thread).  Multi-GPU runs gather synchronously (collective)."""
@@ -358,11 +365,11 @@ class SweepEngine:
                 slot = self._stage_free.pop()
             else:
                 self._stage_made += 1
-                slot = {"dev": torch.empty_like(self.Zcur),
-                        "host": torch.empty(self.Zcur.shape, dtype=self.dtype, pin_memory=True),
+                slot = {"dev": torch.empty(self.V, self.ld, dtype=self.dtype, device=self.device),
+                        "host": torch.empty(self.V, self.ld, dtype=self.dtype, pin_memory=True),
                         "done": torch.cuda.Event()}
         main = torch.cuda.current_stream(self.device)
-        slot["dev"].copy_(self.Zcur)
+        torch.index_select(self.Zcur, 0, self.pos, out=slot["dev"])         # vertex order, on the sweep stream
         copied = torch.cuda.Event()
         copied.record(main)
         self._copy_stream.wait_event(copied)

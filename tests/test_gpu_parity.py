@@ -324,8 +324,8 @@ def test_cli_end_to_end(tmp_path, karate_root, monkeypatch):
     cfg = tmp_path / "config.yaml"
     cfg.write_text("graph:\n  embedding_dim: 2\n\nsimilarity:\n  method: \"CosineSimilarity\"\n  kwargs:\n"
                    "    foo: \"bar\"\n\nembedder:\n  gamma: 0.76\n  tolerence: 10\n")
-    out = tmp_path / "test_output"
-    for argv in (["--data_root", str(karate_root)], ["embedding", "--data_root", str(karate_root)]):
+    for n_run, argv in enumerate((["--data_root", str(karate_root)], ["embedding", "--data_root", str(karate_root)])):
+        out = tmp_path / f"test_output{n_run}"       # no C.npy: each run draws its own X and writes its own history
         args = get_parser().parse_args(argv + ["--output_root", str(out), "--config_file", str(cfg),
                                                "--save_history"])
         buf = io.StringIO()
