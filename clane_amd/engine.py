@@ -7,17 +7,18 @@ the body of ``Embedder.propagate`` (embedder.py:84-94) and the per-vertex tensor
 the D2H copy of one scalar per sweep and ``torch.distributed`` (RCCL).
 
 HBM layout per rank (T = float32 / float64 / bfloat16, ld = d rounded up to a 16-byte pack,
-pad columns zero):
+pad columns zero; on N > 1 GPUs with the column split d is the width of the rank's column slice and
+every rank holds all rows; with a row split n_loc < V_pad):
 
-    Zbuf[2]   [V_pad, ld] T    full-size embedding matrix, ping-pong (read old / write new)
+    Zbuf[2]   [V_pad, ld] T    embedding matrix, ping-pong (read old / write new)
     X_loc     [n_loc, ld] T    content embeddings of the owned rows
     rowptr    [n_loc+1] i64, colidx [E_loc] i32 (positions), P [E_loc] acc, indeg [n_loc] i32
     partials  fixed-order L1-delta partial sums (double)
 
-A sweep is one launch group per *block* of owned rows (partition.py): live chunks first -- each
-followed, on N > 1 GPUs, by the in-place all-gather of its span (async, RCCL's stream, overlapping
-the next block's kernels) -- then the quiet block, which is never exchanged during sweeps.  The
-scalar delta is all-reduced.  On one GPU no collective is issued.
+A sweep is one launch group per *block* of owned rows (one block, unless rows are divided over GPUs:
+then each live chunk is followed by the exchange of its rows -- async on RCCL's stream, overlapping
+the next block's kernels).  The scalar delta is all-reduced.  On one GPU no collective is issued; with
+the column split (the default division) that scalar is the only per-sweep collective.
 """
 from __future__ import annotations
 
