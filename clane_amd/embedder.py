@@ -64,6 +64,7 @@ class Embedder(object):
         # the fp32 fixed point the reference's rule still asks for `tolerence` sweeps in each of `tolerence` rounds.
         self.skip_idle_sweeps = skip_idle_sweeps
         self.sweeps_launched = 0
+        self._round_was_idle = False
         # history_sink(outer, sweep, Z): with save_history, every sweep's embeddings are handed to it from a
         # writer thread, in order, instead of being kept in `history["Z"]` -- the copy to the host overlaps the
         # following sweeps (SweepEngine.stage_Z).  Call flush_history() (iterate() does) before relying on it.
@@ -98,10 +99,12 @@ class Embedder(object):
     def iterate(self):
         """Outer fixed point (reference embedder.py:56-69)."""
         engine = self._engine()
+        replay = False
         while True:
-            engine.snapshot()
-            self.propagate()
-            amount_updated_Z_current = engine.distance_from_snapshot()
+            if not replay:
+                engine.snapshot()
+            self.propagate(_replay=replay)
+            amount_updated_Z_current = 0.0 if replay else engine.distance_from_snapshot()
             self.outer_deltas.append(amount_updated_Z_current)
 
             if self.minimum_amount_updated_Z > amount_updated_Z_current:
@@ -112,6 +115,11 @@ class Embedder(object):
 
             if self.tolerences['global'].value == 0:  # embeddings are no more updated
                 break
+            # A round whose FIRST sweep already had delta 0 changed nothing at all; the built-in CosineSimilarity is
+            # a deterministic function of Z, so the next round would rebuild the same P and repeat the same sweeps
+            # bit for bit: it is accounted (counts, countdown, printout, history) without being launched.
+            replay = (self.skip_idle_sweeps and isinstance(self.similarity_measure, CosineSimilarity)
+                      and self._round_was_idle and amount_updated_Z_current == 0.0)
         self.flush_history()
 
     def flush_history(self) -> None:
@@ -120,11 +128,13 @@ class Embedder(object):
             self._writer.flush()
 
     @torch.no_grad()
-    def propagate(self):
+    def propagate(self, _replay: bool = False):
         """Jacobi sweeps with P frozen until `tolerence` consecutive sweeps bring no new
-        minimum of the L1 delta (reference embedder.py:71-108)."""
+        minimum of the L1 delta (reference embedder.py:71-108).  `_replay` (iterate() only): the round is known
+        to repeat an all-idle one -- nothing is launched, everything is accounted."""
         engine = self._engine()
-        self._build_P(engine)
+        if not _replay:
+            self._build_P(engine)
         minimum_amount_updated = math.inf
         self.tolerences['propagation'].reset()
         history_Z = []
@@ -132,8 +142,9 @@ class Embedder(object):
         outer = len(self.sweep_counts)
         n_sweeps = 0
 
-        idle = False
+        idle = _replay
         staged = None
+        self._round_was_idle = False
         while True:
             if idle:
                 amount_updated = 0.0
@@ -163,6 +174,8 @@ class Embedder(object):
 
             if self.skip_idle_sweeps and amount_updated == 0.0:
                 idle = True
+                if n_sweeps == 1:
+                    self._round_was_idle = True
             if self.verbose:
                 print(f"{amount_updated:.4f} {self.tolerences['propagation'].value}")
             if self.tolerences['propagation'].value == 0 or (self.max_sweeps and n_sweeps >= self.max_sweeps):
