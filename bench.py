@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--hub-threshold", type=int, default=None)
     ap.add_argument("--no-split-hubs", action="store_true", help="hub rows by one workgroup each (no segment split)")
     ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "columns", "halo", "allgather", "allgather_all"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all"],
                     help="N > 1: auto = columns while a rank's row slice is >= 64 bytes, else halo; columns = every GPU holds d/N columns of every row, no exchange per sweep; the others "
                          "divide the rows and say how updated rows travel (clane_amd/halo.py, partition.py)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -213,8 +213,10 @@ def main():
                        f"(rank 0) of X and Z; no exchange per sweep, one scalar all-reduce (RCCL); build_P all-reduces "
                        f"the {E} partial dot products")
     else:
-        parallelism = (f"row split x{world}, {chunks} launch block(s)/sweep, exchange={eng.exchange} over RCCL per "
-                       f"chunk ({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep) + scalar all-reduce")
+        how = ("stored by the producing kernels straight into the readers' tables (hipIpc peer mappings)" if eng.p2p
+               else f"exchange={eng.exchange} over RCCL per chunk")
+        parallelism = (f"row split x{world}, {chunks} launch block(s)/sweep, {how} "
+                       f"({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep) + scalar all-reduce")
     result = {
         "metric": "embedding-update iters/sec (Jacobi sweeps of Z <- X + gamma*P*Z, P frozen)",
         "value": args.steps / elapsed, "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,

@@ -37,7 +37,13 @@ SIGNATURES = {
     "clane_reduce_ws_len": (_i64, []),
     "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p, _p]),
     "clane_spmm_split_slab_len": (_i64, [_i64, _i32]),
+    "clane_device_alloc": (C.c_int, [_i64, C.POINTER(_p)]),
+    "clane_device_free": (C.c_int, [_p]),
+    "clane_ipc_export": (C.c_int, [_p, _p]),
+    "clane_ipc_open": (C.c_int, [_p, C.POINTER(_p)]),
+    "clane_ipc_close": (C.c_int, [_p]),
 }
+IPC_HANDLE_BYTES = 64
 for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_row_sqnorm_{_s}"] = (C.c_int, [_p, _i64, _i32, _i64, _p, _p])
     SIGNATURES[f"clane_edge_score_{_s}"] = (
@@ -68,20 +74,89 @@ class ClaneHipError(RuntimeError):
 
 
 class _MirrorStruct(C.Structure):       # clane_mirror_t
-    _fields_ = [("row_ptr", _p), ("slot", _p), ("buf", _p), ("ld", _i64)]
+    _fields_ = [("row_ptr", _p), ("slot", _p), ("bufs", _p), ("ld", _i64), ("aligned16", _i32)]
+
+
+MIRROR_ROW_BITS = 28
 
 
 class Mirror:
-    """Second destination of the rows an spmm_update* call finishes (``clane_mirror_t``): row r of the call is
-    also stored at rows ``slot[row_ptr[r]:row_ptr[r+1]]`` of ``buf``.  Holds the tensors alive."""
+    """Further destinations of the rows an spmm_update* call finishes (``clane_mirror_t``): row r of the call is
+    also stored at the places ``slot[row_ptr[r]:row_ptr[r+1]]``, a place being ``buffer << 28 | row`` into
+    ``bufs`` (one tensor, or up to 8 of equal leading dimension -- e.g. other GPUs' tables).  Holds them alive."""
 
-    def __init__(self, row_ptr: torch.Tensor, slot: torch.Tensor, buf: torch.Tensor):
+    def __init__(self, row_ptr: torch.Tensor, slot: torch.Tensor, bufs):
         if row_ptr.dtype != torch.int64 or slot.dtype != torch.int32 or not (row_ptr.is_contiguous()
                                                                              and slot.is_contiguous()):
             raise ValueError("Mirror: row_ptr must be contiguous int64 and slot contiguous int32")
-        self.row_ptr, self.slot, self.buf = row_ptr, slot, buf
-        bp, ld = _mat(buf, "mirror.buf")
-        self.c = _MirrorStruct(row_ptr.data_ptr(), slot.data_ptr(), bp, ld)
+        bufs = [bufs] if isinstance(bufs, torch.Tensor) else list(bufs)
+        if not 1 <= len(bufs) <= 8:
+            raise ValueError("Mirror: 1 to 8 destination buffers")
+        mats = [_mat(b, "mirror buffer") for b in bufs]
+        if len({ld for _, ld in mats}) != 1 or len({b.dtype for b in bufs}) != 1:
+            raise ValueError("Mirror: the buffers must share dtype and leading dimension")
+        if max(b.shape[0] for b in bufs) > (1 << MIRROR_ROW_BITS):
+            raise ValueError("Mirror: a buffer has more than 2^28 rows")
+        self.row_ptr, self.slot, self.bufs = row_ptr, slot, bufs
+        self.buf = bufs[0]
+        self.bases = torch.tensor([ptr for ptr, _ in mats], dtype=torch.int64, device=row_ptr.device)
+        self.c = _MirrorStruct(row_ptr.data_ptr(), slot.data_ptr(), self.bases.data_ptr(), mats[0][1],
+                               int(all(ptr % 16 == 0 for ptr, _ in mats)))
+
+
+class _RawDeviceMemory:
+    """What torch.as_tensor needs to view foreign device memory without copying it."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class DeviceBuffer:
+    """A matrix in device memory that is its OWN allocation (hipMalloc through the C ABI), so that another process
+    can map it (hipIpc works on allocation bases; torch sub-allocates) -- or such a mapping of another process's
+    matrix (`DeviceBuffer.open`).  `.tensor` views it; torch neither owns nor frees it: this object does."""
+
+    def __init__(self, lib, shape, dtype: torch.dtype, device, _mapped_from: Optional[bytes] = None):
+        self.lib, self.shape, self.dtype = lib, tuple(int(x) for x in shape), dtype
+        self.nbytes = max(16, int(torch.empty(0, dtype=dtype).element_size()) * int(torch.Size(self.shape).numel()))
+        self.mapped = _mapped_from is not None
+        ptr = _p()
+        with torch.cuda.device(device):
+            if self.mapped:
+                rc = lib.clane_ipc_open(_mapped_from, C.byref(ptr))
+            else:
+                rc = lib.clane_device_alloc(self.nbytes, C.byref(ptr))
+        if rc != 0:
+            raise ClaneHipError(f"{'clane_ipc_open' if self.mapped else 'clane_device_alloc'} failed ({rc}): "
+                                f"{lib.clane_last_error().decode()}")
+        self.ptr = ptr.value
+        raw = torch.as_tensor(_RawDeviceMemory(self.ptr, self.nbytes), device=torch.device(device))
+        self.tensor = raw[:int(torch.Size(self.shape).numel()) * raw.new_empty(0, dtype=dtype).element_size()] \
+            .view(dtype).view(self.shape)
+        if not self.mapped:
+            self.tensor.zero_()
+
+    def export(self) -> bytes:
+        handle = C.create_string_buffer(IPC_HANDLE_BYTES)
+        rc = self.lib.clane_ipc_export(self.ptr, handle)
+        if rc != 0:
+            raise ClaneHipError(f"clane_ipc_export failed ({rc}): {self.lib.clane_last_error().decode()}")
+        return handle.raw
+
+    @classmethod
+    def open(cls, lib, handle: bytes, shape, dtype: torch.dtype, device) -> "DeviceBuffer":
+        return cls(lib, shape, dtype, device, _mapped_from=handle)
+
+    def close(self) -> None:
+        if self.ptr:
+            (self.lib.clane_ipc_close if self.mapped else self.lib.clane_device_free)(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the process is about to give everything back anyway
+            pass
 
 
 def _mirror_arg(mirror: Optional["Mirror"], dtype: torch.dtype):
@@ -187,6 +262,13 @@ class HipKernels:
 
     def reduce_ws_len(self) -> int:
         return int(self.lib.clane_reduce_ws_len())
+
+    def shareable_matrix(self, shape, dtype: torch.dtype, device) -> DeviceBuffer:
+        """Zero-filled device matrix that other processes can map (DeviceBuffer.export / .open)."""
+        return DeviceBuffer(self.lib, shape, dtype, device)
+
+    def open_shared_matrix(self, handle: bytes, shape, dtype: torch.dtype, device) -> DeviceBuffer:
+        return DeviceBuffer.open(self.lib, handle, shape, dtype, device)
 
     # -- K0 -----------------------------------------------------------------------------
     def row_sqnorm(self, Z: torch.Tensor, d: int, sq: torch.Tensor):

@@ -42,6 +42,23 @@ class TorchComm:
                                          group=self.pg, async_op=async_op)
         return w if async_op else _Done()
 
+    def share_matrices(self, kernels, mine: list) -> list:
+        """`mine`: this rank's DeviceBuffers.  Returns, per rank, tensors viewing that rank's matrices: the
+        rank's own ones, the others mapped into this process through hipIpc (the mappings are kept alive by the
+        returned `keep` list, second value)."""
+        meta = [(b.export(), b.shape) for b in mine]
+        everyone = self.all_gather_object(meta)
+        views, keep = [], []
+        device = mine[0].tensor.device
+        for q, items in enumerate(everyone):
+            if q == self.rank:
+                views.append([b.tensor for b in mine])
+                continue
+            opened = [kernels.open_shared_matrix(h, shape, mine[0].dtype, device) for h, shape in items]
+            keep.extend(opened)
+            views.append([b.tensor for b in opened])
+        return views, keep
+
     def all_gather_object(self, obj) -> list:
         if self.world == 1:
             return [obj]

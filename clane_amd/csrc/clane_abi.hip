@@ -7,6 +7,7 @@
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 
 #include "build_p.h"
 #include "edge_score.h"
@@ -103,10 +104,15 @@ void dispatch_layout(const Layout &L, F &&f) {
 template <typename T>
 Mirror<T> make_mirror(const clane_mirror_t *m) {
     if (m == nullptr || m->row_ptr == nullptr) return Mirror<T>{nullptr, nullptr, nullptr, 0};
-    return Mirror<T>{m->row_ptr, m->slot, reinterpret_cast<T *>(m->buf), m->ld};
+    return Mirror<T>{m->row_ptr, m->slot, reinterpret_cast<T *const *>(m->bufs), m->ld};
+}
+// The bases live in device memory: the caller vouches for their alignment; a mirror that is not 16-byte
+// aligned sends the call down the scalar path (an odd address in the alignment check).
+inline const void *mirror_alignment_probe(const clane_mirror_t *m, const void *aligned) {
+    return (m && m->row_ptr && !m->aligned16) ? reinterpret_cast<const void *>(uintptr_t(1)) : aligned;
 }
 inline bool mirror_ok(const clane_mirror_t *m, int d) {
-    return m == nullptr || m->row_ptr == nullptr || (m->slot != nullptr && m->buf != nullptr && m->ld >= d);
+    return m == nullptr || m->row_ptr == nullptr || (m->slot != nullptr && m->bufs != nullptr && m->ld >= d);
 }
 
 #define REQUIRE(cond, ...) \
@@ -224,7 +230,7 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
     if (nrows == 0) return CLANE_OK;
     REQUIRE(rowptr && colidx && P && Z_old && X && Z_new, "spmm_update: null pointer");
     REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update: Z_new must not alias Z_old (Jacobi sweep)");
-    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror && mirror->row_ptr ? mirror->buf : Z_new},
+    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror_alignment_probe(mirror, Z_new)},
                                     {ldz, ldx, ldo, mirror && mirror->row_ptr ? mirror->ld : ldo});
     const int grid = int(spmm_main_grid(nrows));
     const Mirror<T> mir = make_mirror<T>(mirror);
@@ -254,7 +260,7 @@ int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, 
     REQUIRE(rowptr && colidx && P && long_rows && Z_old && X && Z_new && delta_partials,
             "spmm_update_long: null pointer");
     REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update_long: Z_new must not alias Z_old");
-    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror && mirror->row_ptr ? mirror->buf : Z_new},
+    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror_alignment_probe(mirror, Z_new)},
                                     {ldz, ldx, ldo, mirror && mirror->row_ptr ? mirror->ld : ldo});
     REQUIRE(waves_per_row == 4 || waves_per_row == kLongWaves, "spmm_update_long: waves_per_row must be 4 or 16");
     const Mirror<T> mir = make_mirror<T>(mirror);
@@ -364,6 +370,44 @@ int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long) {
     return spmm_main_grid(nrows > 0 ? nrows : 1) + (n_long > 0 ? n_long : 0);
 }
 int64_t clane_reduce_ws_len(void) { return kReduceWs; }
+
+// ---- device memory that other processes can map (peer-to-peer halo rows) -----------------------------------
+#define HIP_REQUIRE(call, what)                                                                  \
+    do {                                                                                         \
+        const hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                                  \
+            return fail(CLANE_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_));                \
+        }                                                                                        \
+    } while (0)
+
+int clane_device_alloc(int64_t bytes, void **ptr) {
+    REQUIRE(bytes > 0 && ptr, "device_alloc: bad arguments");
+    HIP_REQUIRE(hipMalloc(ptr, size_t(bytes)), "hipMalloc");
+    return CLANE_OK;
+}
+int clane_device_free(void *ptr) {
+    HIP_REQUIRE(hipFree(ptr), "hipFree");
+    return CLANE_OK;
+}
+int clane_ipc_export(void *ptr, void *handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == CLANE_IPC_HANDLE_BYTES, "handle size");
+    REQUIRE(ptr && handle64, "ipc_export: null pointer");
+    hipIpcMemHandle_t h;
+    HIP_REQUIRE(hipIpcGetMemHandle(&h, ptr), "hipIpcGetMemHandle");
+    std::memcpy(handle64, &h, sizeof h);
+    return CLANE_OK;
+}
+int clane_ipc_open(const void *handle64, void **ptr) {
+    REQUIRE(ptr && handle64, "ipc_open: null pointer");
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle64, sizeof h);
+    HIP_REQUIRE(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+    return CLANE_OK;
+}
+int clane_ipc_close(void *ptr) {
+    HIP_REQUIRE(hipIpcCloseMemHandle(ptr), "hipIpcCloseMemHandle");
+    return CLANE_OK;
+}
 
 int clane_row_sqnorm_f32(const float *Z, int64_t nrows, int32_t d, int64_t ldz, float *sq, void *stream) {
     return row_sqnorm<float>(Z, nrows, d, ldz, sq, stream);

@@ -147,15 +147,21 @@ __device__ __forceinline__ void fold_subwaves(A (&acc)[VEC]) {
     }
 }
 
-// Optional second destination of finished rows: row r (relative to the call's first row) is also stored at
-// rows slot[row_ptr[r] .. row_ptr[r+1]) of `buf` -- the send buffer of the multi-GPU halo exchange, packed
-// by the kernel that produces the row instead of by a separate gather pass.  row_ptr == nullptr: none.
+// Optional further destinations of finished rows: row r (relative to the call's first row) is also stored at
+// the places slot[row_ptr[r] .. row_ptr[r+1]); a place is (buffer << 28 | row) into `bufs`, a device array of up
+// to 8 matrix base addresses.  One buffer: the send buffer of the halo exchange, packed by the kernel that
+// produces the row instead of by a separate gather pass.  Several: the other GPUs' own tables, mapped into this
+// process -- the row goes straight over xGMI, no exchange step at all.  row_ptr == nullptr: none.
+constexpr int kMirrorRowBits = 28;
 template <typename T>
 struct Mirror {
     const int64_t *row_ptr;
     const int32_t *slot;
-    T *buf;
+    T *const *bufs;
     int64_t ld;
+    __device__ __forceinline__ T *row(int32_t place) const {
+        return bufs[place >> kMirrorRowBits] + int64_t(place & ((1 << kMirrorRowBits) - 1)) * ld;
+    }
 };
 
 // Epilogue of one row's column tile; returns this lane's share of sum|z_new - z_old|.
@@ -178,7 +184,7 @@ __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC
     store_pack<T, VEC>(dst, out);
     if (mirror.row_ptr != nullptr) {
         for (int64_t s = mirror.row_ptr[row]; s < mirror.row_ptr[row + 1]; ++s)
-            store_pack<T, VEC>(mirror.buf + int64_t(mirror.slot[s]) * mirror.ld + col, out);
+            store_pack<T, VEC>(mirror.row(mirror.slot[s]) + col, out);
     }
     return rsum;
 }
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(kWave) void spmm_split_combine_kernel(
         Znew[r * ldo + c] = out;
         if (mirror.row_ptr != nullptr) {
             for (int64_t m = mirror.row_ptr[r]; m < mirror.row_ptr[r + 1]; ++m)
-                mirror.buf[int64_t(mirror.slot[m]) * mirror.ld + c] = out;
+                mirror.row(mirror.slot[m])[c] = out;
         }
         rsum += fabs(Elem<T>::to_acc(out) - zold);
     }

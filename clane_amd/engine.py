@@ -119,6 +119,8 @@ class SweepEngine:
         is independent per column, so a sweep needs no exchange at all (only the delta scalar is all-reduced);
         build_P all-reduces the partial dot products (E values, once per outer iteration).
         "halo" -- rows are divided; a compact per-rank table, rows sent only to the ranks that read them (halo.py);
+        "halo_p2p" -- the same tables, mapped into every process of the box (hipIpc): the kernel that finishes a row
+        stores it into the tables of the ranks that read it (peer-to-peer over xGMI), there is no exchange step;
         "allgather" -- rows divided, full-size Z on every rank, in-place all-gather of the live rows
         (partition.py); "allgather_all" -- the same without the live/quiet split."""
         if X.dim() != 2 or X.shape[0] != csr.num_vertices:
@@ -134,8 +136,8 @@ class SweepEngine:
         self.comm = comm if comm is not None else (TorchComm(process_group) if process_group is not None else None)
         self.world = self.comm.world if self.comm is not None else 1
         rank = self.comm.rank if self.comm is not None else 0
-        if exchange not in ("auto", "columns", "halo", "allgather", "allgather_all"):
-            raise ValueError("exchange must be 'auto', 'columns', 'halo', 'allgather' or 'allgather_all', "
+        if exchange not in ("auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all"):
+            raise ValueError("exchange must be 'auto', 'columns', 'halo', 'halo_p2p', 'allgather' or 'allgather_all', "
                              f"got {exchange!r}")
         if exchange == "auto":
             exchange = pick_exchange(int(X.shape[1]), X.dtype, self.world)
@@ -153,7 +155,10 @@ class SweepEngine:
         row_world, row_rank = (1, 0) if self.columns else (self.world, rank)
         if chunks is None:
             chunks = 1 if row_world == 1 else 4
-        self.halo = row_world > 1 and exchange == "halo"
+        self.halo = row_world > 1 and exchange in ("halo", "halo_p2p")
+        self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
+        if self.p2p and self.world > 8:
+            raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
         if self.halo:
             self.part = build_halo_layout(csr, self.world, rank, chunks, shuffle=shuffle is not False, seed=seed,
                                           hot_rows_first=hot_rows_first)
@@ -234,7 +239,7 @@ class SweepEngine:
         self.fused_pack = bool(fused_pack) and hasattr(_hip, "Mirror")
         for b in self.blocks:
             ex = b.exchange
-            has = ex is not None and ex.send_rows.size > 0
+            has = ex is not None and ex.send_rows.size > 0 and not self.p2p
             self.send_rows.append(torch.from_numpy(ex.send_rows).to(dev) if has else None)
             self.send_buf.append(torch.zeros(ex.send_rows.size, self.ld, dtype=self.dtype, device=dev) if has
                                  else (torch.zeros(0, self.ld, dtype=self.dtype, device=dev) if ex is not None else None))
@@ -258,7 +263,15 @@ class SweepEngine:
             self.slot = torch.from_numpy(self.part.vertex_slot).to(dev)            # int64 [V]
         else:
             self.pos = torch.from_numpy(self.part.position_of_vertex()).to(dev)    # int64 [V]
-        self.Zbuf = [torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype, device=dev) for _ in range(2)]
+        if self.p2p:        # own allocations that the other processes map; views[q][p] = rank q's table p
+            self._shared = [self.k.shareable_matrix((self.part.padded_vertices, self.ld), self.dtype, dev)
+                            for _ in range(2)]
+            self.Zbuf = [b.tensor for b in self._shared]
+            self.peer_tables, self._mapped = self.comm.share_matrices(self.k, self._shared)
+            self._build_p2p_mirrors(deg)
+        else:
+            self.Zbuf = [torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype, device=dev)
+                         for _ in range(2)]
         self.cur = 0
         Xd = X.to(dev)                                                             # this rank's columns, [V, d]
         verts = torch.from_numpy(self.local.vertex).to(dev)
@@ -288,6 +301,47 @@ class SweepEngine:
         self.time_kernels = False
         self._stage_cv, self._stage_free = threading.Condition(), None      # stage_Z: slots made on first use
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
+
+    def _build_p2p_mirrors(self, deg) -> None:
+        """halo_p2p: for each destination parity and own chunk, where every finished row has to go -- (rank q,
+        row of q's table) for each rank q that reads it.  q's table rows come from q's own layout (the start of
+        the chunk's halo slice and the rows the ranks before me put there), gathered once."""
+        me, W, dev = self.comm.rank, self.world, self.device
+        mine = [(b.exchange.recv_start, list(b.exchange.out_splits)) for b in self.blocks]
+        layouts = self.comm.all_gather_object(mine)
+        self.mirrors_p2p = [[None] * len(self.blocks) for _ in range(2)]
+        for i, b in enumerate(self.blocks):
+            ex = b.exchange
+            if ex.send_rows.size == 0:
+                continue
+            place = np.empty(ex.send_rows.size, dtype=np.int64)
+            off = 0
+            for q in range(W):
+                n = ex.in_splits[q]
+                if n == 0:
+                    continue
+                start_q, from_ranks = layouts[q][i]
+                if from_ranks[me] != n:
+                    raise AssertionError(f"rank {q} expects {from_ranks[me]} rows of chunk {i} from rank {me}, not {n}")
+                base = start_q + sum(from_ranks[:me])
+                place[off:off + n] = (q << _hip.MIRROR_ROW_BITS) | (base + np.arange(n, dtype=np.int64))
+                off += n
+            rel = ex.send_rows.astype(np.int64) - b.local_start
+            if rel.min() < 0 or rel.max() >= b.nrows or (deg[ex.send_rows] == 0).any():
+                raise AssertionError("halo send list holds a row outside its chunk or a row that never changes")
+            row_ptr = np.zeros(b.nrows + 1, dtype=np.int64)
+            np.cumsum(np.bincount(rel, minlength=b.nrows), out=row_ptr[1:])
+            slot = place[np.argsort(rel, kind="stable")].astype(np.int32)
+            rp_d, slot_d = torch.from_numpy(row_ptr).to(dev), torch.from_numpy(slot).to(dev)
+            for parity in range(2):
+                self.mirrors_p2p[parity][i] = self._make_mirror(rp_d, slot_d,
+                                                                [self.peer_tables[q][parity] for q in range(W)])
+
+    def _barrier(self) -> None:
+        """Every rank has got here and its queued device work is done (an all-reduce, then the host waits)."""
+        flag = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._all_reduce(flag)
+        flag.item()
 
     def _make_mirror(self, row_ptr, slot, buf):
         make = getattr(self.k, "make_mirror", None)          # substitute kernels (tests) bring their own
@@ -325,6 +379,8 @@ class SweepEngine:
         self.Zbuf[1].copy_(first)
         self.P_valid = False
         self.quiet_stale = False
+        if self.p2p:        # nobody may store into a table that its owner is still loading
+            self._barrier()
 
     def get_Z(self) -> torch.Tensor:
         """Current embeddings as a fresh CPU tensor [V, d] in vertex order (collective when N > 1)."""
@@ -467,7 +523,8 @@ class SweepEngine:
             ctx = torch.cuda.stream(self.side_streams[i % 2]) if self.side_streams else contextlib.nullcontext()
             with ctx:            # bound calls capture the current stream
                 rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
-                po, mir = self.partial_off[i], self.mirrors[i]
+                po = self.partial_off[i]
+                mir = self.mirrors_p2p[1 - cur][i] if self.p2p else self.mirrors[i]
                 po_mid = po + k.spmm_partials_len(b.nrows, 0)
                 po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
                 po_split = po_hub + (0 if self.hub_rows[i] is None else self.hub_rows[i].numel())
@@ -498,7 +555,7 @@ class SweepEngine:
                 steps.append(("event", i, 3))
                 if b.span is not None:
                     steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))
-                elif b.exchange is not None:  # halo: pack the rows of this chunk that others read, swap, no unpack
+                elif b.exchange is not None and not self.p2p:  # halo: the rows others read are packed; swap, no unpack
                     ex = b.exchange
                     if self.send_rows[i] is not None and mir is None:
                         steps.append(("call", self._bind("gather_rows", Znew, self.send_rows[i], self.d,

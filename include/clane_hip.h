@@ -55,15 +55,19 @@ extern "C" {
 /* flags of clane_spmm_update_* */
 #define CLANE_SPMM_SINKS_UNTOUCHED 1
 
-/* Optional second destination of the rows a clane_spmm_update* call finishes: row r (relative to the call's
- * first row) is also stored at rows slot[row_ptr[r] .. row_ptr[r+1]) of `buf` (leading dimension ld, same
- * element type as Z_new).  This is how the send buffer of the multi-GPU halo exchange gets packed by the kernel
- * that produces a row instead of by a separate gather pass.  NULL, or row_ptr == NULL: no mirror. */
+/* Optional further destinations of the rows a clane_spmm_update* call finishes: row r (relative to the call's
+ * first row) is also stored at the places slot[row_ptr[r] .. row_ptr[r+1]); a place is (buffer << 28 | row) into
+ * `bufs`, a DEVICE array of up to 8 matrix base addresses (leading dimension ld, element type of Z_new).
+ * One buffer: the send buffer of the multi-GPU halo exchange gets packed by the kernel that produces a row
+ * instead of by a separate gather pass.  Several: the other GPUs' tables mapped into this process (IPC) -- rows
+ * go straight over xGMI.  aligned16: the caller vouches that every base is 16-byte aligned (the library cannot
+ * look into device memory); 0 selects the scalar path.  NULL, or row_ptr == NULL: no mirror. */
 typedef struct {
     const int64_t *row_ptr; /* [rows of the call + 1] */
     const int32_t *slot;
-    void *buf;
+    void *const *bufs;
     int64_t ld;
+    int32_t aligned16;
 } clane_mirror_t;
 
 int clane_abi_version(void);
@@ -73,6 +77,20 @@ const char *clane_last_error(void);
 int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long);
 /* Doubles of scratch needed by clane_degree_weighted_sums_* / clane_pair_cosine_*. */
 int64_t clane_reduce_ws_len(void);
+
+/* ---- Device memory that another process can map.  Everything else in this library works on memory the caller
+ * owns; these five exist because a halo table that other GPUs store into (clane_mirror_t with several buffers)
+ * must be its own allocation (hipIpcGetMemHandle works on allocation bases) and must be opened with peer access
+ * from the device that is current in the calling process.  No reference counterpart (one process upstream).
+ *   clane_device_alloc / _free : hipMalloc / hipFree on the current device.
+ *   clane_ipc_export(ptr, handle)  : handle = CLANE_IPC_HANDLE_BYTES bytes to hand to the other process.
+ *   clane_ipc_open(handle, &ptr)   : map it (hipIpcMemLazyEnablePeerAccess); clane_ipc_close(ptr) unmaps. */
+#define CLANE_IPC_HANDLE_BYTES 64
+int clane_device_alloc(int64_t bytes, void **ptr);
+int clane_device_free(void *ptr);
+int clane_ipc_export(void *ptr, void *handle64);
+int clane_ipc_open(const void *handle64, void **ptr);
+int clane_ipc_close(void *ptr);
 
 /* ---- K0: sq[v] = sum_k Z[v,k]^2.  Replaces the two `pow(2).sum()` of similarity.py:37
  * (together with clane_degree_weighted_sums_*). */

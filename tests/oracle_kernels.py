@@ -67,8 +67,14 @@ class OracleKernels:
             if rp[r + 1] - rp[r] > min_degree:
                 vals[rp[r]:rp[r + 1]] = torch.softmax(vals[rp[r]:rp[r + 1]], 0)
 
-    def make_mirror(self, row_ptr, slot, buf):
-        return (row_ptr, slot, buf)
+    def make_mirror(self, row_ptr, slot, bufs):
+        return (row_ptr, slot, [bufs] if isinstance(bufs, torch.Tensor) else list(bufs))
+
+    def shareable_matrix(self, shape, dtype, device):
+        class _Plain:                       # same process: nothing to map
+            def __init__(self):
+                self.tensor, self.shape, self.dtype = torch.zeros(shape, dtype=dtype, device=device), tuple(shape), dtype
+        return _Plain()
 
     def _spmm_rows(self, rowptr, colidx, P, rows_sel, row0, Z_old, X, gamma, Z_new, d, mirror=None):
         rp = _np(rowptr)
@@ -84,9 +90,9 @@ class OracleKernels:
                 new = own.clone()
             Z_new[r, :d] = new
             if mirror is not None:
-                mp, ms, mb = mirror
+                mp, ms, mbs = mirror
                 for s in ms[int(mp[r]):int(mp[r + 1])].tolist():
-                    mb[s, :d] = new
+                    mbs[s >> 28][s & ((1 << 28) - 1), :d] = new
             total += float((new.to(acc) - own.to(acc)).abs().sum())
         return total
 

@@ -492,7 +492,8 @@ def test_powerlaw_generator_and_bf16_sweep(dev):
 
 @pytest.mark.parametrize("exchange,world,fused,d", [
     ("columns", 4, True, 256), ("columns", 3, True, 256), ("columns", 4, True, 6), ("columns", 2, True, 100),
-    ("halo", 4, True, 256), ("halo", 3, True, 256), ("halo", 4, False, 256), ("allgather", 4, True, 256)])
+    ("halo", 4, True, 256), ("halo", 3, True, 256), ("halo", 4, False, 256), ("allgather", 4, True, 256),
+    ("halo_p2p", 4, True, 256), ("halo_p2p", 3, True, 100)])
 def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, fused, d):
     """W ranks as threads of this process, all on cuda:0, collectives through tests/thread_comm.py: the column
     split (even, uneven 64 packs / 3, ranks without columns at d=6, ragged d=100) and the halo / all-gather row
@@ -516,6 +517,7 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
                 eng = SweepEngine(csr, X, dev, comm=shared.comm(rank), chunks=3, exchange=exchange, seed=4,
                                   fused_pack=fused, cosine_mode=("per_edge" if d == 100 else "reference"))
                 assert any(m is not None for m in eng.mirrors) == (fused and exchange == "halo")
+                assert eng.p2p == (exchange == "halo_p2p")
                 eng.build_P()
                 P_local = eng.P[:eng.E_loc].cpu()
                 deltas = [eng.sweep(gamma) for _ in range(3)]
@@ -538,7 +540,7 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
         P_all[torch.from_numpy(origin)] = P_local
         assert (nbytes == 0) if exchange == "columns" else (0 < nbytes < (world - 1) * -(-V // world) * d * 4 + 1)
     assert rel(P_all, P_or) < 1e-5
-    if exchange == "halo":                                          # the point of the halo: fewer bytes than all rows
+    if exchange in ("halo", "halo_p2p"):                            # the point of the halo: fewer bytes than all rows
         assert results[0][4] < 0.8 * (world - 1) * (V // world) * d * 4
 
 
@@ -622,8 +624,11 @@ def test_spmm_mirror_packs_send_buffer(dev, k, dtype, d, pad):
     order = np.argsort(rows_of_slot, kind="stable").astype(np.int32)
     row_ptr = np.zeros(V + 1, dtype=np.int64)
     np.cumsum(copies, out=row_ptr[1:])
-    buf = torch.full((rows_of_slot.size, Zo.shape[1]), 7.0, dtype=dtype, device=dev)
-    mir = _hip.Mirror(torch.from_numpy(row_ptr).to(dev), torch.from_numpy(order).to(dev), buf)
+    # two destination buffers (as with peer tables): slot k lives in buffer k % 2, row k // 2
+    buf = torch.full((2, (rows_of_slot.size + 1) // 2, Zo.shape[1]), 7.0, dtype=dtype, device=dev)
+    place = ((order % 2) << _hip.MIRROR_ROW_BITS) | (order // 2)
+    mir = _hip.Mirror(torch.from_numpy(row_ptr).to(dev), torch.from_numpy(place.astype(np.int32)).to(dev),
+                      [buf[0], buf[1]])
     is_split, is_long = deg > seg, deg > T
     to_dev = lambda m: torch.from_numpy(np.nonzero(m)[0].astype(np.int32)).to(dev)  # noqa: E731
     rows_s = np.nonzero(is_split)[0]
@@ -648,9 +653,10 @@ def test_spmm_mirror_packs_send_buffer(dev, k, dtype, d, pad):
     Z_ref, _ = O.sweep(csr.rowptr, csr.colidx, P.cpu().double(), X.double(), Zold.double(), gamma)
     assert rel(Zn[:, :d], Z_ref) < TOL[dtype]
     assert rows_of_slot.size > V and is_split.sum() >= 2 and mid.sum() >= 2
-    assert torch.equal(buf[:, :d], Zn[torch.from_numpy(rows_of_slot).to(dev), :d])
+    k_of = torch.arange(rows_of_slot.size, device=dev)
+    assert torch.equal(buf[k_of % 2, k_of // 2][:, :d], Zn[torch.from_numpy(rows_of_slot).to(dev), :d])
     # an incomplete descriptor is refused on the host
-    bad = _hip.Mirror(mir.row_ptr, mir.slot, buf)
+    bad = _hip.Mirror(mir.row_ptr, mir.slot, buf[0])
     bad.c.slot = None
     with pytest.raises(_hip.ClaneHipError, match="mirror"):
         k.spmm_update(rowptr, colidx, P, V, 0, Zo, Xd, gamma, Zn, d, T, partials, mirror=bad)
@@ -783,6 +789,32 @@ def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
     assert r2["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
     for r in (r1, r2):
         assert r["steps"] == 4 and r["warmup"] == 2 and r["value"] > 0 and r["roofline"]["bound"] == "hbm"
+
+
+def test_bench_halo_p2p_two_processes_share_tables_through_ipc(tmp_path):
+    """exchange="halo_p2p" with two real processes on this box's GPU: each maps the other's tables with hipIpc
+    (clane_ipc_export / clane_ipc_open) and its kernels store finished rows straight into them."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    common = ["--workload", "tiny", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"] + common, capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", "2",
+                          "--backend", "gloo", "--share-gpu", "--exchange", "halo_p2p"] + common, capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert two.returncode == 0, two.stderr[-3000:]
+    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "hipIpc" in r2["config"]["parallelism"]
+    assert r2["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
 
 
 def test_cli_two_processes_on_one_gpu_match_one_process(tmp_path):

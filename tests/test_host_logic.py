@@ -285,6 +285,48 @@ def test_idle_sweeps_are_accounted_but_not_launched(tmp_path):
         assert len(ha) == len(hb) and all(torch.equal(x, y) for x, y in zip(ha, hb))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_p2p_places_rows_in_the_readers_tables(tmp_path, world):
+    """exchange="halo_p2p" on CPU: ranks as threads, each engine's kernels (the oracle-backed double) store finished
+    rows into the OTHER engines' tables through the places the layouts of all ranks imply; no exchange call is
+    made during sweeps, and every rank reproduces the single-process oracle."""
+    import threading
+    from .thread_comm import ThreadWorld
+    gold, g = graph_from_golden(tmp_path, "g5_symkarate_d16_g0.76.npz")
+    X = torch.from_numpy(gold["X"])
+    P_or = O.build_P_values(g.csr.rowptr, g.csr.colidx, X)
+    Z_or, deltas_or = X.clone(), []
+    for _ in range(4):
+        Z_or, dl = O.sweep(g.csr.rowptr, g.csr.colidx, P_or, X, Z_or, 0.76)
+        deltas_or.append(float(dl))
+    shared, results, errors = ThreadWorld(world), [None] * world, []
+
+    def run(rank):
+        try:
+            comm = shared.comm(rank)
+            calls = []
+            real = comm.all_to_all_rows
+            comm.all_to_all_rows = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            eng = SweepEngine(g.csr, X, "cpu", OracleKernels(), comm=comm, chunks=2, exchange="halo_p2p", seed=5)
+            assert eng.p2p and eng.halo and all(b is None or b.shape[0] == 0 for b in eng.send_buf)
+            eng.build_P()
+            deltas = [eng.sweep(0.76) for _ in range(4)]
+            results[rank] = (eng.get_Z(), deltas, len(calls))
+        except Exception as exc:
+            errors.append((rank, exc))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for Z, deltas, n_exchanges in results:
+        assert n_exchanges == 0 and O.rel_l2(Z, Z_or) < 1e-6
+        assert deltas == pytest.approx(deltas_or, rel=1e-5)
+
+
 def test_history_sink_receives_every_sweep_in_order(tmp_path):
     """Embedder(history_sink=...): the same embeddings as history["Z"], streamed (outer, sweep, Z) in order from
     the writer thread and not retained; a failing sink surfaces at flush."""

@@ -17,7 +17,20 @@ class NullComm:
     def all_reduce_sum(self, t): pass
     def all_gather_into(self, out, inp, async_op=False): return bench_done
     def all_to_all_rows(self, out, inp, o, i, async_op=False): return bench_done
-    def all_gather_object(self, obj): return [obj] * self.world
+    def all_gather_object(self, obj):
+        return self.layouts if self.layouts is not None else [obj] * self.world
+    layouts = None
+    def share_matrices(self, kernels, mine):
+        """halo_p2p timed on one GPU: the other ranks' tables are stand-ins in LOCAL memory of the sizes those
+        ranks would have, so the kernels issue exactly the stores they would send over xGMI."""
+        views = []
+        for q in range(self.world):
+            if q == self.rank:
+                views.append([b.tensor for b in mine])
+            else:
+                views.append([torch.zeros(self.table_rows[q], mine[0].shape[1], dtype=mine[0].dtype,
+                                          device=mine[0].tensor.device) for _ in range(2)])
+        return views, []
 
 
 class _Done:
@@ -41,7 +54,14 @@ gen, V, E, d, dname, gseed, xseed = bench.WORKLOADS[args.workload]
 csr = synth.rmat_csr(V, E, seed=gseed) if gen == "rmat" else synth.powerlaw_csr(V, E, seed=gseed)
 X = synth.gaussian_X(V, d, seed=xseed).to(bench.DTYPES[dname])
 for W in args.world:
-    eng = SweepEngine(csr, X, dev, comm=NullComm(W), chunks=args.chunks, exchange=args.exchange,
+    comm = NullComm(W)
+    if args.exchange == "halo_p2p":       # the layouts the other ranks would publish
+        from clane_amd.halo import build_halo_layout
+        lays = [build_halo_layout(csr, W, q, args.chunks, hot_rows_first=not args.natural_order) for q in range(W)]
+        comm.layouts = [[(b.exchange.recv_start, list(b.exchange.out_splits)) for b in lay.blocks] for lay in lays]
+        comm.table_rows = [lay.table_rows for lay in lays]
+        del lays
+    eng = SweepEngine(csr, X, dev, comm=comm, chunks=args.chunks, exchange=args.exchange,
                       hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs, overlap_chunks=not args.no_overlap,
                       fused_pack=not args.no_fused_pack)
     eng.build_P()
