@@ -89,7 +89,7 @@ class Mirror:
         if row_ptr.dtype != torch.int64 or slot.dtype != torch.int32 or not (row_ptr.is_contiguous()
                                                                              and slot.is_contiguous()):
             raise ValueError("Mirror: row_ptr must be contiguous int64 and slot contiguous int32")
-        bufs = [bufs] if isinstance(bufs, torch.Tensor) else list(bufs)
+        bufs = [bufs] if isinstance(bufs, (torch.Tensor, PeerMatrix)) else list(bufs)
         if not 1 <= len(bufs) <= 8:
             raise ValueError("Mirror: 1 to 8 destination buffers")
         mats = [_mat(b, "mirror buffer") for b in bufs]
@@ -111,6 +111,24 @@ class _RawDeviceMemory:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
+class PeerMatrix:
+    """Address + shape of a row-major matrix in ANOTHER process's (GPU's) memory, mapped here.  Not a torch tensor
+    on purpose: torch would attribute it to the owning device; only kernels of this library touch it, by address."""
+
+    def __init__(self, ptr: int, shape, dtype: torch.dtype):
+        self._ptr, self.shape, self.dtype = ptr, tuple(shape), dtype
+
+    def data_ptr(self) -> int:
+        return self._ptr
+
+    def dim(self) -> int:
+        return len(self.shape)
+
+    def stride(self, i: Optional[int] = None):
+        st = (self.shape[1], 1)
+        return st if i is None else st[i]
+
+
 class DeviceBuffer:
     """A matrix in device memory that is its OWN allocation (hipMalloc through the C ABI), so that another process
     can map it (hipIpc works on allocation bases; torch sub-allocates) -- or such a mapping of another process's
@@ -130,10 +148,12 @@ class DeviceBuffer:
             raise ClaneHipError(f"{'clane_ipc_open' if self.mapped else 'clane_device_alloc'} failed ({rc}): "
                                 f"{lib.clane_last_error().decode()}")
         self.ptr = ptr.value
-        raw = torch.as_tensor(_RawDeviceMemory(self.ptr, self.nbytes), device=torch.device(device))
-        self.tensor = raw[:int(torch.Size(self.shape).numel()) * raw.new_empty(0, dtype=dtype).element_size()] \
-            .view(dtype).view(self.shape)
-        if not self.mapped:
+        if self.mapped:
+            self.tensor = PeerMatrix(self.ptr, self.shape, dtype)
+        else:
+            raw = torch.as_tensor(_RawDeviceMemory(self.ptr, self.nbytes), device=torch.device(device))
+            n = int(torch.Size(self.shape).numel()) * torch.empty(0, dtype=dtype).element_size()
+            self.tensor = raw[:n].view(dtype).view(self.shape)
             self.tensor.zero_()
 
     def export(self) -> bytes:

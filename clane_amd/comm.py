@@ -43,9 +43,9 @@ class TorchComm:
         return w if async_op else _Done()
 
     def share_matrices(self, kernels, mine: list) -> list:
-        """`mine`: this rank's DeviceBuffers.  Returns, per rank, tensors viewing that rank's matrices: the
-        rank's own ones, the others mapped into this process through hipIpc (the mappings are kept alive by the
-        returned `keep` list, second value)."""
+        """`mine`: this rank's DeviceBuffers.  Returns, per rank, that rank's matrices: tensors for the rank's own,
+        `PeerMatrix` addresses for the others, mapped into this process through hipIpc (the mappings are kept
+        alive by the returned `keep` list, second value)."""
         meta = [(b.export(), b.shape) for b in mine]
         everyone = self.all_gather_object(meta)
         views, keep = [], []
