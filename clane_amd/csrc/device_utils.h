@@ -61,6 +61,34 @@ __device__ __forceinline__ void store_pack(T *p, const Pack<T, VEC> &v) {
     *reinterpret_cast<Pack<T, VEC> *>(p) = v;
 }
 
+// Data touched once per sweep (a row's own x / z_old, the z_new it writes): with CLANE_NT_STREAM these accesses
+// are marked non-temporal so that they do not push gathered rows out of L2 / the Infinity Cache.
+#ifndef CLANE_NT_STREAM
+#define CLANE_NT_STREAM 0          // bit 0: streamed loads, bit 1: streamed stores
+#endif
+typedef uint32_t clane_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> load_pack_stream(const T *p) {
+    if constexpr ((CLANE_NT_STREAM & 1) && sizeof(Pack<T, VEC>) == 16) {
+        const clane_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const clane_u32x4 *>(p));
+        Pack<T, VEC> out;
+        __builtin_memcpy(&out, &v, 16);
+        return out;
+    } else {
+        return load_pack<T, VEC>(p);
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_pack_stream(T *p, const Pack<T, VEC> &v) {
+    if constexpr ((CLANE_NT_STREAM & 2) && sizeof(Pack<T, VEC>) == 16) {
+        clane_u32x4 w;
+        __builtin_memcpy(&w, &v, 16);
+        __builtin_nontemporal_store(w, reinterpret_cast<clane_u32x4 *>(p));
+    } else {
+        store_pack<T, VEC>(p, v);
+    }
+}
+
 // ---- wave64 cross-lane -------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 

@@ -181,7 +181,7 @@ __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC
         out.v[k] = Elem<T>::from_acc(znew);
         rsum += fabs(Elem<T>::to_acc(out.v[k]) - zold);
     }
-    store_pack<T, VEC>(dst, out);
+    store_pack_stream<T, VEC>(dst, out);
     if (mirror.row_ptr != nullptr) {
         for (int64_t s = mirror.row_ptr[row]; s < mirror.row_ptr[row + 1]; ++s)
             store_pack<T, VEC>(mirror.row(mirror.slot[s]) + col, out);
@@ -261,8 +261,8 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
                 const bool writer = col_ok && sub == 0;
                 Pack<T, VEC> x{}, zo{};
                 if (writer) {
-                    x = load_pack<T, VEC>(X + r * ldx + c0);
-                    zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
+                    x = load_pack_stream<T, VEC>(X + r * ldx + c0);
+                    zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
                 }
                 A acc[VEC];
 #pragma unroll
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
                     e_next = e0;
                     e_end = e0 + dg;
                     if (col_ok) {
-                        x = load_pack<T, VEC>(X + r * ldx + c0);
-                        zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
+                        x = load_pack_stream<T, VEC>(X + r * ldx + c0);
+                        zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
                     }
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[k] = A(0);
@@ -479,8 +479,8 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
         const bool writer = wave == 0 && col_ok && sub == 0;
         Pack<T, VEC> x{}, zo{};
         if (writer) {  // requested before the gathers, consumed after the fold
-            x = load_pack<T, VEC>(X + r * ldx + c0);
-            zo = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
+            x = load_pack_stream<T, VEC>(X + r * ldx + c0);
+            zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
         }
         A acc[VEC];
 #pragma unroll
