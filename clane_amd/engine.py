@@ -188,6 +188,8 @@ class SweepEngine:
         # ---- graph structure ----------------------------------------------------------
         self.rowptr = torch.from_numpy(self.local.rowptr).to(dev)
         self.colidx = torch.from_numpy(self.local.colidx).to(dev)
+        if self.colidx.numel() == 0:       # a graph without edges: the ABI still wants a real pointer
+            self.colidx = torch.zeros(1, dtype=torch.int32, device=dev)
         self.indeg = torch.from_numpy(self.local.indeg).to(dev)
         self.E_loc = int(self.local.colidx.shape[0])
         self.P = torch.zeros(max(self.E_loc, 1), dtype=self.acc_dtype, device=dev)

@@ -226,6 +226,65 @@ def test_spmm_update_vs_oracle(dev, k, dtype, d, pad, long_threshold, waves):
     assert torch.equal(Zn2[:, :d], Zn[:, :d]) and torch.equal(partials, partials2)
 
 
+def test_k3_and_k1_random_shapes(dev, k):
+    """60 seeded random cases -- V from 1 to 700 (fewer rows than a workgroup's block, than a wave's sub-waves;
+    block boundaries), d from 1 to 320, all dtypes, degree mixes from all-empty to all-long, any long threshold --
+    K3 with sinks untouched and K1 + fused softmax against the oracle.  Shapes the sub-wave kernels schedule
+    differently (rows claimed per sub-wave) must not change a result."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        dtype = [torch.float32, torch.float64, torch.bfloat16][case % 3]
+        V = int(rng.choice([1, 2, 3, 7, 8, 9, 31, 32, 33, 64, 100, 257, 700]))
+        d = int(rng.choice([1, 3, 4, 8, 12, 16, 24, 32, 40, 64, 100, 128, 160, 256, 320]))
+        style = case % 4
+        max_deg = [0, 3, 40, min(V, 120)][style]
+        hubs = () if style < 2 else tuple(int(h) for h in rng.integers(1, V + 1, size=3))
+        csr = ragged_csr(V, seed=1000 + case, max_deg=min(max_deg, V), hubs=hubs, empty_frac=[1.0, 0.3, 0.2, 0.0][style])
+        T = int(rng.choice([0, 1, 8, 48, 1000]))
+        acc, gamma = _hip.acc_dtype(dtype), 0.6
+        X = synth.gaussian_X(V, d, seed=case).to(dtype)
+        Zold = (synth.gaussian_X(V, d, seed=case + 7) * 0.5).to(dtype)
+        Xd, Zo = padded(X, dtype, dev), padded(Zold, dtype, dev)
+        rowptr, colidx = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+        if colidx.numel() == 0:                # the ABI wants real pointers even when rowptr says "no edges"
+            colidx = torch.zeros(1, dtype=torch.int32, device=dev)
+        deg = np.diff(csr.rowptr)
+        long_rows = torch.from_numpy(np.nonzero(deg > T)[0].astype(np.int32)).to(dev) if T else None
+        n_long = 0 if long_rows is None else long_rows.numel()
+        tag = f"case {case}: V={V} d={d} {dtype} style={style} T={T} E={csr.num_edges}"
+        # K1 + softmax (reference mode needs nonzero norms: Zold is random)
+        sq = torch.empty(V, dtype=acc, device=dev)
+        k.row_sqnorm(Zo, d, sq)
+        sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
+        k.degree_weighted_sums(sq, rowptr, torch.from_numpy(csr.indeg()).to(dev), V,
+                               torch.zeros(k.reduce_ws_len(), dtype=torch.float64, device=dev), sums2)
+        P = torch.full((max(csr.num_edges, 1),), float("nan"), dtype=acc, device=dev)
+        if csr.num_edges:
+            k.edge_score(rowptr, colidx, V, 0, Zo, d, _hip.SCORE_REFERENCE, sums2, None, P, T,
+                         long_rows if n_long else None, fuse_softmax=True)
+            if n_long:
+                k.segment_softmax(rowptr, V, P, 64, 64, long_rows)
+            P_ref = O.build_P_values(csr.rowptr, csr.colidx, Zold.to(acc).double())
+            assert rel(P[:csr.num_edges], P_ref) < max(TOL[dtype], 1e-6) if dtype != torch.bfloat16 else 1e-4, tag
+        else:
+            P.zero_()
+        # K3
+        Zn = Zo.clone()
+        partials = torch.zeros(k.spmm_partials_len(V, n_long), dtype=torch.float64, device=dev)
+        k.spmm_update(rowptr, colidx, P, V, 0, Zo, Xd, gamma, Zn, d, T, partials, sinks_untouched=True)
+        if n_long:
+            k.spmm_update_long(rowptr, colidx, P, long_rows, 16, 0, Zo, Xd, gamma, Zn, d,
+                               partials[k.spmm_partials_len(V, 0):])
+        Z_ref, _ = O.sweep(csr.rowptr, csr.colidx, P[:csr.num_edges].cpu().double(), X.double(), Zold.double(), gamma)
+        got = Zn[:, :d].cpu()
+        assert rel(got, Z_ref) < TOL[dtype], tag
+        assert float(Zn[:, d:].abs().sum()) == 0.0, tag
+        out = torch.zeros(1, dtype=torch.float64, device=dev)
+        k.reduce_partials(partials, partials.numel(), torch.zeros(k.reduce_ws_len(), dtype=torch.float64, device=dev), out)
+        want = float((got.double() - Zold.double()).abs().sum())
+        assert float(out) == pytest.approx(want, rel=1e-6, abs=1e-12), tag
+
+
 def test_spmm_row_block_with_row0_offset(dev, k):
     """A rank's row block: local rowptr/X/Z_new, global columns, row0 != 0."""
     csr = ragged_csr(400, seed=9, hubs=(300,))
@@ -542,6 +601,18 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
     assert rel(P_all, P_or) < 1e-5
     if exchange in ("halo", "halo_p2p"):                            # the point of the halo: fewer bytes than all rows
         assert results[0][4] < 0.8 * (world - 1) * (V // world) * d * 4
+
+
+def test_graph_without_edges(dev):
+    """No edge at all (only reachable through Graph.from_csr: the reference's loader rejects an empty E file):
+    nothing ever changes, every delta is 0, the countdowns run out, Z stays X."""
+    csr = HostCSR(5, np.zeros(6, dtype=np.int64), np.zeros(0, dtype=np.int32))
+    X = synth.gaussian_X(5, 8, seed=1)
+    g = Graph.from_csr(csr, X)
+    assert g.build_P(CosineSimilarity()).values().numel() == 0
+    emb = Embedder(g, CosineSimilarity(), dev, tolerence=3, verbose=False)
+    emb.iterate()
+    assert torch.equal(g.Z, X) and emb.outer_deltas[-1] == 0.0 and emb.sweep_counts[0] == 4
 
 
 def test_edge_cases_single_vertex_and_nan_termination(tmp_path):
