@@ -327,6 +327,64 @@ def test_halo_p2p_places_rows_in_the_readers_tables(tmp_path, world):
         assert deltas == pytest.approx(deltas_or, rel=1e-5)
 
 
+def test_every_division_on_random_graphs():
+    """24 seeded random graphs (with empty rows, hubs, vertices nobody reads) x world 2..5 x 1..4 chunks x every way
+    of dividing the work -- ranks as threads, oracle-backed kernels: build_P, three sweeps and the read-out agree
+    with the single-process oracle on every rank."""
+    import threading
+    from .thread_comm import ThreadWorld
+    rng = np.random.default_rng(77)
+    modes = ["columns", "halo", "halo_p2p", "allgather", "allgather_all"]
+    for case in range(24):
+        V = int(rng.integers(6, 60))
+        world, chunks, mode = int(rng.integers(2, 6)), int(rng.integers(1, 5)), modes[case % len(modes)]
+        d = int(rng.choice([3, 8, 20]))
+        deg = rng.integers(0, min(V, 9), size=V)
+        deg[rng.random(V) < 0.25] = 0
+        deg[int(rng.integers(V))] = V                                    # one hub that points at everybody
+        cols = [np.sort(rng.choice(V, size=k, replace=False)) for k in deg]
+        rowptr = np.zeros(V + 1, dtype=np.int64)
+        np.cumsum(deg, out=rowptr[1:])
+        csr = HostCSR(V, rowptr, np.concatenate(cols + [np.empty(0, int)]).astype(np.int32))
+        X = torch.from_numpy(rng.standard_normal((V, d)).astype(np.float32))
+        P_or = O.build_P_values(csr.rowptr, csr.colidx, X)
+        Z_or, deltas_or = X.clone(), []
+        for _ in range(3):
+            Z_or, dl = O.sweep(csr.rowptr, csr.colidx, P_or, X, Z_or, 0.7)
+            deltas_or.append(float(dl))
+        shared, results, errors = ThreadWorld(world), [None] * world, []
+
+        def run(rank):
+            try:
+                eng = SweepEngine(csr, X, "cpu", OracleKernels(), comm=shared.comm(rank), chunks=chunks, exchange=mode,
+                                  seed=case)
+                eng.build_P()
+                P_mine = torch.zeros(csr.num_edges)
+                P_mine[torch.from_numpy(eng.local.edge_origin)] = eng.P[:eng.E_loc]
+                owned = torch.zeros(csr.num_edges, dtype=torch.bool)
+                owned[torch.from_numpy(eng.local.edge_origin)] = True
+                deltas = [eng.sweep(0.7) for _ in range(3)]
+                results[rank] = (eng.get_Z(), deltas, P_mine, owned)
+            except Exception as exc:
+                errors.append((rank, exc))
+                shared.barrier.abort()
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+        tag = f"case {case}: V={V} world={world} chunks={chunks} {mode} d={d}"
+        assert not errors, (tag, errors)
+        covered = torch.zeros(csr.num_edges, dtype=torch.int32)
+        for Z, deltas, P_mine, owned in results:
+            assert O.rel_l2(Z, Z_or) < 2e-6, tag
+            assert deltas == pytest.approx(deltas_or, rel=1e-5), tag
+            assert torch.allclose(P_mine[owned], P_or[owned].float(), rtol=1e-5, atol=1e-7), tag
+            covered += owned.int()
+        assert bool((covered >= 1).all()), tag                           # every edge's P is held by some rank
+
+
 def test_history_sink_receives_every_sweep_in_order(tmp_path):
     """Embedder(history_sink=...): the same embeddings as history["Z"], streamed (outer, sweep, Z) in order from
     the writer thread and not retained; a failing sink surfaces at flush."""
