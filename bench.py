@@ -106,7 +106,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
-    dev = _hip.require_gpu("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
+    # one visible device per rank (a launcher that masks HIP_VISIBLE_DEVICES per process): it is cuda:0 there
+    masked = torch.cuda.device_count() == 1 and world > 1
+    dev = _hip.require_gpu("cuda:0" if (args.share_gpu or masked) else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     pg = None
     if world > 1:

@@ -30,6 +30,8 @@ def _distributed_setup():
         return 0, 1
     import torch.distributed as dist
     local_rank = 0 if os.environ.get("CLANE_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() == 1:              # the launcher masked the devices per process
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if not dist.is_initialized():
         if os.environ.get("CLANE_DIST_BACKEND", "nccl") == "gloo":
