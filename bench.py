@@ -32,6 +32,8 @@ WORKLOADS = {
     "rmat200k": ("rmat", 200_000, 4_000_000, 128, "f32", 1, 2),       # BASELINE config 2
     "powerlaw10m": ("powerlaw", 10_000_000, 200_000_000, 128, "bf16", 5, 6),   # BASELINE config 4 (shape)
     "tiny": ("rmat", 20_000, 200_000, 64, "f32", 7, 8),
+    # 8x config 3: a 16 GiB embedding matrix (byte offsets beyond 32 bits, ~85 GB of HBM in use) -- capacity check
+    "rmat16m": ("rmat", 16_000_000, 320_000_000, 256, "f32", 9, 10),
 }
 DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "f64": torch.float64}
 PARITY_TOL = {"f32": 1e-4, "f64": 1e-10, "bf16": 8e-3}       # bf16: 2^-8 rounding of every stored value
