@@ -90,6 +90,9 @@ def main():
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (RCCL refuses that: use --backend gloo)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="opt-in (SURVEY H5): launch sweep t+1 before the host has read sweep t's delta "
+                         "(SweepEngine.sweep_launch / sweep_wait); every delta is still read, one sweep later")
     ap.add_argument("--iterate", action="store_true",
                     help="after the timed sweeps also run the WHOLE algorithm from Z = X -- Embedder.iterate() to "
                          "tolerance (build_P + propagate per outer round) -- and report rounds, sweeps, wall time")
@@ -175,8 +178,16 @@ def main():
     eng.kernel_events = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        delta = eng.sweep(args.gamma)
+    if args.pipelined:
+        ticket = eng.sweep_launch(args.gamma)
+        for _ in range(args.steps - 1):
+            following = eng.sweep_launch(args.gamma)
+            delta = eng.sweep_wait(ticket)
+            ticket = following
+        delta = eng.sweep_wait(ticket)
+    else:
+        for _ in range(args.steps):
+            delta = eng.sweep(args.gamma)
     barrier()
     elapsed = time.perf_counter() - t0
     eng.time_kernels = False
@@ -229,7 +240,9 @@ def main():
         "config": {"workload": f"{'R-MAT' if gen == 'rmat' else 'power-law'} |V|={V} |E|={E} d={d} {dname}, "
                                f"gamma={args.gamma}, CosineSimilarity "
                                f"(reference mode), seeds {gseed}/{xseed}",
-                   "parallelism": parallelism},
+                   "parallelism": parallelism,
+                   "host_sync": ("pipelined: the delta of sweep t is read while sweep t+1 runs" if args.pipelined
+                                 else "after every sweep (reference semantics)")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": per_kernel[dom]["frac"], "traffic": traffic,
                      "algorithmic_bytes_per_launch": per_kernel[dom]["algorithmic_bytes_per_launch"],

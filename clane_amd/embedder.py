@@ -36,6 +36,7 @@ class Embedder(object):
         max_sweeps:         Optional[int] = None,
         history_sink:       Optional[Callable[[int, int, torch.Tensor], None]] = None,
         skip_idle_sweeps:   bool = True,
+        lagged_check:       bool = False,
     ) -> None:
         self.graph = graph
         self.similarity_measure = similarity_measure
@@ -63,6 +64,10 @@ class Embedder(object):
         # 0 too.  Such sweeps are accounted (tolerance countdown, printout, history) without being launched -- at
         # the fp32 fixed point the reference's rule still asks for `tolerence` sweeps in each of `tolerence` rounds.
         self.skip_idle_sweeps = skip_idle_sweeps
+        # lagged_check (opt-in): the next sweep is launched before the host has read this sweep's delta,
+        # so the GPU never waits for the host.  The stopping rule is unchanged: when it says stop, the sweep launched
+        # ahead is discarded (the ping-pong partner still holds the right embeddings).  Off with save_history.
+        self.lagged_check = lagged_check
         self.sweeps_launched = 0
         self._round_was_idle = False
         # history_sink(outer, sweep, Z): with save_history, every sweep's embeddings are handed to it from a
@@ -145,9 +150,18 @@ class Embedder(object):
         idle = _replay
         staged = None
         self._round_was_idle = False
+        ahead = self.lagged_check and not self.save_history and hasattr(engine, "sweep_launch")
+        ticket = None                               # the launched sweep whose delta has not been read yet
+        if ahead and not idle:
+            ticket = engine.sweep_launch(self.gamma)
+            self.sweeps_launched += 1
         while True:
             if idle:
                 amount_updated = 0.0
+            elif ahead:
+                following = engine.sweep_launch(self.gamma)         # runs while the host reads and decides
+                amount_updated = engine.sweep_wait(ticket)
+                ticket = following
             else:
                 amount_updated = engine.sweep(self.gamma)
                 self.sweeps_launched += 1
@@ -172,10 +186,17 @@ class Embedder(object):
             else:
                 self.tolerences['propagation'].endure()
 
+            stop = self.tolerences['propagation'].value == 0 or bool(self.max_sweeps and n_sweeps >= self.max_sweeps)
             if self.skip_idle_sweeps and amount_updated == 0.0:
                 idle = True
                 if n_sweeps == 1:
                     self._round_was_idle = True
+            if ahead and ticket is not None:
+                if stop or idle:                    # the sweep launched ahead is not wanted
+                    engine.discard_launch()
+                    ticket = None
+                else:
+                    self.sweeps_launched += 1
             if self.verbose:
                 print(f"{amount_updated:.4f} {self.tolerences['propagation'].value}")
             if self.tolerences['propagation'].value == 0 or (self.max_sweeps and n_sweeps >= self.max_sweeps):

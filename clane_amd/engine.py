@@ -288,6 +288,13 @@ class SweepEngine:
         self.ws = torch.zeros(self.k.reduce_ws_len(), dtype=torch.float64, device=dev)
         self.sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
         self.delta = torch.zeros(1, dtype=torch.float64, device=dev)
+        # per ping-pong parity: the sweep's delta on the device, its copy in pinned host memory, the copy's event
+        self.delta_pp = torch.zeros(2, dtype=torch.float64, device=dev)
+        self._delta_host = torch.zeros(2, dtype=torch.float64)
+        self._delta_ev = None
+        if self.device.type == "cuda":
+            self._delta_host = self._delta_host.pin_memory()
+            self._delta_ev = [torch.cuda.Event() for _ in range(2)]
         self.block_out = torch.zeros(len(self.blocks), dtype=torch.float64, device=dev)
         self.sq_loc = torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev)
         self.sq_full: Optional[torch.Tensor] = None
@@ -565,18 +572,27 @@ class SweepEngine:
                     steps.append(("alltoall", Znew[ex.recv_start:ex.recv_start + ex.recv_rows], self.send_buf[i],
                                   ex.out_splits, ex.in_splits))
             per_block.append(steps)
-        final = self._bind("reduce_partials", self.partials, self.partials.numel(), self.ws, self.delta)
+        final = self._bind("reduce_partials", self.partials, self.partials.numel(), self.ws,
+                           self.delta_pp[cur:cur + 1])
         return per_block, final
 
     def sweep(self, gamma: float) -> float:
         """Z <- X + gamma * P Z on the owned rows, exchange, return sum|Z_new - Z_old| (global)."""
+        return self.sweep_wait(self.sweep_launch(gamma))
+
+    def sweep_launch(self, gamma: float) -> int:
+        """Enqueue one sweep (kernels, exchange, delta reduction, all-reduce, copy of the delta to pinned host
+        memory) and return a ticket for ``sweep_wait``.  Nothing blocks the host, so the NEXT sweep can be
+        launched before this one's delta is read: it reads the buffer this one writes, and if the host
+        then decides to stop, ``discard_launch()`` drops it -- the ping-pong partner still holds this sweep's Z."""
         if not self.P_valid:
             raise RuntimeError("sweep() before build_P()")
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-        key = (self.cur, float(gamma), stream)
+        parity = self.cur
+        key = (parity, float(gamma), stream)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._plans[key] = self._build_plan(self.cur, float(gamma))
+            plan = self._plans[key] = self._build_plan(parity, float(gamma))
         events = None
         if self.time_kernels:
             events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in self.blocks]
@@ -610,13 +626,30 @@ class SweepEngine:
                 done.record(st)
                 main.wait_event(done)
         final()
-        self._all_reduce(self.delta)
+        mine = self.delta_pp[parity:parity + 1]
+        self._all_reduce(mine)
         for w in works:
             w.wait()
+        self._delta_host[parity:parity + 1].copy_(mine, non_blocking=True)
+        if self._delta_ev is not None:
+            self._delta_ev[parity].record()
         self.cur = 1 - self.cur
         self.sweeps_done += 1
         self.quiet_stale = True
-        return float(self.delta.item())
+        return parity
+
+    def sweep_wait(self, ticket: int) -> float:
+        """The delta of the sweep `ticket` came from (blocks until its copy has landed)."""
+        if self._delta_ev is not None:
+            self._delta_ev[ticket].synchronize()
+        return float(self._delta_host[ticket])
+
+    def discard_launch(self) -> None:
+        """Forget the most recent ``sweep_launch`` (a sweep launched ahead of a stop decision): the current
+        embeddings are again those of the sweep before it.  What it wrote sits in the buffer the next real sweep
+        overwrites; rows without out-edges were not touched by it either."""
+        self.cur = 1 - self.cur
+        self.sweeps_done -= 1
 
     def kernel_times_ms(self):
         """{'split','hub','mid','main'} -> ms per SWEEP (summed over the blocks, averaged over the recorded

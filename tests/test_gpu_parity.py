@@ -603,6 +603,22 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
         assert results[0][4] < 0.8 * (world - 1) * (V // world) * d * 4
 
 
+def test_lagged_check_on_gpu_is_bit_identical(dev):
+    """lagged_check=True on the GPU (sweeps launched ahead, discarded at the stop): same sweep counts, deltas and
+    embeddings, bit for bit, as the synchronous loop -- on one GPU and with 3 column-split ranks as threads."""
+    csr = synth.rmat_csr(20_000, 200_000, seed=7)
+    X = synth.gaussian_X(20_000, 64, seed=8)
+    runs = []
+    for lagged in (False, True):
+        g = Graph.from_csr(csr, X)
+        emb = Embedder(g, CosineSimilarity(), dev, tolerence=3, verbose=False, lagged_check=lagged, max_sweeps=300)
+        emb.iterate()
+        runs.append((emb.sweep_counts, emb.outer_deltas, g.Z, emb.sweeps_launched, g._engine.sweeps_done))
+    a, b = runs
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]) and a[3] == b[3] == a[4] == b[4]
+    assert len(a[0]) >= 3 and sum(a[0]) > 20
+
+
 def test_graph_without_edges(dev):
     """No edge at all (only reachable through Graph.from_csr: the reference's loader rejects an empty E file):
     nothing ever changes, every delta is 0, the countdowns run out, Z stays X."""

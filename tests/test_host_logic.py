@@ -385,6 +385,25 @@ def test_every_division_on_random_graphs():
         assert bool((covered >= 1).all()), tag                           # every edge's P is held by some rank
 
 
+@pytest.mark.parametrize("name", ["g5_symkarate_d16_g0.5.npz", "g4_karate_d2.npz", "g7_readme5.npz"])
+def test_lagged_check_keeps_the_stopping_rule(tmp_path, name):
+    """Embedder(lagged_check=True): the next sweep is launched before this sweep's delta is read, and dropped when
+    the rule says stop.  Same counts, deltas, printout and embeddings as the synchronous loop, bit for bit."""
+    runs = []
+    for lagged in (False, True):
+        gold, g = graph_from_golden(tmp_path / str(lagged), name)
+        eng = attach_cpu_engine(g)
+        emb = Embedder(g, CosineSimilarity(), torch.device("cpu"), gamma=float(gold["gamma"]), tolerence=4,
+                       lagged_check=lagged)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            emb.iterate()
+        runs.append((emb.sweep_counts, emb.outer_deltas, buf.getvalue(), g.Z, emb.sweeps_launched, eng.sweeps_done))
+    a, b = runs
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and torch.equal(a[3], b[3])
+    assert a[4] == b[4] == a[5] == b[5]                # discarded launches are not counted as sweeps
+
+
 def test_history_sink_receives_every_sweep_in_order(tmp_path):
     """Embedder(history_sink=...): the same embeddings as history["Z"], streamed (outer, sweep, Z) in order from
     the writer thread and not retained; a failing sink surfaces at flush."""
