@@ -984,3 +984,22 @@ def test_config3_full_size_properties(dev):
     live = ~sink                                               # rows without out-edges return z itself: F(z) = z
     assert O.rel_l2(lhs[live], rhs[live]) < 1e-5
     assert torch.equal(lhs[sink], (Za - Zb)[sink])
+
+
+def test_integration_stub_from_the_docs_runs(tmp_path):
+    """INTEGRATION.md section B, executed as written (only the library path is made absolute): the ctypes stub a
+    reference maintainer would add drives one sweep through the C ABI and matches the oracle."""
+    import re
+    root = Path(__file__).resolve().parent.parent
+    text = (root / "INTEGRATION.md").read_text()
+    code = re.search(r"```python\n(# clane/_hip_backend.py.*?)```", text, flags=re.S).group(1)
+    code = code.replace('C.CDLL("libclane_hip.so")', f'C.CDLL("{_hip.LIB_PATH}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    gold, g = graph_from_golden(tmp_path, "g5_symkarate_d16_g0.76.npz")
+    state = ns["HipState"](g)
+    P_or = O.build_P_values(g.csr.rowptr, g.csr.colidx, g.X)
+    state.P.copy_(P_or.float())
+    delta = state.sweep(0.76)
+    Z_or, d_or = O.sweep(g.csr.rowptr, g.csr.colidx, P_or, g.X, g.X, 0.76)
+    assert O.rel_l2(state.Z[state.cur].cpu(), Z_or) < 1e-6 and delta == pytest.approx(float(d_or), rel=1e-5)
