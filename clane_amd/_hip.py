@@ -24,7 +24,6 @@ ABI_VERSION = 1
 SCORE_REFERENCE, SCORE_PER_EDGE, SCORE_RAW_DOT = 0, 1, 2
 SPMM_SINKS_UNTOUCHED = 1
 SCORE_FUSE_SOFTMAX = 1
-FUSED_SOFTMAX_MAX_DEGREE = 64
 SCORE_MODES = {"reference": SCORE_REFERENCE, "per_edge": SCORE_PER_EDGE, "raw_dot": SCORE_RAW_DOT}
 
 _p, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32

@@ -57,13 +57,15 @@ __device__ __forceinline__ A finalize_score(A dot, int mode, A D, A nsrc, const 
 // Scores of edges [ea, eb) of the row whose source is global row `src_row` (a whole row, or one
 // wave's slice of a long row).  `softmax`: [ea, eb) is a WHOLE row -- normalise it (in registers when it
 // fits one 64-edge chunk, else with a running max / sum and a second pass over the stored scores).
-// Must be called by all 64 lanes.
+// `stats` (a slice of a long row): leave the raw scores and hand back {max, sum of exp(score - max)} of the
+// slice, for the workgroup to combine.  Must be called by all 64 lanes.
 template <typename T, int VEC, int LPR, int U>
 __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ colidx, int64_t ea, int64_t eb,
                                                  int64_t src_row, const T *__restrict__ Z, int64_t ldz, int d,
                                                  int mode, typename Elem<T>::acc_t D,
                                                  const typename Elem<T>::acc_t *__restrict__ sq,
-                                                 typename Elem<T>::acc_t *__restrict__ scores, bool softmax) {
+                                                 typename Elem<T>::acc_t *__restrict__ scores, bool softmax,
+                                                 typename Elem<T>::acc_t *stats = nullptr) {
     using A = typename Elem<T>::acc_t;
     constexpr int EPW = kWave / LPR;
     constexpr bool kTransposed = (U == 8 && LPR >= 8);
@@ -143,7 +145,7 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
             const A got = lane_get(serve, src);
             if (take) mine = got;
         }
-        if (softmax) {  // graph.py:122-123; running max / sum over the row's chunks (online softmax)
+        if (softmax || stats) {  // graph.py:122-123; running max / sum over the row's chunks (online softmax)
             const bool in = lane < n;
             const A v = in ? mine : -A(INFINITY);
             const A new_m = fmax(run_m, group_max<kWave>(v));
@@ -151,12 +153,16 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
             const A cs = group_sum<kWave>(ex);
             run_s = run_s * exp_acc<A>(run_m - new_m) + cs;
             run_m = new_m;
-            if (eb - ea <= kWave) mine = ex / cs;  // the whole row is in this chunk: finished in registers
+            if (softmax && eb - ea <= kWave) mine = ex / cs;  // the whole row is in this chunk: finished in registers
         }
         if (lane < n) scores[e + lane] = mine;
     }
     if (softmax && eb - ea > kWave) {  // second pass over this wave's own stores (each lane re-reads what it wrote)
         for (int64_t e = ea + lane; e < eb; e += kWave) scores[e] = exp_acc<A>(scores[e] - run_m) / run_s;
+    }
+    if (stats) {
+        stats[0] = run_m;
+        stats[1] = run_s;
     }
 }
 
@@ -272,7 +278,9 @@ __global__ __launch_bounds__(kBlock) void edge_score_subrow_kernel(
 }
 
 // One workgroup of WAVES waves per long row: wave w scores the 64-aligned slice w (same slicing as
-// spmm_long_kernel); a wave with an empty slice leaves at once.  Edges are independent: no fold.
+// spmm_long_kernel); a wave with an empty slice leaves at once.  Edges are independent: no fold.  With
+// `fuse_softmax` the row is soft-maxed here too: every wave keeps {max, sum exp} of its slice, the workgroup
+// combines them through LDS in wave order, and each wave rescales the scores it stored itself.
 template <typename T, int VEC, int LPR, int U, int WAVES>
 __global__ __launch_bounds__(WAVES *kWave) void edge_score_long_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const int32_t *__restrict__ long_rows,
@@ -280,17 +288,33 @@ __global__ __launch_bounds__(WAVES *kWave) void edge_score_long_kernel(
     const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores,
     bool fuse_softmax) {
     using A = typename Elem<T>::acc_t;
+    __shared__ A s_max[WAVES], s_sum[WAVES];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int64_t r = long_rows[blockIdx.x];
     const int64_t e0 = rowptr[r];
     const int64_t e1 = rowptr[r + 1];
     const int64_t seg = ceil_div(ceil_div(e1 - e0, WAVES), kWave) * kWave;
     const int64_t a = e0 + wave * seg;
-    if (a >= e1) return;
+    if (a >= e1) return;  // gfx9 s_barrier waits only for waves that have not terminated
     const int64_t b = a + seg < e1 ? a + seg : e1;
     const A D = global_denominator<A>(mode, sums2);
+    const bool whole_row_here = e1 - e0 <= kWave;
+    const bool combine = fuse_softmax && !whole_row_here;
+    A stats[2];
     score_edge_range<T, VEC, LPR, U>(colidx, a, b, row0 + r, Z, ldz, d, mode, D, sq, scores,
-                                     fuse_softmax && e1 - e0 <= kWave);
+                                     fuse_softmax && whole_row_here, combine ? stats : nullptr);
+    if (!combine) return;
+    if (lane_id() == 0) {
+        s_max[wave] = stats[0];
+        s_sum[wave] = stats[1];
+    }
+    __syncthreads();
+    const int active = int(ceil_div(e1 - e0, seg));
+    A m = s_max[0];
+    for (int w = 1; w < active; ++w) m = fmax(m, s_max[w]);
+    A total = A(0);
+    for (int w = 0; w < active; ++w) total += s_sum[w] * exp_acc<A>(s_max[w] - m);
+    for (int64_t e = a + lane_id(); e < b; e += kWave) scores[e] = exp_acc<A>(scores[e] - m) / total;
 }
 
 }  // namespace clane

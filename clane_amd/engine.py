@@ -484,12 +484,9 @@ class SweepEngine:
         if self.E_loc > 0 and not self.columns:
             for i, b in enumerate(self.blocks):
                 rp = self.rowptr[b.local_start:]
+                # K1 soft-maxes every row it scores: one wave in registers / online, a listed row by its workgroup
                 k.edge_score(rp, self.colidx, b.nrows, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
                              self.long_threshold, self.long_rows[i], fuse_softmax=True)
-                # K1 soft-maxed every row it scored with one wave; listed rows of > 64 edges: one workgroup each
-                if self.long_rows[i] is not None and self.max_degree > _hip.FUSED_SOFTMAX_MAX_DEGREE:
-                    k.segment_softmax(rp, b.nrows, self.P, _hip.FUSED_SOFTMAX_MAX_DEGREE,
-                                      _hip.FUSED_SOFTMAX_MAX_DEGREE, self.long_rows[i])
         elif self.E_loc > 0:
             # column split: dot products of the owned columns, summed over the GPUs, then denominators + softmax
             if busy:

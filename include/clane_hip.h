@@ -116,9 +116,9 @@ int clane_degree_weighted_sums_f64(const double *sq, const int64_t *rowptr, cons
  * Rows with more than `long_threshold` edges (0 = never) are cut into per-wave slices by a
  * second launch over `long_rows` (local row ids, n_long of them; one 16-wave workgroup per row);
  * pass n_long = 0 to have every row walked by a single wave.
- * flags & CLANE_SCORE_FUSE_SOFTMAX: every row scored by a single wave -- all rows of <= long_threshold
- * edges and listed rows of <= 64 edges -- is soft-maxed by this call (graph.py:122-123); the remaining
- * listed rows are finished by clane_segment_softmax_*(min_degree = 64, max_degree = 64, long_rows). */
+ * flags & CLANE_SCORE_FUSE_SOFTMAX: every row this call scores is soft-maxed by it as well (graph.py:122-123):
+ * a row walked by one wave in registers or with a running max / sum, a listed row by its workgroup ({max, sum}
+ * per wave combined through LDS in wave order).  No clane_segment_softmax_* call is needed afterwards. */
 int clane_edge_score_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0, const float *Z,
                          int64_t ldz, int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
                          int32_t flags, int64_t long_threshold, const int32_t *long_rows, int64_t n_long, void *stream);
@@ -142,7 +142,8 @@ int clane_edge_score_finalize_f64(const int64_t *rowptr, const int32_t *colidx, 
  * loop of graph.py:122-123.  Rows with min_degree < deg <= max_degree (max_degree 0 = no upper
  * limit) are normalised by one wave each; the rows listed in `long_rows` (deg > min_degree) by one
  * 16-wave workgroup each.  Empty rows are skipped; max_degree <= min_degree (both > 0) disables the
- * one-wave pass.  After clane_edge_score_* with CLANE_SCORE_FUSE_SOFTMAX pass min_degree = max_degree = 64. */
+ * one-wave pass.  Not needed after clane_edge_score_* with CLANE_SCORE_FUSE_SOFTMAX; used after
+ * clane_edge_score_finalize_* and for plug-in scores. */
 int clane_segment_softmax_f32(const int64_t *rowptr, int64_t nrows, float *vals, int64_t min_degree,
                               int64_t max_degree, const int32_t *long_rows, int64_t n_long, void *stream);
 int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals, int64_t min_degree,

@@ -44,10 +44,9 @@ class OracleKernels:
         elif mode == 1:
             dots = dots / (sq[rows].sqrt() * sq[cols].sqrt())
         scores[rp[0]:rp[-1]] = dots
-        if fuse_softmax:      # every row scored by one wave: <= long_threshold, and listed rows of <= 64 edges
+        if fuse_softmax:      # every row the call scores
             for r in range(nrows):
-                dg = rp[r + 1] - rp[r]
-                if dg > 0 and (dg <= 64 or long_threshold == 0 or dg <= long_threshold):
+                if rp[r + 1] > rp[r]:
                     scores[rp[r]:rp[r + 1]] = torch.softmax(scores[rp[r]:rp[r + 1]], 0)
 
     def edge_score_finalize(self, rowptr, colidx, nrows, row0, mode, sums2, sq, scores):

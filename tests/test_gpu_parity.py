@@ -262,8 +262,6 @@ def test_k3_and_k1_random_shapes(dev, k):
         if csr.num_edges:
             k.edge_score(rowptr, colidx, V, 0, Zo, d, _hip.SCORE_REFERENCE, sums2, None, P, T,
                          long_rows if n_long else None, fuse_softmax=True)
-            if n_long:
-                k.segment_softmax(rowptr, V, P, 64, 64, long_rows)
             P_ref = O.build_P_values(csr.rowptr, csr.colidx, Zold.to(acc).double())
             assert rel(P[:csr.num_edges], P_ref) < max(TOL[dtype], 1e-6) if dtype != torch.bfloat16 else 1e-4, tag
         else:
@@ -495,7 +493,7 @@ def test_spmm_sinks_untouched_flag(dev, k):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.bfloat16])
 @pytest.mark.parametrize("d,pad", [(2, True), (16, True), (128, True), (256, True), (1433, True), (37, False)])
 def test_edge_score_fused_softmax(dev, k, dtype, d, pad):
-    """K1 with CLANE_SCORE_FUSE_SOFTMAX (+ K2 over rows > 64 edges) == K1 raw + K2 over every row."""
+    """K1 with CLANE_SCORE_FUSE_SOFTMAX (every row, listed long rows included) == K1 raw + K2 over every row."""
     csr = ragged_csr(400, seed=d + 7, max_deg=70, hubs=(64, 65, 200, 1))
     V, acc = csr.num_vertices, _hip.acc_dtype(dtype)
     Zc = synth.gaussian_X(V, d, seed=5).to(dtype)
@@ -510,8 +508,8 @@ def test_edge_score_fused_softmax(dev, k, dtype, d, pad):
         k.segment_softmax(rowptr, V, two_pass)
         fused = torch.zeros_like(two_pass)
         k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_PER_EDGE, None, sq, fused, lt, lr, fuse_softmax=True)
-        k.segment_softmax(rowptr, V, fused, 64, 64, lr)     # one-wave pass off; listed rows > 64: workgroup per row
-        # same scores, same softmax up to the reduction order (in-register / running max-sum / K2's three passes)
+        # same scores, same softmax up to the reduction order (in-register / running max-sum per wave combined by
+        # the workgroup / K2's three passes)
         assert rel(fused, two_pass) < (1e-14 if dtype == torch.float64 else 3e-7)
         assert float((fused - two_pass).abs().max()) < (1e-14 if dtype == torch.float64 else 2e-7)
     ref = O.build_P_values(csr.rowptr, csr.colidx, Zc.to(acc).double(), mode="per_edge")
