@@ -36,7 +36,10 @@ int check_launch(const char *what) {
 
 constexpr int kReduceGrid = 1024;              // partial blocks of the two-stage reductions
 constexpr int64_t kReduceWs = 2 * kReduceGrid + 2;  // + the two finished sums
-constexpr int kLongWaves = 16;
+#ifndef CLANE_LONG_WAVES
+#define CLANE_LONG_WAVES 16         // waves of the workgroup-per-row kernels (A/B builds: 8)
+#endif
+constexpr int kLongWaves = CLANE_LONG_WAVES;
 #ifndef CLANE_ROWS_PER_BLOCK
 #define CLANE_ROWS_PER_BLOCK 32   // minimum consecutive rows per workgroup of the row kernels
 #endif
@@ -262,7 +265,7 @@ int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, 
     REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update_long: Z_new must not alias Z_old");
     const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror_alignment_probe(mirror, Z_new)},
                                     {ldz, ldx, ldo, mirror && mirror->row_ptr ? mirror->ld : ldo});
-    REQUIRE(waves_per_row == 4 || waves_per_row == kLongWaves, "spmm_update_long: waves_per_row must be 4 or 16");
+    REQUIRE(waves_per_row == 4 || waves_per_row == 16, "spmm_update_long: waves_per_row must be 4 or 16");
     const Mirror<T> mir = make_mirror<T>(mirror);
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
