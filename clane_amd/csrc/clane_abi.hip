@@ -36,6 +36,9 @@ int check_launch(const char *what) {
 
 constexpr int kReduceGrid = 1024;              // partial blocks of the two-stage reductions
 constexpr int64_t kReduceWs = 2 * kReduceGrid + 2;  // + the two finished sums
+#ifndef CLANE_LONG_U
+#define CLANE_LONG_U CLANE_SPMM_U    // neighbour-row loads in flight per wave of the workgroup-per-row kernels
+#endif
 #ifndef CLANE_LONG_WAVES
 #define CLANE_LONG_WAVES 16         // waves of the workgroup-per-row kernels (A/B builds: 8)
 #endif
@@ -268,7 +271,7 @@ int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, 
     REQUIRE(waves_per_row == 4 || waves_per_row == 16, "spmm_update_long: waves_per_row must be 4 or 16");
     const Mirror<T> mir = make_mirror<T>(mirror);
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
-        constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
+        constexpr int U = VEC > 1 ? CLANE_LONG_U : 4;
         if (waves_per_row == 4)
             spmm_long_kernel<T, PT, VEC, LPR, U, 4><<<int(n_long), 4 * kWave, 0, (hipStream_t)stream>>>(
                 rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
@@ -299,7 +302,7 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
     const Layout L = pick_layout<T>(d, {Z_old, X, Z_new}, {ldz, ldx, ldo});
     const int64_t ld_slab = ceil_div(d, 4) * 4;
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
-        constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
+        constexpr int U = VEC > 1 ? CLANE_LONG_U : 4;
         spmm_split_segment_kernel<T, PT, VEC, LPR, U, kLongWaves>
             <<<unsigned(n_segments), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
                 rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, Z_old, ldz, d, slab, ld_slab);
