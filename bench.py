@@ -136,7 +136,19 @@ def main():
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
         if any(e != everyone[0] for e in everyone):
-            raise SystemExit(f"ranks disagree on the synthetic input: {everyone}")
+            # should not happen (counter-based RNG, same seed, same GPU model); if it does, rank 0's input wins
+            log(f"ranks disagree on the synthetic input ({everyone}): broadcasting rank 0's graph and X")
+            from clane_amd.partition import HostCSR
+            n_edges = torch.tensor([csr.num_edges], dtype=torch.int64, device=dev)
+            dist.broadcast(n_edges, 0)
+            rp = torch.from_numpy(csr.rowptr).to(dev)
+            ci = torch.from_numpy(csr.colidx).to(dev) if rank == 0 else torch.empty(int(n_edges), dtype=torch.int32,
+                                                                                    device=dev)
+            Xd = X.to(dev)
+            for t in (rp, ci, Xd):
+                dist.broadcast(t, 0)
+            csr, X = HostCSR(V, rp.cpu().numpy(), ci.cpu().numpy()), Xd.cpu()
+            E = csr.num_edges
     log(f"{args.workload}: |V|={V} |E|={csr.num_edges} d={d} max outdeg={int(np.diff(csr.rowptr).max())} "
         f"generated in {time.perf_counter() - t0:.1f}s")
 
