@@ -124,6 +124,8 @@ def main():
         pg = dist.group.WORLD
 
     gen, V, E, d, dname, gseed, xseed = WORKLOADS[args.workload]
+    if os.environ.get("CLANE_BENCH_PERTURB_RANK") == str(rank) and world > 1:
+        gseed += 1000           # test hook: this rank draws a different graph, the agreement check must repair it
     t0 = time.perf_counter()
     if gen == "rmat":
         csr = synth.rmat_csr(V, E, seed=gseed, device=str(dev))
