@@ -111,3 +111,12 @@ def test_three_rank_gloo(tmp_path, exchange):
     mp.spawn(_worker, args=(world, _free_port(), 2, "g5_symkarate_d16_g0.5.npz", str(tmp_path), exchange), nprocs=world,
              join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_eight_rank_gloo_columns_with_idle_ranks(tmp_path):
+    """The driver's largest case, rehearsed on CPU: 8 ranks, column split of a d=16 matrix (4 packs: ranks 4-7 hold
+    no column and only join the collectives) -- same collective sequence on every rank, same result."""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), 1, "g5_symkarate_d16_g0.76.npz", str(tmp_path), "columns"),
+             nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
