@@ -62,7 +62,7 @@ def main():
         summary[k] = {"fetch_bytes": fb, "write_bytes": wb, "avg_us_under_pmc": us}
     (out / f"{args.tag}_pmc_traffic_{args.workload}.md").write_text("\n".join(lines) + "\n")
     def bench_name(k):       # names used by bench.py's roofline.kernels
-        if "spmm_update_kernel" in k:
+        if "spmm_update_kernel" in k or "spmm_update_subrow_kernel" in k:
             return "spmm_update_kernel"
         if "spmm_split_segment_kernel" in k:
             return "spmm_split_segment_kernel+combine"
