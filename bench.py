@@ -233,7 +233,11 @@ def main():
     traffic = None
     tfile = ROOT / "profiles" / "traffic.json"
     if tfile.exists():
-        traffic = json.loads(tfile.read_text()).get(f"{args.workload}_n{world}", {}).get(dom, {}).get("bytes_per_launch")
+        table = json.loads(tfile.read_text())
+        entry = table.get(f"{args.workload}_n{world}")
+        if entry is None and world > 1 and eng.columns:     # measured on one GPU over the same column slice
+            entry = table.get(f"{args.workload}_column_slice_of_{world}")
+        traffic = (entry or {}).get(dom, {}).get("bytes_per_launch")
 
     if world == 1:
         parallelism = f"1 GPU, {chunks} launch block(s)/sweep"
