@@ -172,6 +172,9 @@ class SweepEngine:
                                             seed=seed, priority=hot)
             self.blocks = self.part.blocks()
             self.local = localize(csr, self.part, self.device)
+        if self.part.padded_vertices >= 2 ** 31:
+            raise ValueError(f"{self.part.padded_vertices} table rows: column indices are 32-bit (ABI v1); divide the "
+                             "rows over more GPUs (exchange='halo') or wait for 64-bit indices")
         if long_threshold is None:
             rows_per_wave = 64 // lanes_per_row(self.d, X.dtype)
             long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
