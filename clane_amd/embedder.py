@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import collections
 import math
+import time
 import queue
 import threading
 from typing import Callable, Optional
@@ -21,6 +22,8 @@ from .similarity import CosineSimilarity, Similarity
 
 
 class Embedder(object):
+    LAGGED_BELOW_S = 1e-3
+
     def __init__(
         self,
         graph:              Graph,
@@ -36,7 +39,7 @@ class Embedder(object):
         max_sweeps:         Optional[int] = None,
         history_sink:       Optional[Callable[[int, int, torch.Tensor], None]] = None,
         skip_idle_sweeps:   bool = True,
-        lagged_check:       bool = False,
+        lagged_check:       Optional[bool] = None,
     ) -> None:
         self.graph = graph
         self.similarity_measure = similarity_measure
@@ -64,9 +67,12 @@ class Embedder(object):
         # 0 too.  Such sweeps are accounted (tolerance countdown, printout, history) without being launched -- at
         # the fp32 fixed point the reference's rule still asks for `tolerence` sweeps in each of `tolerence` rounds.
         self.skip_idle_sweeps = skip_idle_sweeps
-        # lagged_check (opt-in): the next sweep is launched before the host has read this sweep's delta,
-        # so the GPU never waits for the host.  The stopping rule is unchanged: when it says stop, the sweep launched
-        # ahead is discarded (the ping-pong partner still holds the right embeddings).  Off with save_history.
+        # lagged_check: the next sweep is launched before the host has read this sweep's delta, so the
+        # GPU never waits for the host.  The stopping rule is unchanged: when it says stop, the sweep launched ahead
+        # is discarded (the ping-pong partner still holds the right embeddings) -- counts, deltas and embeddings are
+        # bit-identical either way.  It costs one discarded sweep per propagate and saves the host round trip of
+        # every sweep, so it pays when sweeps are short.  None (default): on one GPU, switched on inside a propagate
+        # once a sweep has taken less than LAGGED_BELOW_S; True / False: always / never.  Off with save_history.
         self.lagged_check = lagged_check
         self.sweeps_launched = 0
         self._round_was_idle = False
@@ -150,7 +156,10 @@ class Embedder(object):
         idle = _replay
         staged = None
         self._round_was_idle = False
-        ahead = self.lagged_check and not self.save_history and hasattr(engine, "sweep_launch")
+        can_lag = not self.save_history and hasattr(engine, "sweep_launch")
+        ahead = bool(self.lagged_check) and can_lag
+        auto = self.lagged_check is None and can_lag and getattr(engine, "world", 1) == 1
+        fastest = math.inf                          # shortest synchronous sweep seen in this propagate (auto mode)
         ticket = None                               # the launched sweep whose delta has not been read yet
         if ahead and not idle:
             ticket = engine.sweep_launch(self.gamma)
@@ -163,7 +172,9 @@ class Embedder(object):
                 amount_updated = engine.sweep_wait(ticket)
                 ticket = following
             else:
+                t_sweep = time.perf_counter()
                 amount_updated = engine.sweep(self.gamma)
+                fastest = min(fastest, time.perf_counter() - t_sweep)
                 self.sweeps_launched += 1
             n_sweeps += 1
             if self.save_history:
@@ -197,6 +208,10 @@ class Embedder(object):
                     ticket = None
                 else:
                     self.sweeps_launched += 1
+            elif auto and not ahead and not stop and not idle and n_sweeps >= 2 and fastest < self.LAGGED_BELOW_S:
+                ahead = True                        # short sweeps: from here on launch one ahead
+                ticket = engine.sweep_launch(self.gamma)
+                self.sweeps_launched += 1
             if self.verbose:
                 print(f"{amount_updated:.4f} {self.tolerences['propagation'].value}")
             if self.tolerences['propagation'].value == 0 or (self.max_sweeps and n_sweeps >= self.max_sweeps):

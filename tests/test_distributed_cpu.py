@@ -90,6 +90,7 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         dist.all_gather_object(counts, emb.sweep_counts)
         assert all(c == counts[0] for c in counts)
         (Path(out_dir) / f"ok{rank}").write_text("ok")
+        dist.barrier()              # leave together: a rank tearing gloo down while others still talk can abort
     finally:
         dist.destroy_process_group()
 
@@ -117,6 +118,12 @@ def test_eight_rank_gloo_columns_with_idle_ranks(tmp_path):
     """The driver's largest case, rehearsed on CPU: 8 ranks, column split of a d=16 matrix (4 packs: ranks 4-7 hold
     no column and only join the collectives) -- same collective sequence on every rank, same result."""
     world = 8
-    mp.spawn(_worker, args=(world, _free_port(), 1, "g5_symkarate_d16_g0.76.npz", str(tmp_path), "columns"),
-             nprocs=world, join=True)
-    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+    for attempt in range(2):        # 8 processes rendezvousing on a small, busy box: one retry on a fresh port
+        try:
+            mp.spawn(_worker, args=(world, _free_port(), 1, "g5_symkarate_d16_g0.76.npz", str(tmp_path / str(attempt)),
+                                    "columns"), nprocs=world, join=True)
+            break
+        except Exception:
+            if attempt == 1:
+                raise
+    assert all((tmp_path / str(attempt) / f"ok{r}").exists() for r in range(world))
