@@ -300,6 +300,7 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()              # leave together
         dist.destroy_process_group()
 
 
