@@ -97,6 +97,10 @@ def embedding(args):
         embedder.verbose = False
     embedder.iterate()
     final_Z = g.Z                                   # collective when world > 1: every rank takes part
+    if world > 1:                                   # leave together: nobody tears the group down while others talk
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
 

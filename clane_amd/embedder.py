@@ -76,6 +76,9 @@ class Embedder(object):
         self.lagged_check = lagged_check
         self.sweeps_launched = 0
         self._round_was_idle = False
+        # dtype the reference's per-sweep delta would have (the sum of |Z_new - Z_old| in Z's dtype): only its printout
+        x_dtype = getattr(getattr(graph, "X", None), "dtype", torch.float32)
+        self._delta_dtype = x_dtype if x_dtype in (torch.float32, torch.float64) else torch.float32
         # history_sink(outer, sweep, Z): with save_history, every sweep's embeddings are handed to it from a
         # writer thread, in order, instead of being kept in `history["Z"]` -- the copy to the host overlaps the
         # following sweeps (SweepEngine.stage_Z).  Call flush_history() (iterate() does) before relying on it.
@@ -212,8 +215,9 @@ class Embedder(object):
                 ahead = True                        # short sweeps: from here on launch one ahead
                 ticket = engine.sweep_launch(self.gamma)
                 self.sweeps_launched += 1
-            if self.verbose:
-                print(f"{amount_updated:.4f} {self.tolerences['propagation'].value}")
+            if self.verbose:        # the reference prints the 0-d tensor itself (embedder.py:104): "tensor(25.7074) 10"
+                shown = torch.tensor(amount_updated, dtype=self._delta_dtype)
+                print(shown, self.tolerences['propagation'].value)
             if self.tolerences['propagation'].value == 0 or (self.max_sweeps and n_sweeps >= self.max_sweeps):
                 if self.save_history:
                     for i, st in in_flight:

@@ -208,6 +208,12 @@ class _LazySeq:
 
 
 class Graph(torch.utils.data.Dataset):
+    # plug-in similarity callables (build_P): edge batches of a `batchwise` callable are gathered this many bytes
+    # at a time; any other callable gets the reference's single call, refused above this size (None: 80 % of the
+    # free HBM at the time of the call)
+    PLUGIN_CHUNK_BYTES = 1 << 30
+    PLUGIN_SINGLE_CALL_MAX_BYTES = None
+
     def __init__(self, data_root: Path, embedding_dim: int = 128, dtype=None, cache: bool = False) -> None:
         """``dtype`` (extension, default None = keep what the files hold, as upstream): storage type of the
         embeddings on the GPU -- "float32", "float64" or "bfloat16" (bf16 storage, fp32 accumulate and P).
@@ -377,10 +383,31 @@ class Graph(torch.utils.data.Dataset):
             rows = torch.repeat_interleave(torch.arange(eng.part.n_local, device=eng.device),
                                            eng.rowptr[1:] - eng.rowptr[:-1])
             Zd = eng.Zcur[:, :eng.d]
-            src_Z = Zd[torch.from_numpy(eng.part.local_positions()).to(eng.device)[rows]]   # single GPU: RowPartition
-            dst_Z = Zd[eng.colidx.long()]
-            scores = similarity(src_Z, dst_Z).detach().to(eng.acc_dtype).reshape(-1)
-            eng.P[:eng.E_loc].copy_(scores)
+            src_pos = torch.from_numpy(eng.part.local_positions()).to(eng.device)[rows]   # single GPU: RowPartition
+            dst_pos = eng.colidx[:eng.E_loc].long()
+            pair_bytes = 2 * eng.E_loc * eng.d * Zd.element_size()          # the two gathered [E, d] batches
+            if getattr(similarity, "batchwise", False):
+                # the callable vouches that a pair's score does not depend on the other pairs of the batch:
+                # gather and score PLUGIN_CHUNK_BYTES at a time (2 x 41 GB at config 3 never exists at once)
+                step = max(1, self.PLUGIN_CHUNK_BYTES // max(1, 2 * eng.d * Zd.element_size()))
+                for a in range(0, eng.E_loc, step):
+                    b = min(a + step, eng.E_loc)
+                    part = similarity(Zd[src_pos[a:b]], Zd[dst_pos[a:b]])
+                    eng.P[a:b].copy_(part.detach().to(eng.acc_dtype).reshape(-1))
+            else:
+                limit = self.PLUGIN_SINGLE_CALL_MAX_BYTES
+                if limit is None and eng.device.type == "cuda":
+                    limit = int(0.8 * torch.cuda.mem_get_info(eng.device)[0])
+                if limit is not None and pair_bytes > limit:
+                    raise ValueError(
+                        f"similarity plugin: the single batched call of the reference's protocol (graph.py:120-121) "
+                        f"needs Z[src] and Z[dst] of all {eng.E_loc} edges at once = {pair_bytes / 2**30:.1f} GiB, more "
+                        f"than the {limit / 2**30:.1f} GiB available. If a pair's score does not depend on the rest of "
+                        f"the batch, set `batchwise = True` on the callable and it is scored in "
+                        f"{self.PLUGIN_CHUNK_BYTES >> 20} MiB chunks; a batch-global measure (like the reference's "
+                        f"CosineSimilarity) has to come as one call.")
+                scores = similarity(Zd[src_pos], Zd[dst_pos]).detach().to(eng.acc_dtype).reshape(-1)
+                eng.P[:eng.E_loc].copy_(scores)
             eng.k.segment_softmax(eng.rowptr, eng.part.n_local, eng.P)
             eng.P_valid = True
         values = self._gather_P(eng)

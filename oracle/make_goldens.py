@@ -76,10 +76,35 @@ def karate_files():
     return vids, edges
 
 
+def g10_labels_and_log(G, S, E):
+    """G10: the reference's karate label file (tests/data_root/Y, a data file no code reads) and the per-sweep
+    lines its propagate prints (embedder.py:104) on the G4 d=2 input -- pins the log format `tensor(25.7074) 10`."""
+    import torch
+    gold = np.load(OUT / "g4_karate_d2.npz")
+    vids, edges = karate_files()
+    tmp = Path(tempfile.mkdtemp(prefix="clane_gold_"))
+    _write_root(tmp / "k", vids, edges, gold["X"])
+    g = G.Graph(tmp / "k")
+    emb = E.Embedder(g, S.CosineSimilarity(), torch.device("cpu"), gamma=float(gold["gamma"]),
+                     tolerence=int(gold["tolerence"]))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        emb.propagate()
+    y_lines = (REF / "tests" / "data_root" / "Y").read_text().strip().split("\n")
+    np.savez_compressed(OUT / "g10_karate_labels_log.npz",
+                        Y_ids=np.array([l.split("\t")[0] for l in y_lines]),
+                        Y_classes=np.array([l.split("\t")[1] for l in y_lines]),
+                        propagate_stdout=np.array(buf.getvalue().splitlines()))
+    shutil.rmtree(tmp)
+
+
 def main():
     import torch
     G, S, E, M = _import_reference()
     OUT.mkdir(parents=True, exist_ok=True)
+    if sys.argv[1:] == ["g10"]:          # add G10 without re-drawing G9's unseeded content embeddings
+        g10_labels_and_log(G, S, E)
+        return
     tmp = Path(tempfile.mkdtemp(prefix="clane_gold_"))
     cs = S.CosineSimilarity()
 
@@ -208,6 +233,7 @@ def main():
                         parser_dests=np.array(sorted(a.dest for a in M.get_parser()._actions)))
 
     shutil.rmtree(tmp)
+    g10_labels_and_log(G, S, E)
     for p in sorted(OUT.glob("*.npz")):
         print(f"{p.name:36s} {p.stat().st_size:9d} B")
 

@@ -467,6 +467,21 @@ def test_custom_similarity_callable_goes_through_plugin_protocol(tmp_path):
     assert calls == [((156, 2), (156, 2))]                 # ONE batched call with all edges (graph.py:121)
     np.testing.assert_allclose(P.values().numpy(), gold["P0_values"], rtol=3e-6, atol=1e-7)
 
+    # a callable that declares itself `batchwise` (a pair's score ignores the rest of the batch) is fed in chunks
+    def dot(a, b):
+        calls.append((tuple(a.shape), tuple(b.shape)))
+        return (a * b).sum(1)
+    whole = g.build_P(dot).values()
+    dot.batchwise = True
+    del calls[:]
+    g.PLUGIN_CHUNK_BYTES = 2 * 2 * 4 * 50                  # 50 edge pairs of d=2 fp32 per chunk
+    np.testing.assert_array_equal(g.build_P(dot).values().numpy(), whole.numpy())
+    assert [c[0][0] for c in calls] == [50, 50, 50, 6]
+    # a batch-global callable larger than the limit is refused with the way out in the message
+    g.PLUGIN_SINGLE_CALL_MAX_BYTES = 1000
+    with pytest.raises(ValueError, match="batchwise = True"):
+        g.build_P(sim)
+
 
 # ---- native loader (csrc/host_loader.cpp) == Python loader == reference semantics --------------------
 def test_native_loader_matches_python_loader(tmp_path, karate_root):
@@ -602,3 +617,21 @@ def test_f1_harness_runs(tmp_path):
     assert len(rows) == 3 and all(m > 0.95 and M > 0.95 for _, m, M in rows)
     (tmp_path / "Y").write_text("\n".join(f"{i}\t{'ABC'[c]}" for i, c in enumerate(y)) + "\n")
     assert np.array_equal(mod.read_labels(tmp_path / "Y"), y)
+
+
+def test_per_sweep_log_lines_are_the_references(tmp_path):
+    """Golden G10: the reference prints the 0-d delta tensor and the countdown after every sweep
+    (embedder.py:104), e.g. ``tensor(25.7074) 10``; the same lines come out here."""
+    import re
+    gold, g = graph_from_golden(tmp_path, "g4_karate_d2.npz")
+    attach_cpu_engine(g)
+    want = list(load_golden("g10_karate_labels_log.npz")["propagate_stdout"])
+    emb = Embedder(g, CosineSimilarity(), torch.device("cpu"), gamma=float(gold["gamma"]),
+                   tolerence=int(gold["tolerence"]))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        emb.propagate()
+    got = buf.getvalue().splitlines()
+    assert got[:6] == want[:6]                       # deltas well above fp32 noise: identical text
+    assert all(re.fullmatch(r"tensor\([0-9.e+-]+\) \d+", ln) for ln in got)
+    assert got[-1].endswith(" 0") and abs(len(got) - len(want)) <= 3
