@@ -32,6 +32,7 @@ _p, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 SIGNATURES = {
     "clane_abi_version": (C.c_int, []),
     "clane_last_error": (C.c_char_p, []),
+    "clane_build_info": (C.c_char_p, []),
     "clane_spmm_partials_len": (_i64, [_i64, _i64]),
     "clane_reduce_ws_len": (_i64, []),
     "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p, _p]),
@@ -278,6 +279,9 @@ class HipKernels:
     # -- sizes --------------------------------------------------------------------------
     def spmm_partials_len(self, nrows: int, n_long: int) -> int:
         return int(self.lib.clane_spmm_partials_len(nrows, n_long))
+
+    def build_info(self) -> str:
+        return self.lib.clane_build_info().decode()
 
     def reduce_ws_len(self) -> int:
         return int(self.lib.clane_reduce_ws_len())

@@ -8,6 +8,7 @@ HIP kernels on a single card.
 """
 from __future__ import annotations
 
+import collections
 from typing import List, Optional
 
 import torch
@@ -19,25 +20,34 @@ class _Done:
 
 
 class TorchComm:
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, force_collectives: bool = False):
+        """``force_collectives``: issue every collective even in a one-rank group (where each is the identity), and
+        let ``SweepEngine`` keep the division it was asked for instead of dropping to the one-GPU plan.  That is how
+        the RCCL calls -- API, dtypes, stream hand-over of the async forms -- are exercised on a box with a single
+        GPU (tests/test_gpu_scale.py)."""
         import torch.distributed as dist
         self._dist = dist
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if process_group is not None else 1
         self.rank = dist.get_rank(process_group) if process_group is not None else 0
+        self.force = bool(force_collectives) and process_group is not None
+        self.calls = collections.Counter()
 
     def all_reduce_sum(self, t: torch.Tensor) -> None:
-        if self.world > 1:
+        if self.world > 1 or self.force:
+            self.calls["all_reduce"] += 1
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.pg)
 
     def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
         """out = concat over ranks of inp (inp may be the rank's own slice of out: in-place form)."""
+        self.calls["all_gather"] += 1
         w = self._dist.all_gather_into_tensor(out, inp, group=self.pg, async_op=async_op)
         return w if async_op else _Done()
 
     def all_to_all_rows(self, out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_splits: List[int],
                         async_op: bool = False):
         """Row blocks of `inp` (in_splits[q] rows to rank q) -> row blocks of `out` (out_splits[q] rows from q)."""
+        self.calls["all_to_all"] += 1
         w = self._dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
                                          group=self.pg, async_op=async_op)
         return w if async_op else _Done()

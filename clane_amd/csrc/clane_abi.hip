@@ -371,6 +371,13 @@ extern "C" {
 
 int clane_abi_version(void) { return CLANE_ABI_VERSION; }
 const char *clane_last_error(void) { return g_err; }
+#define CLANE_STR2(x) #x
+#define CLANE_STR(x) CLANE_STR2(x)
+const char *clane_build_info(void) {
+    return "arch=gfx950;SPMM_U=" CLANE_STR(CLANE_SPMM_U) ";LONG_U=" CLANE_STR(CLANE_LONG_U) ";LONG_WAVES=" CLANE_STR(
+        CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM)
+        ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH);
+}
 
 int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long) {
     return spmm_main_grid(nrows > 0 ? nrows : 1) + (n_long > 0 ? n_long : 0);

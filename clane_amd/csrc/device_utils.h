@@ -143,6 +143,35 @@ __device__ __forceinline__ double block_sum_fixed(double v, double *smem) {
     return s;
 }
 
+// This library is written for gfx950 (MI355X) only.  Two things below lean on the gfx9 ISA rather than on the HIP
+// programming model, so any other target must fail to compile instead of hanging at run time:
+//  * kernels that give one workgroup to one row let waves WITHOUT work terminate before a later s_barrier
+//    (`idle_wave_may_exit`): on gfx9 "s_barrier" counts only the waves of the workgroup that have not ended
+//    (CDNA3/4 ISA guide, s_barrier / s_endpgm), so a 40-edge row costs one working wave, not 16 parked ones
+//    holding their registers;
+//  * a wave executes in lock step, so one release/acquire by lane 0 publishes / observes the LDS accesses of all
+//    64 lanes once the wave has waited for its own LDS counter (`last_wave_of_block`).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "clane_amd's kernels are written for gfx950 only (wave64, gfx9 s_barrier semantics): compile with --offload-arch=gfx950"
+#endif
+
+// True for the waves of a one-workgroup-per-row kernel that have nothing to do and may end before the
+// workgroup's barriers.  `has_work` must be wave-uniform.
+__device__ __forceinline__ bool idle_wave_may_exit(bool has_work) { return !has_work; }
+
+// Ticket taken by every wave of a kBlock-thread workgroup when it has finished its rows; true in the LAST wave to
+// arrive, which may then read what all the others wrote to LDS.  All 64 lanes first wait for their own LDS stores
+// (release fence: s_waitcnt lgkmcnt(0) on gfx9), lane 0 takes the ticket with acquire-release ordering at
+// workgroup scope, and the reads of the last wave are kept behind it by an acquire fence.
+__device__ __forceinline__ bool last_wave_of_block(int *s_done) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int ticket = 0;
+    if (lane_id() == 0) ticket = __hip_atomic_fetch_add(s_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ticket == kWavesPerBlock - 1;
+}
+
 template <typename A>
 __device__ __forceinline__ A exp_acc(A v);
 template <>

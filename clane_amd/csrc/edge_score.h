@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WAVES *kWave) void edge_score_long_kernel(
     const int64_t e1 = rowptr[r + 1];
     const int64_t seg = ceil_div(ceil_div(e1 - e0, WAVES), kWave) * kWave;
     const int64_t a = e0 + wave * seg;
-    if (a >= e1) return;  // gfx9 s_barrier waits only for waves that have not terminated
+    if (idle_wave_may_exit(a < e1)) return;  // before the barrier below: device_utils.h
     const int64_t b = a + seg < e1 ? a + seg : e1;
     const A D = global_denominator<A>(mode, sums2);
     const bool whole_row_here = e1 - e0 <= kWave;

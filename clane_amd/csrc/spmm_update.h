@@ -284,13 +284,8 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
 #endif
     }
     // No closing barrier: a wave that runs out of rows leaves (its slot goes to another workgroup);
-    // the LAST wave to arrive sums the per-row deltas in row order.  LDS is one in-order memory per
-    // CU, so every s_rowsum store issued before a wave's ticket is visible to the last ticket holder.
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's s_rowsum stores have landed
-    int ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&s_done, 1);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != kWavesPerBlock - 1) return;
+    // the LAST wave to arrive sums the per-row deltas in row order (see last_wave_of_block).
+    if (!last_wave_of_block(&s_done)) return;
     double dsum = 0.0;
     for (int i = lane; i < nb; i += kWave) dsum += s_rowsum[i];
     dsum = group_sum<kWave>(dsum);
@@ -434,11 +429,7 @@ __global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
         }
         pos += U;
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's s_rowsum stores have landed
-    int ticket = 0;
-    if (lane == 0) ticket = atomicAdd(&s_done, 1);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != kWavesPerBlock - 1) return;
+    if (!last_wave_of_block(&s_done)) return;
     double dsum = 0.0;
     for (int i = lane; i < nb; i += kWave) dsum += s_rowsum[i];
     dsum = group_sum<kWave>(dsum);
@@ -467,7 +458,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     const int64_t e1 = rowptr[r + 1];
     const int64_t seg = ceil_div(ceil_div(e1 - e0, WAVES), kWave) * kWave;
     const int active = e1 > e0 ? int(ceil_div(e1 - e0, seg)) : 1;  // waves with a non-empty slice (wave 0 always stays)
-    if (wave >= active) return;
+    if (idle_wave_may_exit(wave < active)) return;  // before the barriers below: device_utils.h
     const int64_t a = e0 + wave * seg;
     const int64_t b = a + seg < e1 ? a + seg : e1;
     const EdgeChunk<A> none{0, A(0)};
@@ -536,7 +527,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_split_segment_kernel(
     const int64_t e1 = e0 + edges_per_segment < rowptr[r + 1] ? e0 + edges_per_segment : rowptr[r + 1];
     const int64_t seg = ceil_div(ceil_div(e1 - e0, WAVES), kWave) * kWave;
     const int active = e1 > e0 ? int(ceil_div(e1 - e0, seg)) : 1;
-    if (wave >= active) return;
+    if (idle_wave_may_exit(wave < active)) return;  // before the barriers below: device_utils.h
     const int64_t a = e0 + wave * seg;
     const int64_t b = a + seg < e1 ? a + seg : e1;
     const EdgeChunk<A> none{0, A(0)};

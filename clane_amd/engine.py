@@ -139,10 +139,15 @@ class SweepEngine:
         if exchange not in ("auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all"):
             raise ValueError("exchange must be 'auto', 'columns', 'halo', 'halo_p2p', 'allgather' or 'allgather_all', "
                              f"got {exchange!r}")
+        # a one-rank group whose comm insists on its collectives keeps the division it is given (RCCL rehearsal on a
+        # one-GPU box, comm.TorchComm(force_collectives=True)); "auto" is then the plain one-GPU plan
+        self._forced = self.world == 1 and bool(getattr(self.comm, "force", False)) and exchange in (
+            "columns", "allgather", "allgather_all")
+        divided = self.world > 1 or self._forced
         if exchange == "auto":
             exchange = pick_exchange(int(X.shape[1]), X.dtype, self.world)
-        self.exchange = exchange if self.world > 1 else "none"
-        self.columns = self.world > 1 and exchange == "columns"
+        self.exchange = exchange if divided else "none"
+        self.columns = divided and exchange == "columns"
         self.V, self.d_full = csr.num_vertices, int(X.shape[1])
         self.col0, self.col1 = column_slice(self.d_full, X.dtype, self.world, rank) if self.columns else (0, self.d_full)
         X_all = X
@@ -155,6 +160,7 @@ class SweepEngine:
         row_world, row_rank = (1, 0) if self.columns else (self.world, rank)
         if chunks is None:
             chunks = 1 if row_world == 1 else 4
+        self.hot_rows_first = bool(hot_rows_first)
         self.halo = row_world > 1 and exchange in ("halo", "halo_p2p")
         self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
         if self.p2p and self.world > 8:
@@ -170,7 +176,7 @@ class SweepEngine:
             hot = csr.indeg() if (row_world == 1 and hot_rows_first and not shuffle) else None
             self.part = RowPartition.create(self.V, row_world, row_rank, chunks, live_mask=live, shuffle=shuffle,
                                             seed=seed, priority=hot)
-            self.blocks = self.part.blocks()
+            self.blocks = self.part.blocks(spans_for_one_rank=self._forced and not self.columns)
             self.local = localize(csr, self.part, self.device)
         if self.part.padded_vertices >= 2 ** 31:
             raise ValueError(f"{self.part.padded_vertices} table rows: column indices are 32-bit (ABI v1); divide the "
@@ -675,6 +681,18 @@ class SweepEngine:
         return {"main": int(per_row[~is_long].sum()) + 8, "mid": int(per_row[is_long & ~is_hub & ~is_split].sum()),
                 "hub": int(per_row[is_hub].sum()), "split": int(per_row[is_split].sum())}
 
+    def kernel_config(self) -> dict:
+        """Everything that decides which K3 kernels a sweep launches over which rows, and with which compile-time
+        tuning: measurements of a kernel (profiles/traffic.json) are only valid for the configuration they were
+        taken with, and bench.py refuses to quote them for another."""
+        build = self.k.build_info() if hasattr(self.k, "build_info") else "substitute kernels"
+        return {"build": build, "dtype": str(self.dtype).replace("torch.", ""), "d": self.d,
+                "lanes_per_row": lanes_per_row(self.d, self.dtype) if self.d > 0 else 0,
+                "rows": int(self.part.n_local), "edges": int(self.E_loc), "launch_blocks": len(self.blocks),
+                "long_threshold": self.long_threshold, "hub_threshold": self.hub_threshold,
+                "split_edges": self.split_edges, "segment_edges": self.segment_edges,
+                "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
+
     def exchange_bytes_per_sweep(self) -> int:
         """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""
         s = self.Zcur.element_size()
@@ -704,5 +722,5 @@ class SweepEngine:
 
     # ---- collectives ------------------------------------------------------------------
     def _all_reduce(self, t: torch.Tensor) -> None:
-        if self.world > 1:
+        if self.world > 1 or self._forced:
             self.comm.all_reduce_sum(t)

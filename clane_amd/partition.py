@@ -145,13 +145,14 @@ class RowPartition:
         quiet = self.live_total + r * self.quiet_per_rank + np.arange(self.quiet_per_rank, dtype=np.int64)
         return np.concatenate([live, quiet])
 
-    def blocks(self) -> List[Block]:
-        """Launch plan of one sweep for this rank."""
+    def blocks(self, spans_for_one_rank: bool = False) -> List[Block]:
+        """Launch plan of one sweep for this rank.  ``spans_for_one_rank``: keep the (then trivial) all-gather span
+        of every chunk in a one-rank partition too (TorchComm(force_collectives=True))."""
         lc, w = self.live_per_chunk, self.world_size
         out = []
         for c in range(self.chunks):
             b = c * w * lc
-            span = (b, b + w * lc) if w > 1 else None
+            span = (b, b + w * lc) if (w > 1 or spans_for_one_rank) else None
             out.append(Block(c * lc, lc, b + self.rank * lc, span))
         if self.quiet_per_rank:
             out.append(Block(self.chunks * lc, self.quiet_per_rank,

@@ -72,6 +72,10 @@ typedef struct {
 
 int clane_abi_version(void);
 const char *clane_last_error(void);
+/* Compile-time tuning of this build as "KEY=value;..." (neighbour rows in flight per wave, waves and rows per
+ * workgroup, non-temporal streams): measurements stored beside a benchmark (profiles/traffic.json) carry it, so a
+ * number taken with another build is recognised as stale.  No reference counterpart. */
+const char *clane_build_info(void);
 
 /* Doubles written by clane_spmm_update_*(nrows) plus clane_spmm_update_long_*(n_long). */
 int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long);

@@ -1,0 +1,80 @@
+"""bench.py's host logic without a GPU: the self-launch of N > 1 ranks, the stale-traffic rule of the roofline
+line, and the sampled PyTorch-CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+
+def test_gpus_flag_without_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the driver's command form) must not die on the flag: it
+    starts two fresh rank processes.  Without a GPU those ranks refuse to run (no CPU fallback) and the exit
+    code comes back; with one, the rehearsal flags let both share it and one JSON line comes out."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    run = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1",
+                          "--warmup", "0", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert "starting ranks" in run.stderr and "--nproc-per-node=2" in run.stderr
+    assert "the launcher and the flag disagree" not in run.stderr
+    if torch.cuda.is_available():
+        assert run.returncode == 0, run.stderr[-2000:]
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    else:
+        assert run.returncode != 0 and "no CPU fallback" in run.stderr
+
+
+def _fake_engine(**over):
+    cfg = {"build": "arch=gfx950;SPMM_U=8", "dtype": "float32", "d": 256, "lanes_per_row": 64, "rows": 10, "edges": 99,
+           "launch_blocks": 1, "long_threshold": 32, "hub_threshold": 32, "split_edges": 4096, "segment_edges": 4096,
+           "hot_rows_first": True, "exchange": "none"}
+    cfg.update(over)
+    return SimpleNamespace(kernel_config=lambda: dict(cfg), columns=False), cfg
+
+
+def test_traffic_is_only_quoted_for_the_configuration_it_was_measured_with(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    (tmp_path / "profiles").mkdir()
+    eng, cfg = _fake_engine()
+    table = {"w_n1": {"source": "profiles/x.md", "kernel_config": cfg, "k": {"bytes_per_launch": 123.0}},
+             "old_n1": {"k": {"bytes_per_launch": 5.0}}}
+    (tmp_path / "profiles" / "traffic.json").write_text(json.dumps(table))
+    assert bench.traffic_entry("w", 1, eng, "k") == (123.0, "profiles/x.md")
+    got, why = bench.traffic_entry("w", 1, eng, "other")
+    assert got is None and "not in the measurement" in why
+    got, why = bench.traffic_entry("old", 1, eng, "k")                  # an entry from before configurations were kept
+    assert got is None and "stale" in why
+    got, why = bench.traffic_entry("nope", 1, eng, "k")
+    assert got is None and "no PMC measurement" in why
+    for change in ({"long_threshold": 64}, {"build": "arch=gfx950;SPMM_U=4"}, {"segment_edges": 1024}, {"d": 128}):
+        other, _ = _fake_engine(**change)
+        got, why = bench.traffic_entry("w", 1, other, "k")
+        assert got is None and "stale" in why and list(change)[0] in why
+
+
+def test_sampled_torch_baseline_matches_a_full_sweep_in_order_of_magnitude():
+    import time
+    from clane_amd import synth
+    from oracle import clane_oracle as O
+    csr = synth.rmat_csr(30_000, 400_000, seed=1, device="cpu")
+    X = synth.gaussian_X(30_000, 64, seed=2)
+    P = O.build_P_values(csr.rowptr, csr.colidx, X)
+    out = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=0.02)      # tiny budget: forces row sampling
+    assert out["kind"] == "port" and out["cores"] == torch.get_num_threads() and out["one_thread"]["cores"] == 1
+    assert "torch.sparse.mm" in out["sample"] and "-th row" in out["sample"]
+    Ps = O.as_sparse(csr.rowptr, csr.colidx, P)
+    O.sweep(csr.rowptr, csr.colidx, P, X, X, 0.76, Ps)
+    t0 = time.perf_counter()
+    O.sweep(csr.rowptr, csr.colidx, P, X, X, 0.76, Ps)
+    full = time.perf_counter() - t0
+    assert 0.1 < (1.0 / out["value"]) / full < 10                       # a scaled sample, not a different quantity
+    assert torch.get_num_threads() == out["cores"]                      # thread count restored

@@ -122,3 +122,38 @@ def test_eight_rank_gloo_columns_with_idle_ranks(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), 1, "g5_symkarate_d16_g0.76.npz", str(tmp_path), "columns"),
              nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.parametrize("exchange", ["allgather_all", "allgather", "columns"])
+def test_one_rank_group_with_forced_collectives(tmp_path, exchange):
+    """TorchComm(force_collectives=True) over a ONE-rank group: the engine keeps the division it is given and issues
+    every collective (each the identity) -- the rehearsal the GPU suite runs on RCCL with the box's single GPU."""
+    sys.path.insert(0, str(ROOT))
+    from clane_amd.comm import TorchComm
+    from clane_amd.engine import SweepEngine
+    from clane_amd.graph import Graph
+    from oracle import clane_oracle as O
+    from tests.conftest import load_golden, write_data_root
+    from tests.oracle_kernels import OracleKernels
+    gold, k = load_golden("g5_symkarate_d16_g0.76.npz"), load_golden("g2_karate_csr.npz")
+    g = Graph(write_data_root(tmp_path / "g", k["vertex_ids"], gold["edge_src"], gold["edge_dst"], gold["X"]))
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        comm = TorchComm(dist.group.WORLD, force_collectives=True)
+        eng = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), comm=comm, exchange=exchange, chunks=3, shuffle=False)
+        assert eng.world == 1 and eng.exchange == exchange and eng.columns == (exchange == "columns")
+        eng.build_P()
+        np.testing.assert_allclose(eng.P_global().numpy(), gold["P0_values"], rtol=3e-6, atol=1e-7)
+        X = torch.from_numpy(gold["X"])
+        P_or = O.build_P_values(g.csr.rowptr, g.csr.colidx, X)
+        Z = X.clone()
+        for _ in range(3):
+            delta = eng.sweep(float(gold["gamma"]))
+            Z, d_or = O.sweep(g.csr.rowptr, g.csr.colidx, P_or, X, Z, float(gold["gamma"]))
+            assert abs(delta - float(d_or)) <= 1e-5 * max(1.0, float(d_or))
+        assert O.rel_l2(eng.get_Z(), Z) < 1e-6
+        assert comm.calls["all_reduce"] >= 4 and (exchange == "columns" or comm.calls["all_gather"] == 9)
+        plain = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), comm=TorchComm(dist.group.WORLD), exchange=exchange)
+        assert plain.exchange == "none" and not plain.columns           # without the flag: the one-GPU plan
+    finally:
+        dist.destroy_process_group()

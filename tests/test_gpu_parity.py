@@ -863,23 +863,34 @@ def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
     one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"] + common, capture_output=True,
                          text=True, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(root / "bench.py"), "--gpus", "2",
-                          "--backend", "gloo", "--share-gpu"] + common, capture_output=True, text=True, timeout=600,
-                         cwd=root)
+    # N = 2 exactly as the driver starts it: `python bench.py --gpus 2 ...`, no launcher, WORLD_SIZE unset -- bench.py
+    # starts the two ranks itself (fresh children) and relays rank 0's line
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    two = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu"]
+                         + common, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
+    assert "starting ranks" in two.stderr
     r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len([ln for ln in two.stdout.splitlines() if ln.startswith("{")]) == 1          # ONE JSON line
+    # the first sweep of the two-rank run is checked against the C oracle too (rank 0 gathers Z)
+    assert r2["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and r1["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
+    assert "cpu_baseline" not in r2                                       # N = 1 only, by the bench contract
     assert r2["n_gpus"] == 2 and "column split x2" in r2["config"]["parallelism"] and r2["scaling"] == "strong"
     assert r2["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
     # a rank that drew a different graph (test hook) is overruled by rank 0's input, not trusted and not fatal
     fixed = subprocess.run(two.args, capture_output=True, text=True, timeout=600, cwd=root,
-                           env=dict(os.environ, CLANE_BENCH_PERTURB_RANK="1"))
+                           env=dict(env, CLANE_BENCH_PERTURB_RANK="1"))
     assert fixed.returncode == 0 and "ranks disagree" in fixed.stderr, fixed.stderr[-2000:]
     r3 = json.loads([ln for ln in fixed.stdout.splitlines() if ln.startswith("{")][-1])
     assert r3["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
     for r in (r1, r2):
         assert r["steps"] == 4 and r["warmup"] == 2 and r["value"] > 0 and r["roofline"]["bound"] == "hbm"
+        roof = r["roofline"]
+        assert 0 < roof["frac"] <= 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"])
+        assert roof["achieved"] <= roof["achieved_algorithmic"] + 1e-9 and roof["kernel_config"]["d"] in (64, 32)
+        assert all(0 < kk["frac"] <= 1.0 for kk in roof["kernels"].values()) and roof["k3_pass"]["frac"] <= 1.0
+        assert roof["traffic"] is None and "no valid PMC traffic" in roof["note"]      # nothing measured for `tiny`
 
 
 def test_bench_halo_p2p_two_processes_share_tables_through_ipc(tmp_path):

@@ -1,0 +1,357 @@
+"""GPU parity at scale, in the modes where the edge SCORES matter.
+
+In the reference's own mode (similarity.py:37: one global denominator) a score is about dot / (|E| d) ~ 1e-8 and the
+row softmax equals 1/deg to fp32 epsilon, so a P that matches the oracle says nothing about the dot products behind
+it.  The tests here therefore use the raw dot products (CLANE_SCORE_RAW_DOT) and the true per-edge
+cosine (`cosine_mode="per_edge"`), whose softmax moves with every score, on graphs whose hub rows are walked in
+SEVERAL 64-edge chunks per wave of `edge_score_long_kernel` (rows above 1024 edges: running max / sum per wave, the
+LDS {max, sum} combine, the rescale of the wave's own stores) -- config 2 and config 3 sizes, d = 128 and 256,
+fp32 / fp64 / bf16.  Config 4 (power-law 10M / 200M / d=128 bf16) runs at its full shape on one GPU.
+
+Tolerances as in test_gpu_parity.py: fp32 <= 2e-6 rel-L2 (summation order), fp64 <= 1e-13, bf16 storage <= 8e-3.
+"""
+import importlib.util
+import socket
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from clane_amd import _hip, synth
+from clane_amd.embedder import Embedder
+from clane_amd.engine import SweepEngine, lanes_per_row
+from clane_amd.graph import Graph
+from clane_amd.partition import HostCSR
+from clane_amd.similarity import CosineSimilarity
+from oracle import clane_oracle as O
+
+from .conftest import load_golden, write_data_root
+from .test_gpu_parity import TOL, padded, rel
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return _hip.require_gpu("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def k():
+    return _hip.kernels()
+
+
+def hub_csr(V, hubs, seed, max_deg=6):
+    """Sparse background (0..max_deg edges per row, some empty) plus rows of exactly the given degrees."""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, max_deg + 1, size=V)
+    where = rng.choice(V, size=len(hubs), replace=False)
+    deg[where] = hubs
+    rowptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    cols = np.empty(int(rowptr[-1]), dtype=np.int32)
+    small = rng.integers(0, V, size=(V, max_deg + 2))
+    for r in range(V):
+        dg = deg[r]
+        if dg == 0:
+            continue
+        if dg <= max_deg:
+            c = np.unique(small[r])[:dg]
+            while c.size < dg:                       # the few rows whose draws collided
+                c = np.unique(np.concatenate([c, rng.integers(0, V, size=dg)]))[:dg]
+        else:
+            c = np.sort(rng.choice(V, size=dg, replace=False))
+        cols[rowptr[r]:rowptr[r + 1]] = c
+    return HostCSR(V, rowptr, cols), where
+
+
+def per_edge_rows_f64(csr, Z, rows):
+    """float64 restatement, on the given rows only, of per-edge cosine + row softmax (similarity.py:26-37 with
+    per-pair norms, graph.py:122-123): {row: P values of the row}."""
+    out = {}
+    Zn = Z.numpy() if isinstance(Z, torch.Tensor) else Z
+    for r in rows:
+        a, b = int(csr.rowptr[r]), int(csr.rowptr[r + 1])
+        if a == b:
+            out[int(r)] = np.empty(0)
+            continue
+        zs = Zn[r].astype(np.float64)
+        nb = Zn[csr.colidx[a:b]].astype(np.float64)
+        s = (nb @ zs) / (np.linalg.norm(zs) * np.linalg.norm(nb, axis=1))
+        e = np.exp(s - s.max())
+        out[int(r)] = e / e.sum()
+    return out
+
+
+# ---- (c) hubs of 1 100 / 5 000 / 20 000 edges: one wave of the 16-wave row kernel walks >= 2 chunks -----------------
+@pytest.mark.parametrize("dtype,d", [(torch.float32, 256), (torch.float64, 256), (torch.bfloat16, 256),
+                                     (torch.bfloat16, 128), (torch.float32, 128), (torch.float32, 100)])
+def test_k1_multi_chunk_hub_rows(dev, k, dtype, d):
+    """Rows of 1 025 ... 20 000 edges through edge_score_long_kernel (16 waves: 2 ... 20 chunks of 64 edges per
+    wave): raw dots and per-edge P against the oracle, fused softmax == K1 raw + K1b finalize + K2 (the
+    column-split route), sliced scores == the one-wave kernel's bit for bit."""
+    V = 20_500
+    csr, where = hub_csr(V, [1025, 1100, 5000, 20000, 1024, 64, 65, 2047], seed=d)
+    acc = _hip.acc_dtype(dtype)
+    Zc = synth.gaussian_X(V, d, seed=11).to(dtype)
+    Zf = Zc.to(acc).double()                                            # what the kernels see after widening
+    Zd = padded(Zc, dtype, dev)
+    rowptr, colidx = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    deg = np.diff(csr.rowptr)
+    T = 32 if lanes_per_row(d, dtype) == 64 else 128                  # the engine's defaults for these row widths
+    long_rows = torch.from_numpy(np.nonzero(deg > T)[0].astype(np.int32)).to(dev)
+    assert long_rows.numel() >= 7
+    tol = 5e-6 if dtype == torch.bfloat16 else TOL[dtype]
+
+    dots_ref = O.edge_dots(csr.rowptr, csr.colidx, Zf)
+    raw = torch.full((csr.num_edges,), float("nan"), dtype=acc, device=dev)
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, raw, T, long_rows)
+    assert rel(raw, dots_ref) < tol
+    whole = torch.full_like(raw, float("nan"))                          # every row by one (sub-)wave
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_RAW_DOT, None, None, whole)
+    assert torch.equal(whole, raw)
+    for h in where[:4]:                                                 # the hub rows on their own
+        a, b = csr.rowptr[h], csr.rowptr[h + 1]
+        assert rel(raw[a:b], dots_ref[a:b]) < tol, (h, b - a)
+
+    sq = torch.empty(V, dtype=acc, device=dev)
+    k.row_sqnorm(Zd, d, sq)
+    fused = torch.full_like(raw, float("nan"))
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_PER_EDGE, None, sq, fused, T, long_rows, fuse_softmax=True)
+    P_ref = O.build_P_values(csr.rowptr, csr.colidx, Zf, mode="per_edge")
+    assert rel(fused, P_ref) < max(tol, 1e-6)
+    for h in where[:4]:
+        a, b = csr.rowptr[h], csr.rowptr[h + 1]
+        assert rel(fused[a:b], P_ref[a:b]) < max(tol, 1e-6), (h, b - a)
+        assert float(fused[a:b].double().sum()) == pytest.approx(1.0, abs=1e-5)
+    # the non-fused route of the column split: raw dots, denominators applied afterwards, K2 over every row
+    late = raw.clone()
+    k.edge_score_finalize(rowptr, colidx, V, 0, _hip.SCORE_PER_EDGE, None, sq, late)
+    k.segment_softmax(rowptr, V, late, 0, T, long_rows)
+    assert rel(late, fused) < (1e-14 if dtype == torch.float64 else 3e-7)
+    # reference mode through the same long rows (global denominator): softmax ~ 1/deg, and it must still be exact
+    ws = torch.zeros(k.reduce_ws_len(), dtype=torch.float64, device=dev)
+    sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    k.degree_weighted_sums(sq, rowptr, torch.from_numpy(csr.indeg()).to(dev), V, ws, sums2)
+    k.edge_score(rowptr, colidx, V, 0, Zd, d, _hip.SCORE_REFERENCE, sums2, None, fused, T, long_rows, fuse_softmax=True)
+    assert rel(fused, O.build_P_values(csr.rowptr, csr.colidx, Zf)) < max(tol, 1e-6)
+
+
+# ---- (a) config 2 size, default thresholds, d = 128 (2 rows per wave) and d = 256 (a row fills a wave) -------------
+@pytest.mark.parametrize("d", [128, 256])
+def test_k1_scores_at_scale(dev, k, d):
+    """R-MAT 200k / 4M: `SweepEngine(cosine_mode="per_edge").build_P()` (the engine's own row order, thresholds and
+    long-row lists) against O.build_P_values(mode="per_edge"); raw dot products of all 4M edges against
+    O.edge_dots at <= 2e-6; the rows above 1 024 edges checked on their own."""
+    V, E = 200_000, 4_000_000
+    csr = synth.rmat_csr(V, E, seed=1)
+    deg = np.diff(csr.rowptr)
+    big = np.nonzero(deg > 1024)[0]
+    assert big.size >= 20                                               # multi-chunk rows exist at this size
+    X = synth.gaussian_X(V, d, seed=2)
+    eng = SweepEngine(csr, X, dev, cosine_mode="per_edge")
+    assert eng.long_threshold == (32 if d == 256 else 128) and eng.long_rows[0] is not None
+    eng.build_P()
+    P_gpu = eng.P_global()
+    P_ref = O.build_P_values(csr.rowptr, csr.colidx, X, mode="per_edge")
+    assert rel(P_gpu, P_ref) < 2e-6
+    worst = max(rel(P_gpu[csr.rowptr[r]:csr.rowptr[r + 1]], P_ref[csr.rowptr[r]:csr.rowptr[r + 1]]) for r in big)
+    assert worst < 5e-6, worst
+    # raw dots with the engine's own structure (its vertex order, its long-row list)
+    raw = torch.full((eng.E_loc,), float("nan"), dtype=torch.float32, device=dev)
+    k.edge_score(eng.rowptr, eng.colidx, eng.part.n_local, 0, eng.Zcur, eng.d, _hip.SCORE_RAW_DOT, None, None, raw,
+                 eng.long_threshold, eng.long_rows[0])
+    dots = torch.empty(E)
+    dots[torch.from_numpy(eng.local.edge_origin)] = raw.cpu()
+    dots_ref = O.edge_dots(csr.rowptr, csr.colidx, X)
+    assert rel(dots, dots_ref) < 2e-6
+    worst = max(rel(dots[csr.rowptr[r]:csr.rowptr[r + 1]], dots_ref[csr.rowptr[r]:csr.rowptr[r + 1]]) for r in big)
+    assert worst < 2e-6, worst
+    # and the reference mode on the same engine object (what bench.py and the CLI run)
+    eng.cosine_mode, eng.P_valid = "reference", False
+    eng.build_P()
+    assert rel(eng.P_global(), O.build_P_values(csr.rowptr, csr.colidx, X)) < 2e-6
+
+
+# ---- (b) config 3 at full size: per-edge P on sampled rows + the heaviest hubs -----------------------------------------
+def test_config3_per_edge_P_sampled_rows(dev):
+    """R-MAT 2M / 40M / d=256 fp32 (188k rows above 32 edges, heaviest out-degree ~70k): per-edge P of 2 000 sampled
+    rows and the three heaviest hubs against a float64 restatement of similarity.py:26-37 (per-pair norms) and
+    graph.py:122-123 on those rows; every row with edges sums to 1."""
+    V, E, d = 2_000_000, 40_000_000, 256
+    csr = synth.rmat_csr(V, E, seed=3, device=str(dev))
+    X = synth.gaussian_X(V, d, seed=4)
+    eng = SweepEngine(csr, X, dev, cosine_mode="per_edge")
+    eng.build_P()
+    P = eng.P_global().numpy()
+    deg = np.diff(csr.rowptr)
+    rng = np.random.default_rng(1)
+    rows = np.concatenate([rng.choice(V, size=1500, replace=False),
+                           rng.choice(np.nonzero(deg > 1024)[0], size=500, replace=False), np.argsort(deg)[-3:]])
+    want = per_edge_rows_f64(csr, X, rows)
+    for r in rows:
+        a, b = csr.rowptr[r], csr.rowptr[r + 1]
+        if b > a:
+            got = P[a:b].astype(np.float64)
+            assert np.linalg.norm(got - want[int(r)]) <= 3e-6 * np.linalg.norm(want[int(r)]), (r, b - a)
+    cs = np.concatenate([[0.0], np.cumsum(P.astype(np.float64))])
+    sums = cs[csr.rowptr[1:]] - cs[csr.rowptr[:-1]]
+    assert np.abs(sums[deg > 0] - 1).max() < 1e-4 and np.abs(sums[deg == 0]).max() == 0
+    # unlike the reference mode, this P is far from uniform: the check above can tell a wrong dot product
+    hub = int(np.argmax(deg))
+    ph = P[csr.rowptr[hub]:csr.rowptr[hub + 1]]
+    assert ph.max() / ph.min() > 1.2
+
+
+# ---- (d) config 4 at its full shape on one GPU -------------------------------------------------------------------------
+def test_config4_full_shape(dev):
+    """BASELINE config 4: power-law |V| = 10M, |E| ~ 200M, d = 128, bf16 storage (fp32 accumulate, fp32 P), one GPU.
+    (1) P rows sum to 1; (2) 2 000 sampled rows + the three heaviest hubs of the first sweep against fp32/float64
+    arithmetic on the bf16-rounded inputs (embedder.py:88-92; <= 8e-3: one bf16 rounding of the result); (3) rows
+    without out-edges keep z; (4) delta = sum|Z_new - Z_old|; (5) Embedder.iterate() from Z = X runs to `tolerence`
+    with the outer delta reaching 0 (the bf16 fixed point); (6) at that point the sampled rows satisfy
+    z = x + gamma * P z to bf16 rounding with the P of the final embeddings (graph.py:118-128 + embedder.py:92)."""
+    V, E, d, gamma = 10_000_000, 200_000_000, 128, 0.76
+    csr = synth.powerlaw_csr(V, E, seed=5, device=str(dev))
+    assert 0.97 * E <= csr.num_edges <= E
+    X = synth.gaussian_X(V, d, seed=6).to(torch.bfloat16)
+    g = Graph.from_csr(csr, X)
+    eng = g.engine(dev)
+    assert eng.dtype == torch.bfloat16 and eng.P.dtype == torch.float32
+    eng.build_P()
+    P = eng.P_global().numpy()
+    deg = np.diff(csr.rowptr)
+    cs = np.concatenate([[0.0], np.cumsum(P.astype(np.float64))])
+    sums = cs[csr.rowptr[1:]] - cs[csr.rowptr[:-1]]
+    assert np.abs(sums[deg > 0] - 1).max() < 1e-4
+    del cs, sums
+    delta = eng.sweep(gamma)
+    Z1 = eng.get_Z()
+    rng = np.random.default_rng(0)
+    rows = np.concatenate([rng.choice(V, size=2000, replace=False), np.argsort(deg)[-3:]])
+
+    def residual(Z_in, Z_out, Pv):
+        worst = 0.0
+        for r in rows:
+            a, b = csr.rowptr[r], csr.rowptr[r + 1]
+            if a == b:
+                assert torch.equal(Z_out[r], X[r])
+                continue
+            nb = Z_in[torch.from_numpy(csr.colidx[a:b].astype(np.int64))].double().numpy()
+            want = X[r].double().numpy() + gamma * (Pv[a:b, None].astype(np.float64) * nb).sum(0)
+            got = Z_out[r].double().numpy()
+            worst = max(worst, np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+        return worst
+    assert residual(X, Z1, P) < 8e-3
+    sink = torch.from_numpy(deg == 0)
+    if bool(sink.any()):
+        assert torch.equal(Z1[sink], X[sink])
+    assert delta == pytest.approx(float((Z1.float() - X.float()).abs().sum(dtype=torch.float64)), rel=1e-5)
+    del Z1
+
+    eng.set_Z(X)
+    emb = Embedder(g, CosineSimilarity(), dev, gamma=gamma, tolerence=10, verbose=False, max_sweeps=2000)
+    emb.iterate()
+    assert emb.tolerences["global"].value == 0 and emb.outer_deltas[-1] == 0.0
+    assert 10 <= len(emb.sweep_counts) <= 40 and emb.sweep_counts[0] > 20
+    assert emb.outer_deltas[0] > 1e6 * max(emb.outer_deltas[1], 1e-30) or emb.outer_deltas[1] == 0.0
+    Zf = eng.get_Z()
+    assert torch.isfinite(Zf.float()).all()
+    eng.build_P()
+    assert residual(Zf, Zf, eng.P_global().numpy()) < 8e-3           # the fixed point of the reference's update
+
+
+# ---- RCCL on the hardware that exists: a one-rank "nccl" group on cuda:0 -----------------------------------------------
+def test_rccl_single_rank_group_drives_the_engine_collectives(dev):
+    """backend="nccl" IS RCCL on ROCm.  One rank cannot show scaling, but it runs every collective the engine issues
+    through the real library on device tensors: the in-place all-gather and the split-size all-to-all with
+    `async_op=True` issued from side streams, the float64 scalar all-reduce, and a whole row-partitioned sweep
+    (`exchange="allgather_all"`: north_star's row partition + in-place all-gather) whose result must be the plain
+    one-GPU engine's, bit for bit."""
+    import torch.distributed as dist
+    from clane_amd.comm import TorchComm
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        pg = dist.group.WORLD
+        comm = TorchComm(pg, force_collectives=True)
+        t = torch.arange(5, dtype=torch.float64, device=dev)
+        comm.all_reduce_sum(t)
+        assert torch.equal(t.cpu(), torch.arange(5, dtype=torch.float64))
+        for dtype in (torch.float32, torch.bfloat16, torch.float64):
+            table = torch.zeros(64, 32, dtype=dtype, device=dev)
+            mine = table[16:48]                                         # in-place form: the send buffer is a slice of
+            mine.copy_(torch.randn(32, 32, device=dev).to(dtype))       # the receive buffer
+            keep = mine.clone()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                w = comm.all_gather_into(table[16:48], mine, async_op=True)
+            w.wait()
+            assert torch.equal(table[16:48], keep) and float(table[:16].abs().sum()) == 0
+            send = torch.randn(40, 32, device=dev).to(dtype)
+            recv = torch.zeros(40, 32, dtype=dtype, device=dev)
+            with torch.cuda.stream(side):
+                w = comm.all_to_all_rows(recv, send, [40], [40], async_op=True)
+            w.wait()
+            torch.cuda.current_stream(dev).synchronize()
+            assert torch.equal(recv, send)
+        # a whole engine over the group: chunked blocks, RCCL all-gather per chunk on side streams, scalar all-reduce
+        V, E, d, gamma = 20_000, 300_000, 64, 0.76
+        csr = synth.rmat_csr(V, E, seed=9)
+        X = synth.gaussian_X(V, d, seed=10)
+        plain = SweepEngine(csr, X, dev)
+        plain.build_P()
+        for exchange in ("allgather_all", "allgather", "columns"):
+            eng = SweepEngine(csr, X, dev, comm=TorchComm(pg, force_collectives=True), exchange=exchange, chunks=3,
+                              shuffle=False)
+            assert eng.exchange == exchange and eng.comm.force
+            eng.build_P()
+            assert rel(eng.P_global(), plain.P_global()) < 2e-6
+            plain.set_Z(X)
+            plain.P_valid = True
+            for _ in range(3):
+                da, db = eng.sweep(gamma), plain.sweep(gamma)
+                assert da == pytest.approx(db, rel=1e-6)
+            assert O.rel_l2(eng.get_Z(), plain.get_Z()) < 2e-6
+            assert eng.comm.calls["all_reduce"] >= 3
+            if exchange != "columns":
+                assert eng.comm.calls["all_gather"] >= 9                    # 3 chunks x 3 sweeps
+    finally:
+        dist.destroy_process_group()
+
+
+# ---- f4: the README's downstream protocol fed with GPU output ---------------------------------------------------------
+def test_f1_harness_on_gpu_embeddings(tmp_path):
+    """README.md:51-73 (logistic regression on Z, train ratios 10 % ... 90 %, 10 runs, micro / macro F1) on the
+    karate graph with the reference's own label file (tests/data_root/Y, golden G10): embeddings produced by
+    Embedder.iterate() on the GPU give the same table as the oracle's embeddings (same splits, same seeds)."""
+    spec = importlib.util.spec_from_file_location("evaluate_f1", ROOT / "tools" / "evaluate_f1.py")
+    f1 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(f1)
+    kc, lab, g4 = load_golden("g2_karate_csr.npz"), load_golden("g10_karate_labels_log.npz"), load_golden("g4_karate_d16.npz")
+    assert list(kc["vertex_ids"]) == list(lab["Y_ids"])
+    root = write_data_root(tmp_path / "karate", kc["vertex_ids"], kc["edge_src"], kc["edge_dst"], g4["X"])
+    (root / "Y").write_text("\n".join(f"{i}\t{c}" for i, c in zip(lab["Y_ids"], lab["Y_classes"])) + "\n")
+    y = f1.read_labels(root / "Y")
+    assert len(y) == 34 and len(set(y.tolist())) == 4
+    g = Graph(root)
+    emb = Embedder(g, CosineSimilarity(), torch.device("cuda"), gamma=float(g4["gamma"]), tolerence=int(g4["tolerence"]),
+                   verbose=False)
+    emb.iterate()
+    Z_gpu = g.Z.numpy()
+    orc = O.OracleEmbedder(g.csr.rowptr, g.csr.colidx, torch.from_numpy(g4["X"]), gamma=float(g4["gamma"]),
+                           tolerence=int(g4["tolerence"]))
+    Z_or = orc.iterate().numpy()
+    assert O.rel_l2(torch.from_numpy(Z_gpu), torch.from_numpy(g4["Z_final"])) < 1e-5
+    ratios = [r / 10 for r in range(1, 10)]
+    t_gpu, t_or, t_ref = (np.array(f1.f1_table(Z, y, ratios, runs=10)) for Z in (Z_gpu, Z_or, g4["Z_final"]))
+    assert t_gpu.shape == (9, 3) and np.isfinite(t_gpu).all() and (t_gpu[:, 1:] >= 0).all() and (t_gpu[:, 1:] <= 1).all()
+    np.testing.assert_allclose(t_gpu, t_or, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(t_gpu, t_ref, rtol=0, atol=1e-12)          # and the reference's own embeddings

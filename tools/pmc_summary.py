@@ -7,7 +7,8 @@ gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half th
 launches l1_distance_kernel over two [V, ld] matrices whose byte count is known.
 
     python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE \
-        --known-bytes 4096000000 --tag r01 --workload rmat2m_n1 [--stats gpurun_out/prof1]
+        --known-bytes 4096000000 --tag r02 --workload rmat2m_n1 --bench-json gpurun_out/pmc_fetch.json \
+        [--stats gpurun_out/prof1]
 """
 import argparse
 import collections
@@ -40,6 +41,9 @@ def main():
     ap.add_argument("--tag", default="r01")
     ap.add_argument("--workload", default="rmat2m_n1")
     ap.add_argument("--stats", default=None)
+    ap.add_argument("--bench-json", default=None,
+                    help="the JSON line bench.py printed in the PMC run: its roofline.kernel_config is stored with the "
+                         "entry, and bench.py only quotes the traffic for a run with the same configuration")
     args = ap.parse_args()
     out = Path(__file__).resolve().parent.parent / "profiles"
     out.mkdir(exist_ok=True)
@@ -73,6 +77,9 @@ def main():
     tfile = out / "traffic.json"
     data = json.loads(tfile.read_text()) if tfile.exists() else {}
     entry = {"fetch_correction": factor, "source": f"profiles/{args.tag}_pmc_traffic_{args.workload}.md"}
+    if args.bench_json:
+        line = [ln for ln in Path(args.bench_json).read_text().splitlines() if ln.startswith("{")][-1]
+        entry["kernel_config"] = json.loads(line)["roofline"]["kernel_config"]
     for k, v in summary.items():
         if bench_name(k):
             entry[bench_name(k)] = {"bytes_per_launch": v["fetch_bytes"] + v["write_bytes"], "rocprof_name": k}
