@@ -106,15 +106,17 @@ def cpu_baseline(csr, X, P_host, gamma, Z1_gpu, budget_s=15.0):
 def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=8.0):
     """The PyTorch-CPU restatement SURVEY 8d names --  Z = X + gamma * torch.sparse.mm(P, Z)  plus the L1 delta,
     as in oracle/clane_oracle.py:sweep -- on all host threads and on ONE thread.  A full sweep takes seconds to
-    minutes that way, so each figure is timed on a bounded SAMPLE of the workload, every m-th row of the graph
-    (same degree mix), and scaled by the share of the edges the sample holds."""
+    minutes that way, so each figure is timed on a bounded SAMPLE of the workload, a seeded random 1/m of the rows
+    (same degree mix; every m-th row would not do: R-MAT's hubs sit on the ids with trailing zero bits), and scaled
+    by the share of the edges the sample holds."""
     deg = np.diff(csr.rowptr)
     E, V = int(csr.rowptr[-1]), csr.num_vertices
     Z = Xf
     all_threads = torch.get_num_threads()
 
     def timed(stride, threads, reps):
-        rows = np.arange(0, V, stride, dtype=np.int64)
+        rows = np.arange(V, dtype=np.int64) if stride == 1 else \
+            np.sort(np.random.default_rng(stride).choice(V, size=max(1, V // stride), replace=False))
         take = np.repeat(csr.rowptr[rows], deg[rows]) + (np.arange(int(deg[rows].sum())) -
                                                          np.repeat(np.cumsum(deg[rows]) - deg[rows], deg[rows]))
         idx = torch.stack([torch.from_numpy(np.repeat(np.arange(rows.size), deg[rows])),
@@ -145,11 +147,11 @@ def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=8.0):
     stride_1 = max(1, int(np.ceil(probe1 * 2 / budget_s)))
     per_1, share_1, n_1 = timed(stride_1, 1, 1)
     return {"value": 1.0 / per_all, "unit": "sweeps/s", "cores": all_threads, "kind": "port",
-            "sample": f"X + gamma*torch.sparse.mm(P, Z) + L1 delta (oracle/clane_oracle.py:sweep) on every "
-                      f"{stride_all}-th row ({n_all} rows, {share_all:.1%} of the edges), best of 2, scaled to a whole "
+            "sample": f"X + gamma*torch.sparse.mm(P, Z) + L1 delta (oracle/clane_oracle.py:sweep) on a random "
+                      f"1/{stride_all} of the rows ({n_all} rows, {share_all:.1%} of the edges), best of 2, scaled to a whole "
                       f"sweep; torch {torch.__version__}, {all_threads} threads",
             "one_thread": {"value": 1.0 / per_1, "unit": "sweeps/s", "cores": 1,
-                           "sample": f"the same on every {stride_1}-th row ({n_1} rows, {share_1:.2%} of the edges), "
+                           "sample": f"the same on a random 1/{stride_1} of the rows ({n_1} rows, {share_1:.2%} of the edges), "
                                      f"torch.set_num_threads(1)"}}
 
 
@@ -291,9 +293,11 @@ def main():
     torch.cuda.synchronize()
     build_p_ms = (time.perf_counter() - t0) * 1e3
 
+    calibration_bytes = None
     if args.calibrate:      # known-size streaming read in this library's own 16 B/lane access pattern
         eng.snapshot()
         eng.distance_from_snapshot()
+        calibration_bytes = 2 * eng.part.n_local * eng.ld * eng.Zcur.element_size()    # l1_distance reads two matrices
     Z1 = None
     if not args.no_parity:              # the sweep the oracle is checked against (Z = X before it); collective
         eng.sweep(args.gamma)
@@ -406,6 +410,8 @@ def main():
                      "kernel_config": eng.kernel_config()},
         "build_P_ms": build_p_ms, "last_delta": delta,
     }
+    if calibration_bytes is not None:
+        result["calibration"] = {"kernel": "l1_distance_kernel", "bytes_read": calibration_bytes}
     if Z1 is not None:              # rank 0: the first sweep against the C oracle -- at any N
         from oracle import clane_oracle as O
         if world == 1 and not args.no_cpu_baseline:

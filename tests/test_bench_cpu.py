@@ -59,6 +59,9 @@ def test_traffic_is_only_quoted_for_the_configuration_it_was_measured_with(tmp_p
         other, _ = _fake_engine(**change)
         got, why = bench.traffic_entry("w", 1, other, "k")
         assert got is None and "stale" in why and list(change)[0] in why
+    # the committed table: the headline workload's entry carries the configuration it was measured with
+    real = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    assert "kernel_config" in real["rmat2m_n1"] and real["rmat2m_n1"]["kernel_config"]["d"] == 256
 
 
 def test_sampled_torch_baseline_matches_a_full_sweep_in_order_of_magnitude():
@@ -70,7 +73,7 @@ def test_sampled_torch_baseline_matches_a_full_sweep_in_order_of_magnitude():
     P = O.build_P_values(csr.rowptr, csr.colidx, X)
     out = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=0.02)      # tiny budget: forces row sampling
     assert out["kind"] == "port" and out["cores"] == torch.get_num_threads() and out["one_thread"]["cores"] == 1
-    assert "torch.sparse.mm" in out["sample"] and "-th row" in out["sample"]
+    assert "torch.sparse.mm" in out["sample"] and "random 1/" in out["sample"]
     Ps = O.as_sparse(csr.rowptr, csr.colidx, P)
     O.sweep(csr.rowptr, csr.colidx, P, X, X, 0.76, Ps)
     t0 = time.perf_counter()

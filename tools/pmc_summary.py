@@ -37,7 +37,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch_dir")
     ap.add_argument("write_dir")
-    ap.add_argument("--known-bytes", type=float, required=True, help="bytes read by l1_distance_kernel")
+    ap.add_argument("--known-bytes", type=float, default=None,
+                    help="bytes read by l1_distance_kernel (default: calibration.bytes_read of --bench-json)")
+    ap.add_argument("--out", default=None, help="directory to write into (default: profiles/ of this checkout)")
     ap.add_argument("--tag", default="r01")
     ap.add_argument("--workload", default="rmat2m_n1")
     ap.add_argument("--stats", default=None)
@@ -45,8 +47,16 @@ def main():
                     help="the JSON line bench.py printed in the PMC run: its roofline.kernel_config is stored with the "
                          "entry, and bench.py only quotes the traffic for a run with the same configuration")
     args = ap.parse_args()
-    out = Path(__file__).resolve().parent.parent / "profiles"
-    out.mkdir(exist_ok=True)
+    repo_profiles = Path(__file__).resolve().parent.parent / "profiles"
+    out = Path(args.out) if args.out else repo_profiles
+    out.mkdir(parents=True, exist_ok=True)
+    bench_line = None
+    if args.bench_json:
+        bench_line = json.loads([ln for ln in Path(args.bench_json).read_text().splitlines() if ln.startswith("{")][-1])
+        if args.known_bytes is None:
+            args.known_bytes = float(bench_line["calibration"]["bytes_read"])
+    if args.known_bytes is None:
+        raise SystemExit("--known-bytes or a --bench-json of a `bench.py --calibrate` run is needed")
     fetch, write = per_kernel(args.fetch_dir), per_kernel(args.write_dir)
     cal = [k for k in fetch if "l1_distance_kernel" in k][0]
     factor = args.known_bytes / (fetch[cal][0] * 1024)
@@ -75,11 +85,11 @@ def main():
         return None
 
     tfile = out / "traffic.json"
-    data = json.loads(tfile.read_text()) if tfile.exists() else {}
+    seed = tfile if tfile.exists() else repo_profiles / "traffic.json"
+    data = json.loads(seed.read_text()) if seed.exists() else {}
     entry = {"fetch_correction": factor, "source": f"profiles/{args.tag}_pmc_traffic_{args.workload}.md"}
-    if args.bench_json:
-        line = [ln for ln in Path(args.bench_json).read_text().splitlines() if ln.startswith("{")][-1]
-        entry["kernel_config"] = json.loads(line)["roofline"]["kernel_config"]
+    if bench_line is not None:
+        entry["kernel_config"] = bench_line["roofline"]["kernel_config"]
     for k, v in summary.items():
         if bench_name(k):
             entry[bench_name(k)] = {"bytes_per_launch": v["fetch_bytes"] + v["write_bytes"], "rocprof_name": k}
