@@ -44,8 +44,6 @@ WORKLOADS = {
 DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "f64": torch.float64}
 PARITY_TOL = {"f32": 1e-4, "f64": 1e-10, "bf16": 8e-3}       # bf16: 2^-8 rounding of every stored value
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNEL_NAMES = {"main": "spmm_update_kernel", "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>",
-                "split": "spmm_split_segment_kernel+combine"}
 TRAFFIC_NOTE = ("traffic = rocprofv3 FETCH_SIZE x calibrated factor + WRITE_SIZE per launch (separate --pmc passes, "
                 "profiles/); these counters sit on the L2's fabric side, so Infinity-Cache hits are counted as "
                 "traffic: frac = min(algorithmic, traffic) bytes / kernel time / 8 TB/s is an UPPER bound of the "
@@ -190,6 +188,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=None)
     ap.add_argument("--long-threshold", type=int, default=None)
     ap.add_argument("--hub-threshold", type=int, default=None)
+    ap.add_argument("--class-threshold", type=int, default=None,
+                    help="rows above this many edges take the XCD-affine pass (0 = off; default: by row width)")
+    ap.add_argument("--class-chunk", type=int, default=256)
     ap.add_argument("--no-split-hubs", action="store_true", help="hub rows by one workgroup each (no segment split)")
     ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all"],
@@ -277,12 +278,14 @@ def main():
     t0 = time.perf_counter()
     eng = SweepEngine(csr, X, dev, process_group=pg, chunks=args.chunks, long_threshold=args.long_threshold,
                       hub_threshold=args.hub_threshold, exchange=args.exchange,
-                      hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs)
+                      hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs,
+                      class_threshold=args.class_threshold, class_chunk=args.class_chunk)
     torch.cuda.synchronize()
     log(f"engine up in {time.perf_counter() - t0:.1f}s; rank rows={eng.part.n_local} edges={eng.E_loc} "
         f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
         f"hub(16 waves)={sum(0 if l is None else l.numel() for l in eng.hub_rows)} "
         f"split={sum(0 if l is None else l[0].numel() for l in eng.split_rows)} "
+        f"class={sum(0 if l is None else l[0].numel() for l in eng.class_rows)} "
         f"thresholds {eng.long_threshold}/{eng.hub_threshold}")
 
     # build_P once (timed separately, not part of a step), P frozen afterwards
@@ -345,6 +348,7 @@ def main():
     chunks = len(eng.blocks)          # launches of each kernel per sweep
     kbytes = eng.kernel_bytes()
     per_kernel = {}
+    KERNEL_NAMES = eng.kernel_names()
     for key, ms in ktimes.items():
         if kbytes[key] > 0 and ms > 0:       # ms = per sweep, summed over the blocks
             gbps = kbytes[key] / (ms * 1e-3) / 1e9

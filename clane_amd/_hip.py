@@ -19,7 +19,7 @@ import torch
 
 LIB_NAME = "libclane_hip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SCORE_REFERENCE, SCORE_PER_EDGE, SCORE_RAW_DOT = 0, 1, 2
 SPMM_SINKS_UNTOUCHED = 1
@@ -37,6 +37,7 @@ SIGNATURES = {
     "clane_reduce_ws_len": (_i64, []),
     "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p, _p]),
     "clane_spmm_split_slab_len": (_i64, [_i64, _i32]),
+    "clane_spmm_class_slab_len": (_i64, [_i64, _i32]),
     "clane_device_alloc": (C.c_int, [_i64, C.POINTER(_p)]),
     "clane_device_free": (C.c_int, [_p]),
     "clane_ipc_export": (C.c_int, [_p, _p]),
@@ -56,6 +57,9 @@ for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_spmm_update_split_{_s}"] = (
         C.c_int,
         [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
+    SIGNATURES[f"clane_spmm_update_class_{_s}"] = (
+        C.c_int,
+        [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 for _s in ("f32", "f64"):
@@ -378,6 +382,29 @@ class HipKernels:
                      _vec(P, acc_dtype(Z_old.dtype), "P"), _vec(split_rows, torch.int32, "split_rows"),
                      _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(seg_row, torch.int32, "seg_row"),
                      split_rows.numel(), seg_row.numel(), edges_per_segment, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
+                     _vec(slab, acc_dtype(Z_old.dtype), "slab"), _mirror_arg(mirror, Z_new.dtype),
+                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+
+    def spmm_class_slab_len(self, n_slots: int, d: int) -> int:
+        return int(self.lib.clane_spmm_class_slab_len(n_slots, d))
+
+    def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block: int, class_rows, slot_ptr,
+                          row0: int, Z_old, X, gamma: float, Z_new, d: int, slab, partials,
+                          mirror: Optional[Mirror] = None):
+        """XCD-affine pass over the listed long rows (edges sorted by (column % 8, column), cut into items; item
+        blocks of class b at block index 8 j + b) + fixed-order combine; writes class_rows.numel() partials."""
+        zo, ldz = _mat(Z_old, "Z_old")
+        xp, ldx = _mat(X, "X")
+        zn, ldo = _mat(Z_new, "Z_new")
+        n_items = item_e0.numel()
+        if n_items % items_per_block or item_len.numel() != n_items or item_slot.numel() != n_items:
+            raise ValueError("spmm_update_class: the item arrays must hold whole blocks of items_per_block items")
+        self._invoke(self._fn("clane_spmm_update_class", Z_old.dtype), "clane_spmm_update_class",
+                     _vec(colidx, torch.int32, "colidx"), _vec(P, acc_dtype(Z_old.dtype), "P"),
+                     _vec(item_e0, torch.int64, "item_e0"), _vec(item_len, torch.int32, "item_len"),
+                     _vec(item_slot, torch.int32, "item_slot"), n_items // items_per_block, items_per_block,
+                     _vec(class_rows, torch.int32, "class_rows"), _vec(slot_ptr, torch.int64, "slot_ptr"),
+                     class_rows.numel(), row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
                      _vec(slab, acc_dtype(Z_old.dtype), "slab"), _mirror_arg(mirror, Z_new.dtype),
                      _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 

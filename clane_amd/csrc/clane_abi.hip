@@ -49,10 +49,17 @@ constexpr int kLongWaves = CLANE_LONG_WAVES;
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Row kernels (K1, K2, K3): a workgroup owns `rows_per_block` consecutive rows; the grid is kept
-// <= 65536 workgroups and >> the 2048 resident ones, so the dispatcher load-balances skewed rows.
+// Row kernels (K1, K2, K3): a workgroup owns `rows_per_block` consecutive rows.  The grid aims at ~32k workgroups
+// (>> the 2048 resident ones, so the dispatcher load-balances skewed rows) of at least CLANE_ROWS_PER_BLOCK rows:
+// a workgroup's start-up -- rowptr slice to LDS, barrier, first claims -- is a chain of dependent round trips, and
+// with 8 rows per wave-instruction (128-byte rows) 32 rows are ONE row per sub-wave.  Measured
+// (profiles/r02_ab_rows_per_block.md): 2M rows x 128 B 0.760 -> 0.712 ms at 64 rows; 10M rows bf16 8.6 -> 8.2 ms at
+// 256; a 200k-row graph loses 12 % above 32 (too few workgroups), 2M rows lose 30 % at 256.
+#ifndef CLANE_TARGET_GRID
+#define CLANE_TARGET_GRID 32768
+#endif
 inline int rows_per_block(int64_t nrows) {
-    const int64_t r = ceil_div(ceil_div(nrows, 65536), kWavesPerBlock) * kWavesPerBlock;
+    const int64_t r = ceil_div(ceil_div(nrows, CLANE_TARGET_GRID), kWavesPerBlock) * kWavesPerBlock;
     return int(r < CLANE_ROWS_PER_BLOCK ? CLANE_ROWS_PER_BLOCK : r > kMaxRowsPerBlock ? kMaxRowsPerBlock : r);
 }
 inline int row_grid(int64_t nrows) { return int(ceil_div(nrows > 0 ? nrows : 1, rows_per_block(nrows))); }
@@ -313,6 +320,40 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
     return check_launch("spmm_update_split");
 }
 
+template <typename T, typename PT>
+int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0, const int32_t *item_len,
+                      const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,
+                      const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const T *Z_old, int64_t ldz, const T *X,
+                      int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d,
+                      typename Elem<T>::acc_t *slab, const clane_mirror_t *mirror, double *delta_partials,
+                      void *stream) {
+    REQUIRE(mirror_ok(mirror, d), "spmm_update_class: incomplete mirror descriptor");
+    REQUIRE(n_blocks >= 0 && n_blocks <= INT32_MAX && n_rows >= 0 && n_rows <= INT32_MAX && row0 >= 0 && d > 0,
+            "spmm_update_class: bad shape");
+    REQUIRE(items_per_block >= kWavesPerBlock && items_per_block <= kMaxItemsPerBlock,
+            "spmm_update_class: items_per_block must be in [%d, %d]", kWavesPerBlock, kMaxItemsPerBlock);
+    REQUIRE(ldz >= d && ldx >= d && ldo >= d, "spmm_update_class: leading dimension < d");
+    if (n_rows == 0) return CLANE_OK;
+    REQUIRE(colidx && P && item_e0 && item_len && item_slot && class_rows && slot_ptr && Z_old && X && Z_new && slab &&
+                delta_partials,
+            "spmm_update_class: null pointer");
+    REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update_class: Z_new must not alias Z_old");
+    REQUIRE(aligned16(slab), "spmm_update_class: slab must be 16-byte aligned");
+    const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror_alignment_probe(mirror, Z_new)},
+                                    {ldz, ldx, ldo, mirror && mirror->row_ptr ? mirror->ld : ldo});
+    const int64_t ld_slab = ceil_div(d, 8) * 8;
+    const Mirror<T> mir = make_mirror<T>(mirror);
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        constexpr int U = VEC > 1 ? CLANE_LONG_U : 4;
+        if (n_blocks > 0)
+            spmm_class_chunk_kernel<T, PT, VEC, LPR, U><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
+                colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab);
+        spmm_class_combine_kernel<T, VEC><<<unsigned(n_rows), kWave, 0, (hipStream_t)stream>>>(
+            class_rows, slot_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
+    });
+    return check_launch("spmm_update_class");
+}
+
 template <typename T>
 int l1_distance(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows, int32_t d, double *ws, double *out,
                 void *stream) {
@@ -376,7 +417,7 @@ const char *clane_last_error(void) { return g_err; }
 const char *clane_build_info(void) {
     return "arch=gfx950;SPMM_U=" CLANE_STR(CLANE_SPMM_U) ";LONG_U=" CLANE_STR(CLANE_LONG_U) ";LONG_WAVES=" CLANE_STR(
         CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM)
-        ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH);
+        ";TARGET_GRID=" CLANE_STR(CLANE_TARGET_GRID) ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH);
 }
 
 int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long) {
@@ -504,6 +545,23 @@ CLANE_SPLIT_WRAPPER(f32, float, float, float, float)
 CLANE_SPLIT_WRAPPER(f64, double, double, double, double)
 CLANE_SPLIT_WRAPPER(bf16, uint16_t, bf16_t, float, float)
 #undef CLANE_SPLIT_WRAPPER
+#define CLANE_CLASS_WRAPPER(SUF, CT, T, PT, GT)                                                                        \
+    int clane_spmm_update_class_##SUF(const int32_t *colidx, const PT *P, const int64_t *item_e0,                     \
+                                      const int32_t *item_len, const int32_t *item_slot, int64_t n_blocks,            \
+                                      int32_t items_per_block, const int32_t *class_rows, const int64_t *slot_ptr,    \
+                                      int64_t n_rows, int64_t row0, const CT *Z_old, int64_t ldz, const CT *X,        \
+                                      int64_t ldx, GT gamma, CT *Z_new, int64_t ldo, int32_t d, GT *slab,             \
+                                      const clane_mirror_t *mirror, double *delta_partials, void *stream) {           \
+        return spmm_update_class<T, PT>(colidx, P, item_e0, item_len, item_slot, n_blocks, items_per_block,           \
+                                        class_rows, slot_ptr, n_rows, row0, reinterpret_cast<const T *>(Z_old), ldz,  \
+                                        reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new),     \
+                                        ldo, d, slab, mirror, delta_partials, stream);                                \
+    }
+CLANE_CLASS_WRAPPER(f32, float, float, float, float)
+CLANE_CLASS_WRAPPER(f64, double, double, double, double)
+CLANE_CLASS_WRAPPER(bf16, uint16_t, bf16_t, float, float)
+#undef CLANE_CLASS_WRAPPER
+int64_t clane_spmm_class_slab_len(int64_t n_slots, int32_t d) { return n_slots * (ceil_div(d, 8) * 8); }
 int64_t clane_spmm_split_slab_len(int64_t n_segments, int32_t d) { return n_segments * (ceil_div(d, 4) * 4); }
 
 CLANE_SPMM_WRAPPERS(f32, float, float, float, float)

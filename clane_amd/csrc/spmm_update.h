@@ -586,3 +586,127 @@ __global__ __launch_bounds__(kWave) void spmm_split_combine_kernel(
 }
 
 }  // namespace clane
+
+namespace clane {
+
+// ---- class-affine rows: every gathered row is read through ONE XCD's L2 --------------------------------------
+// The 256 CUs sit in 8 XCDs with a private 4 MiB L2 each, and workgroups are dealt to the XCDs round-robin
+// (workgroup w runs on XCD w % 8).  When any workgroup may gather any row, all eight L2s end up caching the SAME
+// few thousand hottest rows.  Here the edges of a long row are sorted by (column % 8, column) and cut into CHUNKS of
+// at most a few hundred edges of one class; the chunks of class b are dealt to the workgroups w = 8 j + b, so
+// XCD b only ever gathers rows r with r % 8 == b and the eight L2s cache eight DIFFERENT eighths of the hot rows
+// (Z is laid out hottest rows first, so every class gets its share of the heat).  Measured on config 3
+// (profiles/r02_xcd_class_experiment.md): pure 1-KiB-row gathers 8.9 -> 14.3 TB/s, the rows above 128 edges
+// 3.4 -> 2.4 ms.
+// A chunk is done by one wave -- its partial sum goes to slab[slot] -- and spmm_class_combine_kernel then adds a
+// row's slots IN ORDER (reproducible: no atomics) and runs the usual epilogue.  A workgroup owns
+// `items_per_block` consecutive chunks of its class (padding chunks have length 0); their descriptors are staged
+// in LDS, waves claim them from an LDS counter and request the next chunk's colidx / P before gathering the
+// current one, exactly like spmm_update_kernel does with rows.
+constexpr int kMaxItemsPerBlock = 64;
+
+template <typename T, typename PT, int VEC, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void spmm_class_chunk_kernel(
+    const int32_t *__restrict__ colidx, const PT *__restrict__ P, const int64_t *__restrict__ item_e0,
+    const int32_t *__restrict__ item_len, const int32_t *__restrict__ item_slot, int items_per_block,
+    const T *__restrict__ Zold, int64_t ldz, int d, typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab) {
+    using A = typename Elem<T>::acc_t;
+    __shared__ int64_t s_e0[kMaxItemsPerBlock];
+    __shared__ int s_len[kMaxItemsPerBlock];
+    __shared__ int s_slot[kMaxItemsPerBlock];
+    __shared__ int s_next;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int sub = lane / LPR;
+    const int sl = lane % LPR;
+    const int64_t base = int64_t(blockIdx.x) * items_per_block;
+    for (int i = threadIdx.x; i < items_per_block; i += kBlock) {
+        s_e0[i] = item_e0[base + i];
+        s_len[i] = item_len[base + i];
+        s_slot[i] = item_slot[base + i];
+    }
+    if (threadIdx.x == 0) s_next = kWavesPerBlock;
+    __syncthreads();
+
+    auto claim = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&s_next, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    int cur = wave;
+    int64_t e0 = 0, e1 = 0;
+    EdgeChunk<A> ch{0, A(0)};
+    if (cur < items_per_block) {
+        e0 = s_e0[cur];
+        e1 = e0 + s_len[cur];
+        ch = load_chunk<A, PT>(colidx, P, e0, e1);
+    }
+    while (cur < items_per_block) {
+        const int nxt = claim();
+        int64_t n0 = 0, n1 = 0;
+        EdgeChunk<A> chn{0, A(0)};
+        if (nxt < items_per_block) {
+            n0 = s_e0[nxt];
+            n1 = n0 + s_len[nxt];
+            chn = load_chunk<A, PT>(colidx, P, n0, n1);
+        }
+        if (e1 > e0) {
+            A *out = slab + int64_t(s_slot[cur]) * ld_slab;
+            for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
+                const int c0 = t0 + sl * VEC;
+                const bool col_ok = c0 < d;
+                A acc[VEC];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+                gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
+                fold_subwaves<LPR>(acc);
+                if (col_ok && sub == 0) {
+                    Pack<A, VEC> o;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];
+                    store_pack<A, VEC>(out + c0, o);
+                }
+            }
+        }
+        cur = nxt;
+        e0 = n0;
+        e1 = n1;
+        ch = chn;
+    }
+}
+
+// One wave per class row: its slots summed in order, then  z = x + gamma * sum,  delta, store.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kWave) void spmm_class_combine_kernel(
+    const int32_t *__restrict__ class_rows, const int64_t *__restrict__ slot_ptr, int64_t row0,
+    const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
+    const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
+    Mirror<T> mirror, double *__restrict__ partials) {
+    using A = typename Elem<T>::acc_t;
+    const int i = blockIdx.x;
+    const int64_t r = class_rows[i];
+    const int64_t s0 = slot_ptr[i], s1 = slot_ptr[i + 1];
+    A rsum = A(0);
+    for (int t0 = 0; t0 < d; t0 += kWave * VEC) {
+        const int c0 = t0 + lane_id() * VEC;
+        if (c0 < d) {
+            const Pack<T, VEC> x = load_pack_stream<T, VEC>(X + r * ldx + c0);
+            const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
+            A acc[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+#pragma unroll 4
+            for (int64_t s = s0; s < s1; ++s) {
+                const Pack<A, VEC> part = load_pack<A, VEC>(slab + s * ld_slab + c0);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += part.v[k];
+            }
+            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0);
+        }
+    }
+    rsum = group_sum<kWave>(rsum);
+    if (lane_id() == 0) partials[i] = double(rsum);
+}
+
+}  // namespace clane
+

@@ -32,7 +32,7 @@ import torch
 from . import _hip
 from .comm import TorchComm
 from .halo import build_halo_layout
-from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
+from .partition import XCD_CLASSES, Block, HostCSR, LocalCSR, RowPartition, localize
 
 # Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md):
 #   deg <= T   one (sub-)wave per row, rows claimed dynamically inside a workgroup
@@ -54,6 +54,17 @@ HUB_FACTOR = 1
 SPLIT_EDGES = 4096
 MIN_SEGMENT_EDGES = 1024
 TARGET_SEGMENTS = 512                   # two workgroups per CU
+# Rows above CLASS_THRESHOLD edges are gathered XCD-affine (csrc/spmm_update.h, spmm_class_chunk_kernel): their edges
+# are sorted by (column % 8, column), cut into chunks of at most CLASS_CHUNK edges of one class, and the chunks of
+# class b run on the workgroups 8 j + b = XCD b, so each XCD's 4 MiB L2 caches its own eighth of the hot rows instead
+# of all eight caching the same ones.  Costs one partial sum (d accumulators, written + read once) per chunk, which
+# is why short rows stay with the row kernels.  Threshold by rows per wave-instruction, 0 = off; measured
+# (profiles/r02_class_threshold_sweep.md), sweep ms without -> with: config 3 (1 KiB rows) 5.36 -> 4.38 at 64;
+# its column slices: 512-B rows 2.55 -> 2.09 at 64, 256-B rows 1.26 -> 1.09 at 128..256, 128-B rows 0.716 -> 0.679
+# at 256; config 4's shape (bf16, 256-B rows) 8.24 -> 7.79 at 256; config 2 (Z fits the Infinity Cache) unchanged.
+CLASS_THRESHOLD_BY_ROWS_PER_WAVE = {1: 64, 2: 64, 4: 256, 8: 256}
+CLASS_CHUNK = 256
+CLASS_ITEMS_PER_BLOCK = 32
 
 
 def lanes_per_row(d: int, dtype: torch.dtype) -> int:
@@ -88,6 +99,46 @@ def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
     return min(d, p0 * vec), min(d, p1 * vec)
 
 
+def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int) -> dict:
+    """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
+    (column % 8, column)): every class segment of a row is cut into chunks of at most `chunk` edges.
+    Slots -- where the partial sums go -- are numbered row by row, class by class, chunk by chunk, so a row's slots
+    are contiguous (`slot_ptr`) and summed in that order.  Items are laid out for the kernel: blocks of
+    `items_per_block` items of ONE class, block j of class b at block index 8 j + b, padded with empty items
+    (len 0, slot -1).  Returns int64 e0, int32 len, int32 slot (flat, whole blocks) and int64 slot_ptr [rows + 1]."""
+    n = rows.size
+    sizes = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    idx = np.repeat(rowptr[rows] - start, sizes) + np.arange(int(sizes.sum()), dtype=np.int64)
+    cls = colidx[idx].astype(np.int64) % XCD_CLASSES
+    rid = np.repeat(np.arange(n, dtype=np.int64), sizes)
+    if idx.size > 1 and (np.diff(rid * XCD_CLASSES + cls) < 0).any():
+        raise AssertionError("class rows must have their edges sorted by (column % 8, column)")
+    seg_len = np.bincount(rid * XCD_CLASSES + cls, minlength=n * XCD_CLASSES)
+    seg_e0 = np.repeat(rowptr[rows], XCD_CLASSES) + (np.cumsum(seg_len) - seg_len
+                                                      - np.repeat(start, XCD_CLASSES))
+    nchunk = -(-seg_len // chunk)
+    tot = int(nchunk.sum())
+    seg_of = np.repeat(np.arange(n * XCD_CLASSES), nchunk)
+    within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
+    e0 = seg_e0[seg_of] + within * chunk
+    ln = np.minimum(chunk, seg_len[seg_of] - within * chunk)
+    slot_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(nchunk.reshape(n, XCD_CLASSES).sum(1), out=slot_ptr[1:])
+    item_cls = seg_of % XCD_CLASSES
+    per_class = [np.nonzero(item_cls == c)[0] for c in range(XCD_CLASSES)]
+    nblk = max(1, max(-(-len(pc) // items_per_block) for pc in per_class))
+    flat = XCD_CLASSES * nblk * items_per_block
+    out_e0 = np.zeros(flat, dtype=np.int64)
+    out_len = np.zeros(flat, dtype=np.int32)
+    out_slot = np.full(flat, -1, dtype=np.int32)
+    for c, pc in enumerate(per_class):
+        t = np.arange(len(pc))
+        where = (t // items_per_block) * (XCD_CLASSES * items_per_block) + c * items_per_block + t % items_per_block
+        out_e0[where], out_len[where], out_slot[where] = e0[pc], ln[pc], pc
+    return {"e0": out_e0, "len": out_len, "slot": out_slot, "slot_ptr": slot_ptr}
+
+
 class StagedZ:
     """The embeddings of one moment on their way to the host (``SweepEngine.stage_Z``): the sweeps go on while
     the copy drains over PCIe; ``result()`` waits for it and returns a fresh ``[V, d]`` CPU tensor in vertex order."""
@@ -112,7 +163,8 @@ class SweepEngine:
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
                  exchange: str = "auto", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
-                 overlap_chunks: bool = True, fused_pack: bool = True):
+                 overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
+                 class_chunk: int = CLASS_CHUNK):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
@@ -162,6 +214,15 @@ class SweepEngine:
             chunks = 1 if row_world == 1 else 4
         self.hot_rows_first = bool(hot_rows_first)
         self.halo = row_world > 1 and exchange in ("halo", "halo_p2p")
+        rows_per_wave = 64 // lanes_per_row(self.d, X.dtype) if self.d > 0 else 1
+        if class_threshold is None:         # XCD-affine long rows: not with the halo tables (their own relabelling)
+            class_threshold = 0 if self.halo else CLASS_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
+        elif class_threshold and self.halo:
+            raise ValueError("class_threshold: the XCD-affine row kernels are not available with exchange='halo'")
+        self.class_threshold = int(class_threshold)
+        self.class_chunk = int(class_chunk)
+        if self.class_threshold and not (64 <= self.class_chunk <= 4096 and self.class_chunk % 64 == 0):
+            raise ValueError("class_chunk must be a multiple of 64 in [64, 4096]")
         self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
         if self.p2p and self.world > 8:
             raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
@@ -177,12 +238,11 @@ class SweepEngine:
             self.part = RowPartition.create(self.V, row_world, row_rank, chunks, live_mask=live, shuffle=shuffle,
                                             seed=seed, priority=hot)
             self.blocks = self.part.blocks(spans_for_one_rank=self._forced and not self.columns)
-            self.local = localize(csr, self.part, self.device)
+            self.local = localize(csr, self.part, self.device, class_threshold=self.class_threshold)
         if self.part.padded_vertices >= 2 ** 31:
             raise ValueError(f"{self.part.padded_vertices} table rows: column indices are 32-bit (ABI v1); divide the "
                              "rows over more GPUs (exchange='halo') or wait for 64-bit indices")
         if long_threshold is None:
-            rows_per_wave = 64 // lanes_per_row(self.d, X.dtype)
             long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
             if rows_per_wave > 1:
                 # A T-edge row walked by one sub-wave takes T/8 gather groups in sequence -- the tail of its launch.
@@ -190,6 +250,10 @@ class SweepEngine:
                 # 3 545 sweeps/s at T=128, 2 013 at T=1024), so T also scales with the edges of the pass.
                 by_size = 1 << max(7, int(self.local.colidx.shape[0] // 32768).bit_length() - 1)
                 long_threshold = min(long_threshold, by_size)
+        # K1 / K2 (build_P) cut rows at the same degree as before; K3's one-(sub-)wave pass also stops below the class rows
+        self.score_threshold = int(long_threshold)
+        if self.class_threshold:            # the class rows are nobody else's
+            long_threshold = min(long_threshold, self.class_threshold) if long_threshold > 0 else self.class_threshold
         self.long_threshold = int(long_threshold)
         self.hub_threshold = int(hub_threshold) if hub_threshold is not None else HUB_FACTOR * self.long_threshold
         dev = self.device
@@ -206,23 +270,38 @@ class SweepEngine:
         deg = np.diff(self.local.rowptr)
         self.max_degree = int(deg.max()) if deg.size else 0
         # per block: row lists relative to the block's first row (the kernels get rowptr / X / Z_new offset to it)
-        self.long_rows: List[Optional[torch.Tensor]] = []     # every row above long_threshold (K1 / K2 slice these)
+        self.long_rows: List[Optional[torch.Tensor]] = []     # every row above score_threshold (K1 / K2 slice these)
         self.mid_rows: List[Optional[torch.Tensor]] = []      # long_threshold < deg <= hub_threshold: 4 waves/row
         self.hub_rows: List[Optional[torch.Tensor]] = []      # hub_threshold < deg <= SPLIT_EDGES: 16 waves/row
         self.split_rows: List[Optional[tuple]] = []           # deg > SPLIT_EDGES: (rows, seg_ptr, seg_row) on device
+        self.class_rows: List[Optional[tuple]] = []           # deg > class_threshold: (rows, slot_ptr, e0, len, slot)
         self.split_edges = SPLIT_EDGES if split_hubs else 0
         hub_edges = int(deg[deg > SPLIT_EDGES].sum()) // max(1, len(self.blocks))
         self.segment_edges = int(min(SPLIT_EDGES, max(MIN_SEGMENT_EDGES, hub_edges // TARGET_SEGMENTS // 1024 * 1024)))
-        max_segments = 0
+        max_segments = max_slots = 0
         self.partial_off = [0]
         to_dev = lambda a: torch.from_numpy(a.astype(np.int32)).to(dev) if a.size else None  # noqa: E731
         for b in self.blocks:
             db = deg[b.local_start:b.local_start + b.nrows]
             is_long = db > self.long_threshold if self.long_threshold > 0 else np.zeros_like(db, dtype=bool)
-            is_split = is_long & (db > self.split_edges) if self.split_edges > 0 else np.zeros_like(is_long)
-            is_hub = is_long & (db > self.hub_threshold) & ~is_split
-            self.long_rows.append(to_dev(np.nonzero(is_long)[0]))
-            self.mid_rows.append(to_dev(np.nonzero(is_long & ~is_hub & ~is_split)[0]))
+            is_class = db > self.class_threshold if self.class_threshold > 0 else np.zeros_like(db, dtype=bool)
+            is_long = is_long | is_class
+            is_split = (is_long & (db > self.split_edges) if self.split_edges > 0 else np.zeros_like(is_long)) & ~is_class
+            is_hub = is_long & (db > self.hub_threshold) & ~is_split & ~is_class
+            self.long_rows.append(to_dev(np.nonzero(db > self.score_threshold)[0] if self.score_threshold > 0
+                                         else np.empty(0, dtype=np.int64)))
+            self.mid_rows.append(to_dev(np.nonzero(is_long & ~is_hub & ~is_split & ~is_class)[0]))
+            rows_c = np.nonzero(is_class)[0]
+            if rows_c.size:
+                rows_abs = rows_c + b.local_start
+                items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk,
+                                    CLASS_ITEMS_PER_BLOCK)
+                self.class_rows.append((to_dev(rows_c), torch.from_numpy(items["slot_ptr"]).to(dev),
+                                        torch.from_numpy(items["e0"]).to(dev), torch.from_numpy(items["len"]).to(dev),
+                                        torch.from_numpy(items["slot"]).to(dev)))
+                max_slots = max(max_slots, int(items["slot_ptr"][-1]))
+            else:
+                self.class_rows.append(None)
             self.hub_rows.append(to_dev(np.nonzero(is_hub)[0]))
             rows_s = np.nonzero(is_split)[0]
             if rows_s.size:
@@ -238,8 +317,10 @@ class SweepEngine:
             self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(b.nrows, int(is_long.sum())))
         self.partials = torch.zeros(self.partial_off[-1], dtype=torch.float64, device=dev)
         # segment sums of the split hub rows: one slab per launch stream (blocks on a stream run in order)
-        self.slabs = [torch.zeros(max(1, self.k.spmm_split_slab_len(max_segments, self.d)), dtype=self.acc_dtype,
-                                  device=dev) for _ in range(2)]
+        slab_len = max(1, self.k.spmm_split_slab_len(max_segments, max(self.d, 1)))
+        if max_slots:
+            slab_len = max(slab_len, self.k.spmm_class_slab_len(max_slots, self.d))
+        self.slabs = [torch.zeros(slab_len, dtype=self.acc_dtype, device=dev) for _ in range(2)]
 
         # ---- halo exchange: send lists and send buffers (one per own chunk) -----------------
         # The kernel that finishes a row also stores it to its slots of the send buffer (`mirrors`: row -> slots,
@@ -495,20 +576,20 @@ class SweepEngine:
                 rp = self.rowptr[b.local_start:]
                 # K1 soft-maxes every row it scores: one wave in registers / online, a listed row by its workgroup
                 k.edge_score(rp, self.colidx, b.nrows, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
-                             self.long_threshold, self.long_rows[i], fuse_softmax=True)
+                             self.score_threshold, self.long_rows[i], fuse_softmax=True)
         elif self.E_loc > 0:
             # column split: dot products of the owned columns, summed over the GPUs, then denominators + softmax
             if busy:
                 for i, b in enumerate(self.blocks):
                     k.edge_score(self.rowptr[b.local_start:], self.colidx, b.nrows, b.row0, Z, self.d,
-                                 _hip.SCORE_RAW_DOT, None, None, self.P, self.long_threshold, self.long_rows[i])
+                                 _hip.SCORE_RAW_DOT, None, None, self.P, self.score_threshold, self.long_rows[i])
             else:
                 self.P.zero_()
             self._all_reduce(self.P)
             for i, b in enumerate(self.blocks):
                 rp = self.rowptr[b.local_start:]
                 k.edge_score_finalize(rp, self.colidx, b.nrows, b.row0, mode, self.sums2, sq, self.P)
-                k.segment_softmax(rp, b.nrows, self.P, 0, self.long_threshold if self.long_rows[i] is not None else 0,
+                k.segment_softmax(rp, b.nrows, self.P, 0, self.score_threshold if self.long_rows[i] is not None else 0,
                                   self.long_rows[i])
         self.P_valid = True
 
@@ -543,11 +624,18 @@ class SweepEngine:
                 po_mid = po + k.spmm_partials_len(b.nrows, 0)
                 po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
                 po_split = po_hub + (0 if self.hub_rows[i] is None else self.hub_rows[i].numel())
+                po_class = po_split + (0 if self.split_rows[i] is None else self.split_rows[i][0].numel())
                 # biggest rows first: split hubs, 16-wave rows, (4-wave rows), then the one-(sub-)wave-per-row pass
                 steps.append(("event", i, 0))
                 if self.d == 0:              # column-split rank without columns: nothing to launch, delta stays 0
                     per_block.append(steps + [("event", i, e) for e in (4, 1, 2, 3)])
                     continue
+                if self.class_rows[i] is not None:
+                    rows_c, slot_ptr, it_e0, it_len, it_slot = self.class_rows[i]
+                    steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
+                                                     CLASS_ITEMS_PER_BLOCK, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
+                                                     Zn, self.d, self.slabs[i % 2], self.partials[po_class:],
+                                                     mirror=mir)))
                 if self.split_rows[i] is not None:
                     rows_s, seg_ptr, seg_row = self.split_rows[i]
                     steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
@@ -676,10 +764,21 @@ class SweepEngine:
         deg = np.diff(self.local.rowptr)
         per_row = deg * (self.d * s + 4 + ps) + np.where(deg > 0, 3 * self.d * s, 0) + 8   # sinks: rowptr only
         is_long = deg > self.long_threshold if self.long_threshold > 0 else np.zeros_like(deg, dtype=bool)
-        is_split = is_long & (deg > self.split_edges) if self.split_edges > 0 else np.zeros_like(is_long)
-        is_hub = is_long & (deg > self.hub_threshold) & ~is_split
-        return {"main": int(per_row[~is_long].sum()) + 8, "mid": int(per_row[is_long & ~is_hub & ~is_split].sum()),
-                "hub": int(per_row[is_hub].sum()), "split": int(per_row[is_split].sum())}
+        is_class = deg > self.class_threshold if self.class_threshold > 0 else np.zeros_like(deg, dtype=bool)
+        is_long = is_long | is_class
+        is_split = (is_long & (deg > self.split_edges) if self.split_edges > 0 else np.zeros_like(is_long)) & ~is_class
+        is_hub = is_long & (deg > self.hub_threshold) & ~is_split & ~is_class
+        return {"main": int(per_row[~is_long].sum()) + 8,
+                "mid": int(per_row[is_long & ~is_hub & ~is_split & ~is_class].sum()),
+                "hub": int(per_row[is_hub].sum()), "split": int(per_row[is_split | is_class].sum())}
+
+    def kernel_names(self):
+        """Names of the K3 kernels behind the keys of kernel_times_ms() / kernel_bytes()."""
+        narrow = self.d > 0 and lanes_per_row(self.d, self.dtype) < 64
+        return {"main": "spmm_update_subrow_kernel" if narrow else "spmm_update_kernel",
+                "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>",
+                "split": "spmm_class_chunk_kernel+combine" if self.class_threshold > 0
+                else "spmm_split_segment_kernel+combine"}
 
     def kernel_config(self) -> dict:
         """Everything that decides which K3 kernels a sweep launches over which rows, and with which compile-time
@@ -689,8 +788,10 @@ class SweepEngine:
         return {"build": build, "dtype": str(self.dtype).replace("torch.", ""), "d": self.d,
                 "lanes_per_row": lanes_per_row(self.d, self.dtype) if self.d > 0 else 0,
                 "rows": int(self.part.n_local), "edges": int(self.E_loc), "launch_blocks": len(self.blocks),
-                "long_threshold": self.long_threshold, "hub_threshold": self.hub_threshold,
+                "long_threshold": self.long_threshold, "score_threshold": self.score_threshold,
+                "hub_threshold": self.hub_threshold,
                 "split_edges": self.split_edges, "segment_edges": self.segment_edges,
+                "class_threshold": self.class_threshold, "class_chunk": self.class_chunk,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 
     def exchange_bytes_per_sweep(self) -> int:

@@ -176,10 +176,15 @@ class LocalCSR:
     edge_origin: np.ndarray     # int64 [E_local]  index of each local edge in the global CSR order
 
 
-def localize(csr: HostCSR, part: RowPartition, device=None) -> LocalCSR:
+XCD_CLASSES = 8          # MI355X: 8 XCDs, one private L2 each; the class of a table row is its position % 8
+
+
+def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int = 0) -> LocalCSR:
     """Slice + relabel the global CSR for one rank.  The one heavy step -- re-sorting every row's edges by their
     new column -- is a single sort of unique (row, column) keys; with ``device`` = a GPU it runs there (40M edges:
-    seconds on the host, milliseconds on the card)."""
+    seconds on the host, milliseconds on the card).
+    ``class_threshold`` > 0: rows with more edges than that are sorted by (column % 8, column) instead, so that the
+    edges to one XCD class are contiguous (engine: class-affine rows, csrc/spmm_update.h)."""
     V = csr.num_vertices
     if V != part.num_vertices:
         raise ValueError("partition built for a different vertex count")
@@ -193,7 +198,9 @@ def localize(csr: HostCSR, part: RowPartition, device=None) -> LocalCSR:
     rowptr = np.zeros(part.n_local + 1, dtype=np.int64)
     np.cumsum(deg, out=rowptr[1:])
     indeg = np.where(valid, csr.indeg()[safe], 0).astype(np.int32)
-    identity = part.world_size == 1 and part.chunks == 1 and np.array_equal(pos, np.arange(V))
+    by_class = deg > class_threshold if class_threshold > 0 else np.zeros_like(deg, dtype=bool)
+    identity = (part.world_size == 1 and part.chunks == 1 and not by_class.any()
+                and np.array_equal(pos, np.arange(V)))
     if identity:
         return LocalCSR(rowptr, csr.colidx.astype(np.int32), indeg, verts, np.arange(csr.num_edges, dtype=np.int64))
     import torch
@@ -204,6 +211,10 @@ def localize(csr: HostCSR, part: RowPartition, device=None) -> LocalCSR:
     # original edge id of every local edge: start-of-row + offset within the row
     origin = t(csr.rowptr[safe])[row_of] + (torch.arange(int(rowptr[-1]), device=dev) - rowptr_t[:-1][row_of])
     cols = t(pos)[t(csr.colidx.astype(np.int64))[origin]]
-    order = torch.argsort(row_of * part.padded_vertices + cols)          # keys are unique: any sort is THE order
+    key = row_of * part.padded_vertices + cols                           # keys are unique: any sort is THE order
+    if by_class.any():
+        key = row_of * (XCD_CLASSES * part.padded_vertices) + cols + torch.where(
+            t(by_class)[row_of], (cols % XCD_CLASSES) * part.padded_vertices, torch.zeros_like(cols))
+    order = torch.argsort(key)
     cols, origin = cols[order], origin[order]
     return LocalCSR(rowptr, cols.to(torch.int32).cpu().numpy(), indeg, verts, origin.cpu().numpy())

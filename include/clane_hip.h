@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CLANE_ABI_VERSION 1
+#define CLANE_ABI_VERSION 2 /* 2: + clane_build_info, clane_spmm_update_class_* */
 
 #define CLANE_OK 0
 #define CLANE_ERR_INVALID_ARGUMENT (-1)
@@ -219,6 +219,39 @@ int clane_spmm_update_split_f64(const int64_t *rowptr, const int32_t *colidx, co
 int clane_spmm_update_split_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P,
                                  const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,
                                  int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,
+                                 const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
+                                 uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
+                                 double *delta_partials, void *stream);
+
+/*  clane_spmm_update_class_* : long rows whose gathers are kept XCD-affine (no reference counterpart: the reference's
+ *                             loop is embedder.py:84-92 for every row alike).  MI355X has 8 XCDs with a private 4 MiB
+ *                             L2 each and deals workgroups to them round-robin (workgroup w -> XCD w % 8).  The caller
+ *                             sorts the edges of each listed row by (column % 8, column) and cuts every class segment
+ *                             into ITEMS of a few hundred edges; item arrays are laid out in blocks of
+ *                             `items_per_block` (4..64) items of ONE class, block j of class b at block index
+ *                             8 j + b (n_blocks blocks, padding items have item_len = 0), so XCD b only gathers rows
+ *                             r with r % 8 == b and the eight L2s cache different eighths of the hot rows.
+ *                             item_e0 / item_len: edge range of an item in colidx / P; item_slot: where its partial
+ *                             sum goes in `slab` (clane_spmm_class_slab_len(n_slots, d) accumulate-type elements,
+ *                             16-byte aligned).  class_rows[n_rows] local row ids; slot_ptr[n_rows+1]: the slots of
+ *                             row i are [slot_ptr[i], slot_ptr[i+1]) and are added in that order (reproducible),
+ *                             then the usual epilogue.  Writes n_rows doubles to delta_partials. */
+int64_t clane_spmm_class_slab_len(int64_t n_slots, int32_t d);
+int clane_spmm_update_class_f32(const int32_t *colidx, const float *P, const int64_t *item_e0, const int32_t *item_len,
+                                const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
+                                const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
+                                const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
+                                int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
+                                double *delta_partials, void *stream);
+int clane_spmm_update_class_f64(const int32_t *colidx, const double *P, const int64_t *item_e0, const int32_t *item_len,
+                                const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
+                                const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
+                                const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma,
+                                double *Z_new, int64_t ldo, int32_t d, double *slab, const clane_mirror_t *mirror,
+                                double *delta_partials, void *stream);
+int clane_spmm_update_class_bf16(const int32_t *colidx, const float *P, const int64_t *item_e0, const int32_t *item_len,
+                                 const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
+                                 const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
                                  const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
                                  uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
                                  double *delta_partials, void *stream);

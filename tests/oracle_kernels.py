@@ -120,6 +120,41 @@ class OracleKernels:
         for i, r in enumerate(split_rows.tolist()):
             partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d, mirror)
 
+    def spmm_class_slab_len(self, n_slots, d):
+        return n_slots * (-(-d // 8) * 8)
+
+    def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
+                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None):
+        """The XCD-affine pass: partial sums per item into the slab, a row's slots added in order.  Also checks the
+        layout contract the kernel relies on: whole blocks, every item of block w gathers only rows of class w % 8."""
+        e0, ln, sl = _np(item_e0), _np(item_len), _np(item_slot)
+        assert 4 <= items_per_block <= 64 and e0.size % items_per_block == 0 and e0.size // items_per_block % 8 == 0
+        acc = P.dtype
+        ld = -(-d // 8) * 8
+        view = slab[:self.spmm_class_slab_len(int(slot_ptr[-1]), d)].view(-1, ld)
+        view.fill_(float("nan"))
+        for k in range(e0.size):
+            if ln[k] == 0:
+                assert sl[k] == -1
+                continue
+            a, b = int(e0[k]), int(e0[k]) + int(ln[k])
+            cols = colidx[a:b].long()
+            assert bool((cols % 8 == (k // items_per_block) % 8).all()), "item gathers a row of another XCD class"
+            view[sl[k], :d] = (P[a:b].unsqueeze(1) * Z_old[cols, :d].to(acc)).sum(0)
+        mp = None if mirror is None else mirror
+        for i, r in enumerate(class_rows.tolist()):
+            agg = torch.zeros(d, dtype=acc)
+            for s_ in range(int(slot_ptr[i]), int(slot_ptr[i + 1])):
+                agg = agg + view[s_, :d]
+            own = Z_old[row0 + r, :d]
+            new = (X[r, :d].to(acc) + gamma * agg).to(Z_new.dtype)
+            Z_new[r, :d] = new
+            if mp is not None:
+                p_, ms, mbs = mp
+                for s_ in ms[int(p_[r]):int(p_[r + 1])].tolist():
+                    mbs[s_ >> 28][s_ & ((1 << 28) - 1), :d] = new
+            partials[i] = float((new.to(acc) - own.to(acc)).abs().sum())
+
     def reduce_partials(self, partials, n, ws, out):
         out[0] = partials[:n].sum()
 

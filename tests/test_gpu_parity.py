@@ -437,7 +437,7 @@ def test_rmat_200k_parity_and_properties(dev):
     csr = synth.rmat_csr(V, E, seed=1)
     assert csr.num_edges == E and int(np.diff(csr.rowptr).max()) > 1024       # has hub rows -> long-row pass
     X = synth.gaussian_X(V, d, seed=2)
-    eng = SweepEngine(csr, X, dev, long_threshold=64, hub_threshold=256)      # exercise all three K3 kernels
+    eng = SweepEngine(csr, X, dev, long_threshold=64, hub_threshold=256, class_threshold=0)   # the three row kernels
     assert eng.hub_rows[0] is not None and eng.mid_rows[0] is not None
     eng.build_P()
     P_or = O.build_P_values(csr.rowptr, csr.colidx, X)
@@ -687,6 +687,77 @@ def test_spmm_split_hub_rows(dev, k, dtype, d):
     untouched = torch.ones(V, dtype=torch.bool)
     untouched[sel] = False
     assert float(Zs[untouched.to(dev)].abs().sum()) == 0.0           # only the listed rows are written
+
+
+@pytest.mark.parametrize("dtype,d,pad", [(torch.float32, 256, True), (torch.float32, 100, True), (torch.float64, 64, True),
+                                         (torch.bfloat16, 128, True), (torch.float32, 32, True), (torch.float32, 37, False),
+                                         (torch.float32, 1433, True)])
+@pytest.mark.parametrize("chunk", [64, 256])
+def test_spmm_class_affine_rows(dev, k, dtype, d, pad, chunk):
+    """clane_spmm_update_class_*: rows whose edges are sorted by (column % 8, column) and cut into chunks of one
+    class, chunk blocks of class b at block index 8 j + b, partial sums added per row in slot order == the oracle,
+    == the one-workgroup-per-row kernel up to summation order; only the listed rows are written; two launches are
+    bitwise equal; the mirror gets the finished rows."""
+    from clane_amd.engine import class_items
+    csr0 = ragged_csr(900, seed=3, hubs=(700, 129, 64, 900, 385, 65))
+    V, acc, gamma = csr0.num_vertices, _hip.acc_dtype(dtype), 0.76
+    deg = np.diff(csr0.rowptr)
+    rows = np.nonzero(deg > 100)[0]
+    colidx = csr0.colidx.copy()
+    for r in rows:                                                  # class order inside the listed rows
+        a, b = csr0.rowptr[r], csr0.rowptr[r + 1]
+        c = colidx[a:b]
+        colidx[a:b] = c[np.lexsort((c, c % 8))]
+    X = synth.gaussian_X(V, d, seed=1).to(dtype)
+    Zold = (synth.gaussian_X(V, d, seed=2) * 0.5).to(dtype)
+    P = torch.rand(csr0.num_edges, generator=torch.Generator().manual_seed(3)).to(acc) / 50
+    Xd, Zo = padded(X, dtype, dev, None if pad else d), padded(Zold, dtype, dev, None if pad else d)
+    ci_d, P_d = torch.from_numpy(colidx).to(dev), P.to(dev)
+    rp_d = torch.from_numpy(csr0.rowptr).to(dev)
+    items = class_items(csr0.rowptr, colidx, rows, chunk, 8)
+    assert int(items["slot_ptr"][-1]) == int((items["len"] > 0).sum()) >= 8 * rows.size - 8
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    rows_d = t(rows.astype(np.int32))
+    slab = torch.full((k.spmm_class_slab_len(int(items["slot_ptr"][-1]), d),), float("nan"), dtype=acc, device=dev)
+    rng = np.random.default_rng(0)
+    copies = np.zeros(V, dtype=np.int64)
+    copies[rows] = rng.integers(1, 3, rows.size)
+    row_ptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(copies, out=row_ptr[1:])
+    buf = torch.full((int(row_ptr[-1]), Zo.shape[1]), 7.0, dtype=dtype, device=dev)
+    mir = _hip.Mirror(t(row_ptr), t(np.arange(int(row_ptr[-1]), dtype=np.int32)), buf)
+    Zc = torch.zeros_like(Zo)
+    pc = torch.zeros(rows.size, dtype=torch.float64, device=dev)
+    args = (ci_d, P_d, t(items["e0"]), t(items["len"]), t(items["slot"]), 8, rows_d, t(items["slot_ptr"]), 0, Zo, Xd,
+            gamma)
+    k.spmm_update_class(*args, Zc, d, slab, pc, mirror=mir)
+    Z_ref, _ = O.sweep(csr0.rowptr, colidx, P.double(), X.double(), Zold.double(), gamma)
+    sel = torch.from_numpy(rows.astype(np.int64))
+    assert rel(Zc[sel.to(dev), :d], Z_ref[sel]) < TOL[dtype]
+    Zl = torch.zeros_like(Zo)
+    pl = torch.zeros(rows.size, dtype=torch.float64, device=dev)
+    k.spmm_update_long(rp_d, ci_d, P_d, rows_d, 16, 0, Zo, Xd, gamma, Zl, d, pl)
+    assert rel(Zc[sel.to(dev), :d], Zl[sel.to(dev), :d]) < (1e-13 if dtype == torch.float64 else TOL[dtype])
+    assert torch.allclose(pc, pl, rtol=1e-5 if dtype != torch.bfloat16 else 2e-2)
+    want = float((Zc[sel.to(dev), :d].double() - Zo[sel.to(dev), :d].double()).abs().sum())
+    assert float(pc.sum()) == pytest.approx(want, rel=1e-6)
+    untouched = torch.ones(V, dtype=torch.bool)
+    untouched[sel] = False
+    assert float(Zc[untouched.to(dev)].abs().sum()) == 0.0           # only the listed rows are written
+    if pad:
+        assert float(Zc[:, d:].abs().sum()) == 0.0
+    src = torch.from_numpy(np.repeat(np.arange(V), copies)).to(dev)
+    assert torch.equal(buf[:, :d], Zc[src, :d])                      # every copy of every finished row
+    Z2 = torch.zeros_like(Zo)
+    p2 = torch.zeros_like(pc)
+    k.spmm_update_class(*args, Z2, d, slab, p2)
+    assert torch.equal(Z2, Zc) and torch.equal(p2, pc)               # fixed slot order: bitwise reproducible
+    with pytest.raises(_hip.ClaneHipError, match="items_per_block"):
+        k.spmm_update_class(ci_d, P_d, t(items["e0"]), t(items["len"]), t(items["slot"]), 2, rows_d,
+                            t(items["slot_ptr"]), 0, Zo, Xd, gamma, Z2, d, slab, p2)
+    with pytest.raises(ValueError, match="whole blocks"):
+        k.spmm_update_class(ci_d, P_d, t(items["e0"])[:-1], t(items["len"])[:-1], t(items["slot"])[:-1], 8, rows_d,
+                            t(items["slot_ptr"]), 0, Zo, Xd, gamma, Z2, d, slab, p2)
 
 
 @pytest.mark.parametrize("dtype,d,pad", [(torch.float32, 256, True), (torch.float32, 100, True), (torch.float64, 64, True),

@@ -153,7 +153,7 @@ def test_k1_scores_at_scale(dev, k, d):
     assert big.size >= 20                                               # multi-chunk rows exist at this size
     X = synth.gaussian_X(V, d, seed=2)
     eng = SweepEngine(csr, X, dev, cosine_mode="per_edge")
-    assert eng.long_threshold == (32 if d == 256 else 128) and eng.long_rows[0] is not None
+    assert eng.score_threshold == (32 if d == 256 else 128) and eng.long_rows[0] is not None
     eng.build_P()
     P_gpu = eng.P_global()
     P_ref = O.build_P_values(csr.rowptr, csr.colidx, X, mode="per_edge")
@@ -163,7 +163,7 @@ def test_k1_scores_at_scale(dev, k, d):
     # raw dots with the engine's own structure (its vertex order, its long-row list)
     raw = torch.full((eng.E_loc,), float("nan"), dtype=torch.float32, device=dev)
     k.edge_score(eng.rowptr, eng.colidx, eng.part.n_local, 0, eng.Zcur, eng.d, _hip.SCORE_RAW_DOT, None, None, raw,
-                 eng.long_threshold, eng.long_rows[0])
+                 eng.score_threshold, eng.long_rows[0])
     dots = torch.empty(E)
     dots[torch.from_numpy(eng.local.edge_origin)] = raw.cpu()
     dots_ref = O.edge_dots(csr.rowptr, csr.colidx, X)

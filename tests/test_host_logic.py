@@ -356,8 +356,10 @@ def test_every_division_on_random_graphs():
 
         def run(rank):
             try:
+                # every other case of the non-halo divisions: rows above 3 edges take the XCD-affine class pass
+                ct = 3 if (case % 2 and not mode.startswith("halo")) else None
                 eng = SweepEngine(csr, X, "cpu", OracleKernels(), comm=shared.comm(rank), chunks=chunks, exchange=mode,
-                                  seed=case)
+                                  seed=case, class_threshold=ct, class_chunk=64)
                 eng.build_P()
                 P_mine = torch.zeros(csr.num_edges)
                 P_mine[torch.from_numpy(eng.local.edge_origin)] = eng.P[:eng.E_loc]
@@ -635,3 +637,51 @@ def test_per_sweep_log_lines_are_the_references(tmp_path):
     assert got[:6] == want[:6]                       # deltas well above fp32 noise: identical text
     assert all(re.fullmatch(r"tensor\([0-9.e+-]+\) \d+", ln) for ln in got)
     assert got[-1].endswith(" 0") and abs(len(got) - len(want)) <= 3
+
+
+@pytest.mark.parametrize("chunks,hot", [(1, True), (3, True), (1, False)])
+def test_class_affine_rows_layout_and_result(chunks, hot):
+    """Rows above `class_threshold` edges: edges sorted by (column % 8, column), cut into chunks of one class, chunk
+    blocks of class b at block index 8 j + b (the test double asserts that contract), slots contiguous per row --
+    and the sweep equals the oracle's whatever the thresholds."""
+    from clane_amd.engine import class_items
+    rng = np.random.default_rng(5)
+    V, d = 700, 12
+    deg = rng.integers(0, 9, size=V)
+    deg[rng.random(V) < 0.2] = 0
+    for i, h in enumerate((700, 300, 129, 65, 64, 9)):
+        deg[11 * i + 5] = h
+    cols = [np.sort(rng.choice(V, size=k, replace=False)) for k in deg]
+    rowptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    csr = HostCSR(V, rowptr, np.concatenate(cols).astype(np.int32))
+    X = torch.from_numpy(rng.standard_normal((V, d)).astype(np.float32))
+    P_or = O.build_P_values(csr.rowptr, csr.colidx, X)
+    Z_or, deltas_or = X.clone(), []
+    for _ in range(3):
+        Z_or, dl = O.sweep(csr.rowptr, csr.colidx, P_or, X, Z_or, 0.7)
+        deltas_or.append(float(dl))
+    for ct, chunk, lt in ((8, 64, None), (64, 128, 4), (128, 64, 0)):
+        eng = SweepEngine(csr, X, "cpu", OracleKernels(), chunks=chunks, hot_rows_first=hot, class_threshold=ct,
+                          class_chunk=chunk, long_threshold=lt)
+        n_class = sum(0 if c is None else c[0].numel() for c in eng.class_rows)
+        assert n_class == int((deg > ct).sum()) and 0 < eng.long_threshold <= ct
+        assert eng.kernel_names()["split"].startswith("spmm_class") and eng.kernel_config()["class_threshold"] == ct
+        # layout: the class rows' edges are sorted by (class, column); everybody else's by column
+        lr, lc = eng.local.rowptr, eng.local.colidx.astype(np.int64)
+        for r in range(eng.part.n_local):
+            c = lc[lr[r]:lr[r + 1]]
+            key = (c % 8) * 10**9 + c if c.size > ct else c
+            assert (np.diff(key) > 0).all()
+        eng.build_P()
+        assert O.rel_l2(eng.P_global(), P_or) < 1e-6
+        deltas = [eng.sweep(0.7) for _ in range(3)]
+        assert O.rel_l2(eng.get_Z(), Z_or) < 2e-6 and deltas == pytest.approx(deltas_or, rel=1e-5)
+        kb = eng.kernel_bytes()
+        assert kb["split"] > 0 and sum(kb.values()) == sum(SweepEngine(csr, X, "cpu", OracleKernels(), chunks=chunks,
+                                                                       class_threshold=0).kernel_bytes().values())
+    with pytest.raises(ValueError, match="class_chunk"):
+        SweepEngine(csr, X, "cpu", OracleKernels(), class_threshold=8, class_chunk=100)
+    # the item builder refuses rows that are not in class order
+    with pytest.raises(AssertionError, match="sorted by"):
+        class_items(csr.rowptr, csr.colidx, np.array([5]), 64, 8)

@@ -16,6 +16,9 @@ ap.add_argument("--world", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--long-threshold", type=int, default=None)
 ap.add_argument("--chunks", type=int, default=1)
+ap.add_argument("--class-threshold", type=int, nargs="+", default=[None],
+                help="rows above this many edges take the XCD-affine pass (0 = off; default: the engine's choice)")
+ap.add_argument("--class-chunk", type=int, nargs="+", default=[256])
 ap.add_argument("--calibrate", action="store_true",
                 help="also launch l1_distance over two [V, d/N] matrices (known bytes) -- PMC calibration")
 args = ap.parse_args()
@@ -23,9 +26,12 @@ dev = _hip.require_gpu("cuda:0")
 gen, V, E, d, dname, gseed, xseed = bench.WORKLOADS[args.workload]
 csr = synth.rmat_csr(V, E, seed=gseed) if gen == "rmat" else synth.powerlaw_csr(V, E, seed=gseed)
 X = synth.gaussian_X(V, d, seed=xseed).to(bench.DTYPES[dname])
-for W in args.world:
+for W, ct, cc in [(W, ct, cc) for W in args.world for ct in args.class_threshold for cc in args.class_chunk]:
+    if ct == 0 and cc != args.class_chunk[0]:
+        continue
     dl = d // W
-    eng = SweepEngine(csr, X[:, :dl].contiguous(), dev, chunks=args.chunks, long_threshold=args.long_threshold)
+    eng = SweepEngine(csr, X[:, :dl].contiguous(), dev, chunks=args.chunks, long_threshold=args.long_threshold,
+                      class_threshold=ct, class_chunk=cc)
     eng.build_P()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -53,6 +59,7 @@ for W in args.world:
     kb = eng.kernel_bytes()
     nbytes = sum(kb.values())
     print(json.dumps({"world": W, "d_local": dl, "ms_per_sweep": round(ms, 3), "long_threshold": eng.long_threshold,
+                      "class_threshold": eng.class_threshold, "class_chunk": eng.class_chunk,
                       "build_P_ms": round(build_ms, 3),
                       "algorithmic_GB": round(nbytes / 1e9, 2), "TBps": round(nbytes / ms / 1e9, 2),
                       "kernels_ms": {k: round(v, 3) for k, v in kt.items()},

@@ -76,10 +76,14 @@ def main():
         summary[k] = {"fetch_bytes": fb, "write_bytes": wb, "avg_us_under_pmc": us}
     (out / f"{args.tag}_pmc_traffic_{args.workload}.md").write_text("\n".join(lines) + "\n")
     def bench_name(k):       # names used by bench.py's roofline.kernels
-        if "spmm_update_kernel" in k or "spmm_update_subrow_kernel" in k:
+        if "spmm_update_subrow_kernel" in k:
+            return "spmm_update_subrow_kernel"
+        if "spmm_update_kernel" in k:
             return "spmm_update_kernel"
         if "spmm_split_segment_kernel" in k:
             return "spmm_split_segment_kernel+combine"
+        if "spmm_class_chunk_kernel" in k:
+            return "spmm_class_chunk_kernel+combine"
         if "spmm_long_kernel" in k:
             return f"spmm_long_kernel<{k.rstrip('>').split(',')[-1].strip()} waves>"
         return None
@@ -93,6 +97,11 @@ def main():
     for k, v in summary.items():
         if bench_name(k):
             entry[bench_name(k)] = {"bytes_per_launch": v["fetch_bytes"] + v["write_bytes"], "rocprof_name": k}
+    for k, v in summary.items():        # the combine launch belongs to the same bench entry as its chunk / segment pass
+        for part, whole in (("spmm_class_combine_kernel", "spmm_class_chunk_kernel+combine"),
+                            ("spmm_split_combine_kernel", "spmm_split_segment_kernel+combine")):
+            if part in k and whole in entry:
+                entry[whole]["bytes_per_launch"] += v["fetch_bytes"] + v["write_bytes"]
     data[args.workload] = entry
     tfile.write_text(json.dumps(data, indent=1) + "\n")
     if args.stats:
