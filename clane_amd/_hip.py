@@ -391,7 +391,7 @@ class HipKernels:
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block: int, class_rows, slot_ptr,
                           row0: int, Z_old, X, gamma: float, Z_new, d: int, slab, partials,
                           mirror: Optional[Mirror] = None):
-        """XCD-affine pass over the listed long rows (edges sorted by (column % 8, column), cut into items; item
+        """XCD-affine pass over the listed long rows (edges sorted by (XCD class of the column, column), cut into items; item
         blocks of class b at block index 8 j + b) + fixed-order combine; writes class_rows.numel() partials."""
         zo, ldz = _mat(Z_old, "Z_old")
         xp, ldx = _mat(X, "X")

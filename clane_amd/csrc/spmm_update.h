@@ -592,12 +592,13 @@ namespace clane {
 // ---- class-affine rows: every gathered row is read through ONE XCD's L2 --------------------------------------
 // The 256 CUs sit in 8 XCDs with a private 4 MiB L2 each, and workgroups are dealt to the XCDs round-robin
 // (workgroup w runs on XCD w % 8).  When any workgroup may gather any row, all eight L2s end up caching the SAME
-// few thousand hottest rows.  Here the edges of a long row are sorted by (column % 8, column) and cut into CHUNKS of
-// at most a few hundred edges of one class; the chunks of class b are dealt to the workgroups w = 8 j + b, so
-// XCD b only ever gathers rows r with r % 8 == b and the eight L2s cache eight DIFFERENT eighths of the hot rows
-// (Z is laid out hottest rows first, so every class gets its share of the heat).  Measured on config 3
-// (profiles/r02_xcd_class_experiment.md): pure 1-KiB-row gathers 8.9 -> 14.3 TB/s, the rows above 128 edges
-// 3.4 -> 2.4 ms.
+// few thousand hottest rows.  Here every table row has a class 0..7 (host side, partition.xcd_class:
+// (row / 8) % 8), the edges of a long row are sorted by (class of the column, column) and cut into CHUNKS of at most
+// a few hundred edges of one class, and the chunks of class b are dealt to the workgroups w = 8 j + b: XCD b only
+// ever gathers rows of class b, so the eight L2s cache eight DIFFERENT eighths of the hot rows (Z is laid out
+// hottest rows first: every class gets its share of the heat).  Measured (profiles/r02_gather_rows_ceiling.md,
+// r02_class_threshold_sweep.md): pure 1-KiB-row gathers 9.1 -> 11.5..14.3 TB/s, 256-byte rows 11.3 -> 19.5 TB/s;
+// config 3's sweep 5.36 -> 4.38 ms.
 // A chunk is done by one wave -- its partial sum goes to slab[slot] -- and spmm_class_combine_kernel then adds a
 // row's slots IN ORDER (reproducible: no atomics) and runs the usual epilogue.  A workgroup owns
 // `items_per_block` consecutive chunks of its class (padding chunks have length 0); their descriptors are staged

@@ -32,7 +32,7 @@ import torch
 from . import _hip
 from .comm import TorchComm
 from .halo import build_halo_layout
-from .partition import XCD_CLASSES, Block, HostCSR, LocalCSR, RowPartition, localize
+from .partition import XCD_CLASSES, Block, HostCSR, LocalCSR, RowPartition, localize, xcd_class
 
 # Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md):
 #   deg <= T   one (sub-)wave per row, rows claimed dynamically inside a workgroup
@@ -55,7 +55,7 @@ SPLIT_EDGES = 4096
 MIN_SEGMENT_EDGES = 1024
 TARGET_SEGMENTS = 512                   # two workgroups per CU
 # Rows above CLASS_THRESHOLD edges are gathered XCD-affine (csrc/spmm_update.h, spmm_class_chunk_kernel): their edges
-# are sorted by (column % 8, column), cut into chunks of at most CLASS_CHUNK edges of one class, and the chunks of
+# are sorted by (class of the column, column) -- partition.xcd_class --, cut into chunks of at most CLASS_CHUNK edges of one class, and the chunks of
 # class b run on the workgroups 8 j + b = XCD b, so each XCD's 4 MiB L2 caches its own eighth of the hot rows instead
 # of all eight caching the same ones.  Costs one partial sum (d accumulators, written + read once) per chunk, which
 # is why short rows stay with the row kernels.  Threshold by rows per wave-instruction, 0 = off; measured
@@ -64,7 +64,7 @@ TARGET_SEGMENTS = 512                   # two workgroups per CU
 # at 256; config 4's shape (bf16, 256-B rows) 8.24 -> 7.79 at 256; config 2 (Z fits the Infinity Cache) unchanged.
 CLASS_THRESHOLD_BY_ROWS_PER_WAVE = {1: 64, 2: 64, 4: 256, 8: 256}
 CLASS_CHUNK = 256
-CLASS_ITEMS_PER_BLOCK = 32
+CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
 
 
 def lanes_per_row(d: int, dtype: torch.dtype) -> int:
@@ -101,7 +101,7 @@ def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
 
 def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int) -> dict:
     """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
-    (column % 8, column)): every class segment of a row is cut into chunks of at most `chunk` edges.
+    (xcd_class(column), column)): every class segment of a row is cut into chunks of at most `chunk` edges.
     Slots -- where the partial sums go -- are numbered row by row, class by class, chunk by chunk, so a row's slots
     are contiguous (`slot_ptr`) and summed in that order.  Items are laid out for the kernel: blocks of
     `items_per_block` items of ONE class, block j of class b at block index 8 j + b, padded with empty items
@@ -110,10 +110,10 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     sizes = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
     start = np.concatenate([[0], np.cumsum(sizes)[:-1]])
     idx = np.repeat(rowptr[rows] - start, sizes) + np.arange(int(sizes.sum()), dtype=np.int64)
-    cls = colidx[idx].astype(np.int64) % XCD_CLASSES
+    cls = xcd_class(colidx[idx].astype(np.int64))
     rid = np.repeat(np.arange(n, dtype=np.int64), sizes)
     if idx.size > 1 and (np.diff(rid * XCD_CLASSES + cls) < 0).any():
-        raise AssertionError("class rows must have their edges sorted by (column % 8, column)")
+        raise AssertionError("class rows must have their edges sorted by (xcd_class(column), column)")
     seg_len = np.bincount(rid * XCD_CLASSES + cls, minlength=n * XCD_CLASSES)
     seg_e0 = np.repeat(rowptr[rows], XCD_CLASSES) + (np.cumsum(seg_len) - seg_len
                                                       - np.repeat(start, XCD_CLASSES))

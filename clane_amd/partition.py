@@ -176,14 +176,22 @@ class LocalCSR:
     edge_origin: np.ndarray     # int64 [E_local]  index of each local edge in the global CSR order
 
 
-XCD_CLASSES = 8          # MI355X: 8 XCDs, one private L2 each; the class of a table row is its position % 8
+XCD_CLASSES = 8          # MI355X: 8 XCDs, one private L2 each
+
+
+def xcd_class(position):
+    """XCD class (0..7) of the table row at `position` (numpy array, torch tensor or int): blocks of 8 consecutive
+    rows, dealt round-robin.  NOT position % 8: that pins three low address bits of every row an XCD gathers, and
+    only part of its L2's channels / sets get used -- measured on the pure gather (profiles/r02_gather_rows_ceiling.md):
+    128-byte rows 13.4 TB/s with % 8, 19.3 TB/s with this; 256-byte rows 17.1 -> 19.5; 1-KiB rows the same."""
+    return (position >> 3) & (XCD_CLASSES - 1)
 
 
 def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int = 0) -> LocalCSR:
     """Slice + relabel the global CSR for one rank.  The one heavy step -- re-sorting every row's edges by their
     new column -- is a single sort of unique (row, column) keys; with ``device`` = a GPU it runs there (40M edges:
     seconds on the host, milliseconds on the card).
-    ``class_threshold`` > 0: rows with more edges than that are sorted by (column % 8, column) instead, so that the
+    ``class_threshold`` > 0: rows with more edges than that are sorted by (xcd_class(column), column) instead, so that the
     edges to one XCD class are contiguous (engine: class-affine rows, csrc/spmm_update.h)."""
     V = csr.num_vertices
     if V != part.num_vertices:
@@ -214,7 +222,7 @@ def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int
     key = row_of * part.padded_vertices + cols                           # keys are unique: any sort is THE order
     if by_class.any():
         key = row_of * (XCD_CLASSES * part.padded_vertices) + cols + torch.where(
-            t(by_class)[row_of], (cols % XCD_CLASSES) * part.padded_vertices, torch.zeros_like(cols))
+            t(by_class)[row_of], xcd_class(cols) * part.padded_vertices, torch.zeros_like(cols))
     order = torch.argsort(key)
     cols, origin = cols[order], origin[order]
     return LocalCSR(rowptr, cols.to(torch.int32).cpu().numpy(), indeg, verts, origin.cpu().numpy())

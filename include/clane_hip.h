@@ -226,11 +226,13 @@ int clane_spmm_update_split_bf16(const int64_t *rowptr, const int32_t *colidx, c
 /*  clane_spmm_update_class_* : long rows whose gathers are kept XCD-affine (no reference counterpart: the reference's
  *                             loop is embedder.py:84-92 for every row alike).  MI355X has 8 XCDs with a private 4 MiB
  *                             L2 each and deals workgroups to them round-robin (workgroup w -> XCD w % 8).  The caller
- *                             sorts the edges of each listed row by (column % 8, column) and cuts every class segment
+ *                             gives every table row a CLASS 0..7 (the engine: (row / 8) % 8 -- not row % 8, which would
+ *                             pin low address bits and use only part of an L2), sorts the edges of each listed row by
+ *                             (class of the column, column) and cuts every class segment
  *                             into ITEMS of a few hundred edges; item arrays are laid out in blocks of
  *                             `items_per_block` (4..64) items of ONE class, block j of class b at block index
  *                             8 j + b (n_blocks blocks, padding items have item_len = 0), so XCD b only gathers rows
- *                             r with r % 8 == b and the eight L2s cache different eighths of the hot rows.
+ *                             of class b and the eight L2s cache different eighths of the hot rows.
  *                             item_e0 / item_len: edge range of an item in colidx / P; item_slot: where its partial
  *                             sum goes in `slab` (clane_spmm_class_slab_len(n_slots, d) accumulate-type elements,
  *                             16-byte aligned).  class_rows[n_rows] local row ids; slot_ptr[n_rows+1]: the slots of

@@ -8,6 +8,7 @@ substitutes it: ``SweepEngine`` only gets it when a test passes it in explicitly
 import numpy as np
 import torch
 
+from clane_amd.partition import xcd_class
 from oracle import clane_oracle as O
 
 
@@ -126,7 +127,7 @@ class OracleKernels:
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
                           Z_old, X, gamma, Z_new, d, slab, partials, mirror=None):
         """The XCD-affine pass: partial sums per item into the slab, a row's slots added in order.  Also checks the
-        layout contract the kernel relies on: whole blocks, every item of block w gathers only rows of class w % 8."""
+        layout contract the kernel relies on: whole blocks, every item of block w gathers only rows of XCD class w % 8."""
         e0, ln, sl = _np(item_e0), _np(item_len), _np(item_slot)
         assert 4 <= items_per_block <= 64 and e0.size % items_per_block == 0 and e0.size // items_per_block % 8 == 0
         acc = P.dtype
@@ -139,7 +140,7 @@ class OracleKernels:
                 continue
             a, b = int(e0[k]), int(e0[k]) + int(ln[k])
             cols = colidx[a:b].long()
-            assert bool((cols % 8 == (k // items_per_block) % 8).all()), "item gathers a row of another XCD class"
+            assert bool((xcd_class(cols) == (k // items_per_block) % 8).all()), "item gathers a row of another XCD class"
             view[sl[k], :d] = (P[a:b].unsqueeze(1) * Z_old[cols, :d].to(acc)).sum(0)
         mp = None if mirror is None else mirror
         for i, r in enumerate(class_rows.tolist()):

@@ -694,11 +694,12 @@ def test_spmm_split_hub_rows(dev, k, dtype, d):
                                          (torch.float32, 1433, True)])
 @pytest.mark.parametrize("chunk", [64, 256])
 def test_spmm_class_affine_rows(dev, k, dtype, d, pad, chunk):
-    """clane_spmm_update_class_*: rows whose edges are sorted by (column % 8, column) and cut into chunks of one
+    """clane_spmm_update_class_*: rows whose edges are sorted by (XCD class of the column, column) and cut into chunks of one
     class, chunk blocks of class b at block index 8 j + b, partial sums added per row in slot order == the oracle,
     == the one-workgroup-per-row kernel up to summation order; only the listed rows are written; two launches are
     bitwise equal; the mirror gets the finished rows."""
     from clane_amd.engine import class_items
+    from clane_amd.partition import xcd_class
     csr0 = ragged_csr(900, seed=3, hubs=(700, 129, 64, 900, 385, 65))
     V, acc, gamma = csr0.num_vertices, _hip.acc_dtype(dtype), 0.76
     deg = np.diff(csr0.rowptr)
@@ -707,7 +708,7 @@ def test_spmm_class_affine_rows(dev, k, dtype, d, pad, chunk):
     for r in rows:                                                  # class order inside the listed rows
         a, b = csr0.rowptr[r], csr0.rowptr[r + 1]
         c = colidx[a:b]
-        colidx[a:b] = c[np.lexsort((c, c % 8))]
+        colidx[a:b] = c[np.lexsort((c, xcd_class(c)))]
     X = synth.gaussian_X(V, d, seed=1).to(dtype)
     Zold = (synth.gaussian_X(V, d, seed=2) * 0.5).to(dtype)
     P = torch.rand(csr0.num_edges, generator=torch.Generator().manual_seed(3)).to(acc) / 50

@@ -13,7 +13,7 @@ from clane_amd import _hip
 from clane_amd.embedder import Embedder, IterativeEmbedder
 from clane_amd.engine import SweepEngine
 from clane_amd.graph import Graph
-from clane_amd.partition import HostCSR, RowPartition, localize
+from clane_amd.partition import HostCSR, RowPartition, localize, xcd_class
 from clane_amd.similarity import AsymmertricSimilarity, CosineSimilarity, Similarity
 from oracle import clane_oracle as O
 
@@ -641,7 +641,7 @@ def test_per_sweep_log_lines_are_the_references(tmp_path):
 
 @pytest.mark.parametrize("chunks,hot", [(1, True), (3, True), (1, False)])
 def test_class_affine_rows_layout_and_result(chunks, hot):
-    """Rows above `class_threshold` edges: edges sorted by (column % 8, column), cut into chunks of one class, chunk
+    """Rows above `class_threshold` edges: edges sorted by (XCD class of the column, column), cut into chunks of one class, chunk
     blocks of class b at block index 8 j + b (the test double asserts that contract), slots contiguous per row --
     and the sweep equals the oracle's whatever the thresholds."""
     from clane_amd.engine import class_items
@@ -671,7 +671,7 @@ def test_class_affine_rows_layout_and_result(chunks, hot):
         lr, lc = eng.local.rowptr, eng.local.colidx.astype(np.int64)
         for r in range(eng.part.n_local):
             c = lc[lr[r]:lr[r + 1]]
-            key = (c % 8) * 10**9 + c if c.size > ct else c
+            key = xcd_class(c) * 10**9 + c if c.size > ct else c
             assert (np.diff(key) > 0).all()
         eng.build_P()
         assert O.rel_l2(eng.P_global(), P_or) < 1e-6

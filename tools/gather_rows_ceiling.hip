@@ -26,9 +26,12 @@
 // LPR lanes cover one row with 16 B each; a wave reads 64/LPR rows per instruction, U instructions in flight.
 // Work is cut into groups of 64 indices; group g belongs to "bucket" g % nb, and workgroup w only takes groups of
 // bucket w % nb (nb = 1: no affinity; nb = 8 with bucketed index lists: XCD-affine).
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+// nt_from >= 0: a group whose FIRST index is >= nt_from is read with non-temporal loads (cold rows should not push
+// the hot ones out of L2); groups are pure (all hot or all cold) in the lists used with it.
 template <int LPR, int U>
 __global__ __launch_bounds__(256) void gather(const float4 *__restrict__ Z, const int *__restrict__ idx,
-                                              long n_groups, int nb, float4 *__restrict__ out) {
+                                              long n_groups, int nb, float4 *__restrict__ out, int nt_from = -1) {
     constexpr int EPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane / LPR, sl = lane % LPR;
     const long wave_in_bucket = (long)(blockIdx.x / nb) * 4 + (threadIdx.x >> 6);
@@ -38,12 +41,22 @@ __global__ __launch_bounds__(256) void gather(const float4 *__restrict__ Z, cons
     for (long k = wave_in_bucket; k * nb + bucket < n_groups; k += waves_per_bucket) {
         const long g = k * nb + bucket;
         const int my = idx[g * 64 + lane];
+        const bool cold = nt_from >= 0 && __builtin_amdgcn_readfirstlane(my) >= nt_from;
         for (int j = 0; j < 64; j += EPW * U) {
             float4 z[U];
+            if (cold) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = __shfl(my, j + u * EPW + sub, 64);
-                z[u] = Z[(long)c * LPR + sl];
+                for (int u = 0; u < U; ++u) {
+                    const int c = __shfl(my, j + u * EPW + sub, 64);
+                    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(Z + (long)c * LPR + sl));
+                    z[u] = float4{v.x, v.y, v.z, v.w};
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = __shfl(my, j + u * EPW + sub, 64);
+                    z[u] = Z[(long)c * LPR + sl];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -58,14 +71,14 @@ __global__ __launch_bounds__(256) void gather(const float4 *__restrict__ Z, cons
 }
 
 template <int LPR>
-float run(const float4 *Z, const int *idx, long n_groups, int nb, float4 *out, int grid) {
+float run(const float4 *Z, const int *idx, long n_groups, int nb, float4 *out, int grid, int nt_from = -1) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
     float best = 1e9;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
-        gather<LPR, 8><<<grid, 256>>>(Z, idx, n_groups, nb, out);
+        gather<LPR, 8><<<grid, 256>>>(Z, idx, n_groups, nb, out, nt_from);
         CK(hipEventRecord(b));
         CK(hipEventSynchronize(b));
         float ms;
@@ -75,7 +88,23 @@ float run(const float4 *Z, const int *idx, long n_groups, int nb, float4 *out, i
     return best;
 }
 
+static int g_class_mode = 0;
+static inline int cls_of(int r) {
+    if (g_class_mode == 0) return r & 7;                                   // row % 8
+    if (g_class_mode == 1) return (r ^ (r >> 3) ^ (r >> 6) ^ (r >> 9)) & 7;  // xor-folded: every class holds every value of the low bits
+    return (r >> 3) & 7;                                                   // blocks of 8 consecutive rows
+}
+
+int run_all();
 int main() {
+    for (g_class_mode = 0; g_class_mode < 3; ++g_class_mode) {
+        printf("== class of a row: %s\n", g_class_mode == 0 ? "r % 8" : g_class_mode == 1 ? "xor-fold(r) % 8" : "(r / 8) % 8");
+        run_all();
+    }
+    return 0;
+}
+
+int run_all() {
     const long V = 2000000;
     const long n_idx = 40000000 / 512 * 512;
     std::vector<int> h(n_idx);
@@ -95,7 +124,7 @@ int main() {
     // bucketed copy: group g (64 indices) holds only rows with row % 8 == g % 8 (equal-sized buckets by construction
     // of the tail: leftovers are dropped from both lists so that both variants read the same multiset)
     std::vector<std::vector<int>> by(8);
-    for (long i = 0; i < n_idx; ++i) by[h[i] & 7].push_back(h[i]);
+    for (long i = 0; i < n_idx; ++i) by[cls_of(h[i])].push_back(h[i]);
     size_t per = by[0].size();
     for (auto &b : by) per = std::min(per, b.size());
     per = per / 64 * 64;
@@ -123,10 +152,57 @@ int main() {
         }
         printf("%.3f %.3f %.3f\n", double(c4) / n, double(c32) / n, double(c250) / n);
     }
+    // XCD-affine with PURE groups: per class, the hot indices (row < H) first, then the cold ones, each kind padded to
+    // whole groups by repeating its last index (a few extra reads, counted); groups of the classes interleaved as above.
+    const int H = 32768;
+    std::vector<int> pure;
+    {
+        std::vector<std::vector<int>> hot(8), cold(8);
+        for (int b = 0; b < 8; ++b)
+            for (size_t i = 0; i < per; ++i) (by[b][i] < H ? hot[b] : cold[b]).push_back(by[b][i]);
+        size_t gh = 0, gc = 0;
+        for (int b = 0; b < 8; ++b) {
+            gh = std::max(gh, (hot[b].size() + 63) / 64);
+            gc = std::max(gc, (cold[b].size() + 63) / 64);
+        }
+        for (int b = 0; b < 8; ++b) {
+            hot[b].resize(gh * 64, hot[b].back());
+            cold[b].resize(gc * 64, cold[b].back());
+            std::shuffle(cold[b].begin(), cold[b].end(), rng);
+            std::shuffle(hot[b].begin(), hot[b].end(), rng);
+        }
+        // interleave hot and cold groups in time (as the rows of a sweep would), class-affine in space
+        pure.resize((gh + gc) * 8 * 64);
+        size_t ih = 0, ic = 0, g = 0;
+        while (ih < gh || ic < gc) {
+            const bool take_hot = ic >= gc || (ih < gh && ih * gc <= ic * gh);
+            for (int b = 0; b < 8; ++b) {
+                const std::vector<int> &src = take_hot ? hot[b] : cold[b];
+                const size_t k = take_hot ? ih : ic;
+                std::copy(src.begin() + k * 64, src.begin() + (k + 1) * 64, pure.begin() + (g * 8 + b) * 64);
+            }
+            take_hot ? ++ih : ++ic;
+            ++g;
+        }
+    }
+    int *idx_pure;
+    CK(hipMalloc(&idx_pure, pure.size() * sizeof(int)));
+    CK(hipMemcpy(idx_pure, pure.data(), pure.size() * sizeof(int), hipMemcpyHostToDevice));
+    for (int nt : {-1}) {
+        const long np = (long)pure.size(), ng = np / 64;
+        const int grid = 8192;
+        const float t128 = run<8>(Z, idx_pure, ng, 8, out, grid, nt), t256 = run<16>(Z, idx_pure, ng, 8, out, grid, nt);
+        const float t512 = run<32>(Z, idx_pure, ng, 8, out, grid, nt), t1k = run<64>(Z, idx_pure, ng, 8, out, grid, nt);
+        printf("%-12s grid %5d | 128 B rows %6.3f ms %7.1f GB/s | 256 B %6.3f ms %7.1f | 512 B %6.3f ms %7.1f | "
+               "1 KiB %6.3f ms %7.1f   (pure hot / cold groups, %ld reads)\n",
+               nt < 0 ? "affine,pure" : "affine,pure,NT cold", grid, t128, np * 128.0 / t128 / 1e6, t256,
+               np * 256.0 / t256 / 1e6, t512, np * 512.0 / t512 / 1e6, t1k, np * 1024.0 / t1k / 1e6, np);
+        fflush(stdout);
+    }
     for (int variant = 0; variant < 2; ++variant) {
         CK(hipMemcpy(idx, variant ? bucketed.data() : plain.data(), n * sizeof(int), hipMemcpyHostToDevice));
         const int nb = variant ? 8 : 1;
-        for (int grid : {2048, 8192}) {
+        for (int grid : {8192}) {
             const float t128 = run<8>(Z, idx, n_groups, nb, out, grid);
             const float t256 = run<16>(Z, idx, n_groups, nb, out, grid);
             const float t512 = run<32>(Z, idx, n_groups, nb, out, grid);
@@ -138,5 +214,9 @@ int main() {
             fflush(stdout);
         }
     }
+    CK(hipFree(Z));
+    CK(hipFree(idx));
+    CK(hipFree(out));
+    CK(hipFree(idx_pure));
     return 0;
 }

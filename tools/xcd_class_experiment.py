@@ -26,6 +26,7 @@ ap.add_argument("--workload", default="rmat2m")
 ap.add_argument("--min-degree", type=int, nargs="+", default=[32, 128])
 ap.add_argument("--chunk", type=int, nargs="+", default=[64, 128, 256])
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--block-class", action="store_true", help="class = (row / 8) % 8 instead of row % 8")
 ap.add_argument("--cols", type=int, default=None, help="use only the first COLS columns (a column slice)")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
@@ -35,7 +36,7 @@ if args.cols:
     d = args.cols
 csr = synth.rmat_csr(V, E, seed=gseed) if gen == "rmat" else synth.powerlaw_csr(V, E, seed=gseed)
 X = synth.gaussian_X(V, d, seed=xseed).to(bench.DTYPES[dname])
-eng = SweepEngine(csr, X, dev)                 # hot-rows-first layout, position-relabelled CSR
+eng = SweepEngine(csr, X, dev, class_threshold=0)   # hot-rows-first layout, position-relabelled CSR, columns sorted
 rowptr, colidx = eng.local.rowptr, eng.local.colidx.astype(np.int64)
 deg = np.diff(rowptr)
 P = torch.rand(colidx.size, device=dev) / 20
@@ -83,7 +84,7 @@ for dmin in args.min_degree:
     idx = np.repeat(a - start, sizes) + np.arange(n_edges)
     cols = colidx[idx]
     rid = np.repeat(np.arange(n, dtype=np.int64), sizes)
-    cls = cols % 8
+    cls = (cols >> 3) & 7 if args.block_class else cols % 8
     order = np.lexsort((cols, cls, rid))
     cols, idx, rid, cls = cols[order], idx[order], rid[order], cls[order]
     Pv = P[torch.from_numpy(idx).to(dev)]
