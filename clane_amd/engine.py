@@ -792,6 +792,7 @@ class SweepEngine:
                 "hub_threshold": self.hub_threshold,
                 "split_edges": self.split_edges, "segment_edges": self.segment_edges,
                 "class_threshold": self.class_threshold, "class_chunk": self.class_chunk,
+                "class_of_row": "(row / 8) % 8" if self.class_threshold else None,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 
     def exchange_bytes_per_sweep(self) -> int:
