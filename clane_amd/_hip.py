@@ -60,6 +60,8 @@ for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_spmm_update_class_{_s}"] = (
         C.c_int,
         [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
+    SIGNATURES[f"clane_edge_score_class_{_s}"] = (
+        C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p])
     SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
     SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
 for _s in ("f32", "f64"):
@@ -320,6 +322,27 @@ class HipKernels:
             SCORE_FUSE_SOFTMAX if fuse_softmax else 0, long_threshold,
             None if n_long == 0 else _vec(long_rows, torch.int32, "long_rows"), n_long,
             self._stream(Z)), "clane_edge_score")
+
+    def edge_score_class(self, rowptr, colidx, item_e0, item_len, item_slot, item_row, items_per_block: int, class_rows,
+                         slot_ptr, row0: int, Z, d: int, mode: int, sums2, sq, scores, stats=None,
+                         fuse_softmax: bool = False):
+        """K1 over the class rows' work items (XCD-affine gathers); with `fuse_softmax` every listed row leaves
+        soft-maxed (stats: 2 accumulate-type elements per slot)."""
+        zp, ldz = _mat(Z, "Z")
+        n_items = item_e0.numel()
+        if n_items % items_per_block or any(t.numel() != n_items for t in (item_len, item_slot, item_row)):
+            raise ValueError("edge_score_class: the item arrays must hold whole blocks of items_per_block items")
+        if fuse_softmax and (stats is None or stats.numel() < 2 * int(slot_ptr[-1])):
+            raise ValueError("edge_score_class: stats needs 2 elements per slot")
+        acc = acc_dtype(Z.dtype)
+        self._check(self._fn("clane_edge_score_class", Z.dtype)(
+            _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
+            _vec(item_e0, torch.int64, "item_e0"), _vec(item_len, torch.int32, "item_len"),
+            _vec(item_slot, torch.int32, "item_slot"), _vec(item_row, torch.int32, "item_row"),
+            n_items // items_per_block, items_per_block, _vec(class_rows, torch.int32, "class_rows"),
+            _vec(slot_ptr, torch.int64, "slot_ptr"), class_rows.numel(), row0, zp, ldz, d, mode, _ptr(sums2), _ptr(sq),
+            _vec(scores, acc, "scores"), SCORE_FUSE_SOFTMAX if fuse_softmax else 0,
+            None if stats is None else _vec(stats, acc, "stats"), self._stream(Z)), "clane_edge_score_class")
 
     def edge_score_finalize(self, rowptr, colidx, nrows: int, row0: int, mode: int, sums2, sq, scores):
         """RAW_DOT scores summed over the GPUs of a column-split run -> scores of `mode`, in place."""

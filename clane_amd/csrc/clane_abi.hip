@@ -195,6 +195,39 @@ int edge_score(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int6
     return check_launch("edge_score");
 }
 
+template <typename T>
+int edge_score_class(const int64_t *rowptr, const int32_t *colidx, const int64_t *item_e0, const int32_t *item_len,
+                     const int32_t *item_slot, const int32_t *item_row, int64_t n_blocks, int32_t items_per_block,
+                     const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const T *Z,
+                     int64_t ldz, int32_t d, int32_t mode, const double *sums2, const typename Elem<T>::acc_t *sq,
+                     typename Elem<T>::acc_t *scores, int32_t flags, typename Elem<T>::acc_t *stats, void *stream) {
+    REQUIRE(n_blocks >= 0 && n_blocks <= INT32_MAX && n_rows >= 0 && n_rows <= INT32_MAX && row0 >= 0 && d > 0 &&
+                ldz >= d,
+            "edge_score_class: bad shape");
+    REQUIRE(items_per_block >= kWavesPerBlock && items_per_block <= kMaxItemsPerBlock,
+            "edge_score_class: items_per_block must be in [%d, %d]", kWavesPerBlock, kMaxItemsPerBlock);
+    REQUIRE(mode == CLANE_SCORE_REFERENCE || mode == CLANE_SCORE_PER_EDGE || mode == CLANE_SCORE_RAW_DOT,
+            "edge_score_class: unknown mode %d", mode);
+    if (n_rows == 0 || n_blocks == 0) return CLANE_OK;
+    const bool fuse = (flags & CLANE_SCORE_FUSE_SOFTMAX) != 0;
+    REQUIRE(colidx && item_e0 && item_len && item_slot && item_row && Z && scores, "edge_score_class: null pointer");
+    REQUIRE(!fuse || (rowptr && class_rows && slot_ptr && stats),
+            "edge_score_class: CLANE_SCORE_FUSE_SOFTMAX needs rowptr, class_rows, slot_ptr and stats");
+    REQUIRE(mode != CLANE_SCORE_REFERENCE || sums2, "edge_score_class: mode REFERENCE needs sums2");
+    REQUIRE(mode != CLANE_SCORE_PER_EDGE || sq, "edge_score_class: mode PER_EDGE needs sq");
+    const Layout L = pick_layout<T>(d, {Z}, {ldz});
+    dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
+        constexpr int U = VEC > 1 ? 8 : 4;
+        edge_score_class_kernel<T, VEC, LPR, U><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
+            colidx, item_e0, item_len, item_slot, item_row, items_per_block, row0, Z, ldz, d, mode, sums2, sq, scores,
+            fuse ? stats : nullptr);
+    });
+    if (fuse)
+        edge_softmax_class_kernel<typename Elem<T>::acc_t><<<unsigned(n_rows), kBlock, 0, (hipStream_t)stream>>>(
+            rowptr, class_rows, slot_ptr, stats, scores);
+    return check_launch("edge_score_class");
+}
+
 template <typename A>
 int segment_softmax(const int64_t *rowptr, int64_t nrows, A *vals, int64_t min_degree, int64_t max_degree,
                     const int32_t *long_rows, int64_t n_long, void *stream) {
@@ -494,6 +527,21 @@ CLANE_EDGE_SCORE_WRAPPER(f32, float, float, float)
 CLANE_EDGE_SCORE_WRAPPER(f64, double, double, double)
 CLANE_EDGE_SCORE_WRAPPER(bf16, uint16_t, bf16_t, float)
 #undef CLANE_EDGE_SCORE_WRAPPER
+#define CLANE_EDGE_SCORE_CLASS_WRAPPER(SUF, CT, T, AT)                                                                \
+    int clane_edge_score_class_##SUF(const int64_t *rowptr, const int32_t *colidx, const int64_t *item_e0,            \
+                                     const int32_t *item_len, const int32_t *item_slot, const int32_t *item_row,      \
+                                     int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,            \
+                                     const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const CT *Z, int64_t ldz, \
+                                     int32_t d, int32_t mode, const double *sums2, const AT *sq, AT *scores,          \
+                                     int32_t flags, AT *stats, void *stream) {                                        \
+        return edge_score_class<T>(rowptr, colidx, item_e0, item_len, item_slot, item_row, n_blocks, items_per_block, \
+                                   class_rows, slot_ptr, n_rows, row0, reinterpret_cast<const T *>(Z), ldz, d, mode,  \
+                                   sums2, sq, scores, flags, stats, stream);                                          \
+    }
+CLANE_EDGE_SCORE_CLASS_WRAPPER(f32, float, float, float)
+CLANE_EDGE_SCORE_CLASS_WRAPPER(f64, double, double, double)
+CLANE_EDGE_SCORE_CLASS_WRAPPER(bf16, uint16_t, bf16_t, float)
+#undef CLANE_EDGE_SCORE_CLASS_WRAPPER
 
 int clane_edge_score_finalize_f32(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t row0,
                                   int32_t mode, const double *sums2, const float *sq, float *scores, void *stream) {

@@ -12,6 +12,7 @@ constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 resident 256-thread workgroups
+constexpr int kMaxItemsPerBlock = 64;  // class-affine passes: chunk descriptors a workgroup stages in LDS
 
 struct bf16_t {
     uint16_t bits;

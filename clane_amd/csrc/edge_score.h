@@ -317,4 +317,63 @@ __global__ __launch_bounds__(WAVES *kWave) void edge_score_long_kernel(
     for (int64_t e = a + lane_id(); e < b; e += kWave) scores[e] = exp_acc<A>(scores[e] - m) / total;
 }
 
+// ---- class-affine rows (see spmm_update.h: every gathered row is read through ONE XCD's L2) ------------------
+// K1 over the same work items as K3's class pass: a wave scores the edges of one item -- a chunk of one row's edges
+// whose columns all belong to one XCD class -- with the source row in registers, exactly like a slice of
+// edge_score_long_kernel, and leaves {max, sum of exp(score - max)} of the chunk in stats[2 * slot].  Item blocks of
+// class b sit at block index 8 j + b, so XCD b only gathers rows of class b.
+template <typename T, int VEC, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void edge_score_class_kernel(
+    const int32_t *__restrict__ colidx, const int64_t *__restrict__ item_e0, const int32_t *__restrict__ item_len,
+    const int32_t *__restrict__ item_slot, const int32_t *__restrict__ item_row, int items_per_block, int64_t row0,
+    const T *__restrict__ Z, int64_t ldz, int d, int mode, const double *__restrict__ sums2,
+    const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores,
+    typename Elem<T>::acc_t *__restrict__ stats) {
+    using A = typename Elem<T>::acc_t;
+    __shared__ int s_next;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int64_t base = int64_t(blockIdx.x) * items_per_block;
+    if (threadIdx.x == 0) s_next = kWavesPerBlock;
+    __syncthreads();
+    const A D = global_denominator<A>(mode, sums2);
+    int cur = wave;
+    while (cur < items_per_block) {
+        const int64_t e0 = item_e0[base + cur];
+        const int len = item_len[base + cur];
+        if (len > 0) {
+            A st[2];
+            score_edge_range<T, VEC, LPR, U>(colidx, e0, e0 + len, row0 + item_row[base + cur], Z, ldz, d, mode, D, sq,
+                                             scores, false, stats ? st : nullptr);
+            if (stats && lane_id() == 0) {
+                const int64_t slot = item_slot[base + cur];
+                stats[2 * slot] = st[0];
+                stats[2 * slot + 1] = st[1];
+            }
+        }
+        int v = 0;
+        if (lane_id() == 0) v = atomicAdd(&s_next, 1);
+        cur = __builtin_amdgcn_readfirstlane(v);
+    }
+}
+
+// One workgroup per class row: the chunks' {max, sum} combined in slot order (every thread walks the same list: the
+// result does not depend on the thread count), then the row's scores become  exp(score - max) / total
+// (graph.py:122-123).
+template <typename A>
+__global__ __launch_bounds__(kBlock) void edge_softmax_class_kernel(const int64_t *__restrict__ rowptr,
+                                                                    const int32_t *__restrict__ class_rows,
+                                                                    const int64_t *__restrict__ slot_ptr,
+                                                                    const A *__restrict__ stats,
+                                                                    A *__restrict__ scores) {
+    const int i = blockIdx.x;
+    const int64_t r = class_rows[i];
+    const int64_t s0 = slot_ptr[i], s1 = slot_ptr[i + 1];
+    A m = -A(INFINITY);
+    for (int64_t s = s0; s < s1; ++s) m = fmax(m, stats[2 * s]);
+    A total = A(0);
+    for (int64_t s = s0; s < s1; ++s) total += stats[2 * s + 1] * exp_acc<A>(stats[2 * s] - m);
+    const int64_t e1 = rowptr[r + 1];
+    for (int64_t e = rowptr[r] + threadIdx.x; e < e1; e += kBlock) scores[e] = exp_acc<A>(scores[e] - m) / total;
+}
+
 }  // namespace clane

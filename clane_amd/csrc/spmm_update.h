@@ -604,7 +604,6 @@ namespace clane {
 // `items_per_block` consecutive chunks of its class (padding chunks have length 0); their descriptors are staged
 // in LDS, waves claim them from an LDS counter and request the next chunk's colidx / P before gathering the
 // current one, exactly like spmm_update_kernel does with rows.
-constexpr int kMaxItemsPerBlock = 64;
 
 template <typename T, typename PT, int VEC, int LPR, int U>
 __global__ __launch_bounds__(kBlock) void spmm_class_chunk_kernel(

@@ -99,13 +99,15 @@ def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
     return min(d, p0 * vec), min(d, p1 * vec)
 
 
-def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int) -> dict:
+def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int,
+                row_ids: Optional[np.ndarray] = None) -> dict:
     """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
     (xcd_class(column), column)): every class segment of a row is cut into chunks of at most `chunk` edges.
     Slots -- where the partial sums go -- are numbered row by row, class by class, chunk by chunk, so a row's slots
     are contiguous (`slot_ptr`) and summed in that order.  Items are laid out for the kernel: blocks of
     `items_per_block` items of ONE class, block j of class b at block index 8 j + b, padded with empty items
-    (len 0, slot -1).  Returns int64 e0, int32 len, int32 slot (flat, whole blocks) and int64 slot_ptr [rows + 1]."""
+    (len 0, slot -1).  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
+    item's row, default `rows` itself) and int64 slot_ptr [rows + 1]."""
     n = rows.size
     sizes = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
     start = np.concatenate([[0], np.cumsum(sizes)[:-1]])
@@ -132,11 +134,14 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     out_e0 = np.zeros(flat, dtype=np.int64)
     out_len = np.zeros(flat, dtype=np.int32)
     out_slot = np.full(flat, -1, dtype=np.int32)
+    out_row = np.zeros(flat, dtype=np.int32)
+    ids = (rows if row_ids is None else row_ids).astype(np.int32)
+    item_row = ids[seg_of // XCD_CLASSES]
     for c, pc in enumerate(per_class):
         t = np.arange(len(pc))
         where = (t // items_per_block) * (XCD_CLASSES * items_per_block) + c * items_per_block + t % items_per_block
-        out_e0[where], out_len[where], out_slot[where] = e0[pc], ln[pc], pc
-    return {"e0": out_e0, "len": out_len, "slot": out_slot, "slot_ptr": slot_ptr}
+        out_e0[where], out_len[where], out_slot[where], out_row[where] = e0[pc], ln[pc], pc, item_row[pc]
+    return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "slot_ptr": slot_ptr}
 
 
 class StagedZ:
@@ -167,7 +172,7 @@ class SweepEngine:
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
                  exchange: str = "auto", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
-                 class_chunk: int = CLASS_CHUNK):
+                 class_chunk: int = CLASS_CHUNK, class_k1: bool = True):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
@@ -224,6 +229,7 @@ class SweepEngine:
             raise ValueError("class_threshold: the XCD-affine row kernels are not available with exchange='halo'")
         self.class_threshold = int(class_threshold)
         self.class_chunk = int(class_chunk)
+        self.class_k1 = bool(class_k1) and self.class_threshold > 0    # build_P scores the class rows XCD-affine too
         if self.class_threshold and not (64 <= self.class_chunk <= 4096 and self.class_chunk % 64 == 0):
             raise ValueError("class_chunk must be a multiple of 64 in [64, 4096]")
         self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
@@ -247,6 +253,10 @@ class SweepEngine:
                              "rows over more GPUs (exchange='halo') or wait for 64-bit indices")
         if long_threshold is None:
             long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
+            if rows_per_wave == 1 and self.class_threshold:
+                # with the class pass taking the rows above class_threshold, the 33..64-edge rows are better off with
+                # one wave each than with a 16-wave workgroup of which 15 waves leave at once (4.34 -> 4.30 ms)
+                long_threshold = max(long_threshold, self.class_threshold)
             if rows_per_wave > 1:
                 # A T-edge row walked by one sub-wave takes T/8 gather groups in sequence -- the tail of its launch.
                 # That is nothing next to a 40M-edge pass and a third of a 4M-edge one (R-MAT 200k/4M/d=128:
@@ -255,6 +265,9 @@ class SweepEngine:
                 long_threshold = min(long_threshold, by_size)
         # K1 / K2 (build_P) cut rows at the same degree as before; K3's one-(sub-)wave pass also stops below the class rows
         self.score_threshold = int(long_threshold)
+        # K1 with the class pass: its one-(sub-)wave kernel stops below the class rows as well
+        self.k1_threshold = (min(self.score_threshold, self.class_threshold) if self.score_threshold > 0
+                             else self.class_threshold) if self.class_k1 else self.score_threshold
         if self.class_threshold:            # the class rows are nobody else's
             long_threshold = min(long_threshold, self.class_threshold) if long_threshold > 0 else self.class_threshold
         self.long_threshold = int(long_threshold)
@@ -277,7 +290,8 @@ class SweepEngine:
         self.mid_rows: List[Optional[torch.Tensor]] = []      # long_threshold < deg <= hub_threshold: 4 waves/row
         self.hub_rows: List[Optional[torch.Tensor]] = []      # hub_threshold < deg <= SPLIT_EDGES: 16 waves/row
         self.split_rows: List[Optional[tuple]] = []           # deg > SPLIT_EDGES: (rows, seg_ptr, seg_row) on device
-        self.class_rows: List[Optional[tuple]] = []           # deg > class_threshold: (rows, slot_ptr, e0, len, slot)
+        self.class_rows: List[Optional[tuple]] = []           # deg > class_threshold: (rows, slot_ptr, e0, len, slot, row)
+        self.k1_long_rows: List[Optional[torch.Tensor]] = []  # K1's workgroup-per-row list: above k1_threshold, not class
         self.split_edges = SPLIT_EDGES if split_hubs else 0
         hub_edges = int(deg[deg > SPLIT_EDGES].sum()) // max(1, len(self.blocks))
         self.segment_edges = int(min(SPLIT_EDGES, max(MIN_SEGMENT_EDGES, hub_edges // TARGET_SEGMENTS // 1024 * 1024)))
@@ -298,13 +312,16 @@ class SweepEngine:
             if rows_c.size:
                 rows_abs = rows_c + b.local_start
                 items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk,
-                                    CLASS_ITEMS_PER_BLOCK)
+                                    CLASS_ITEMS_PER_BLOCK, row_ids=rows_c)
                 self.class_rows.append((to_dev(rows_c), torch.from_numpy(items["slot_ptr"]).to(dev),
                                         torch.from_numpy(items["e0"]).to(dev), torch.from_numpy(items["len"]).to(dev),
-                                        torch.from_numpy(items["slot"]).to(dev)))
+                                        torch.from_numpy(items["slot"]).to(dev), torch.from_numpy(items["row"]).to(dev)))
                 max_slots = max(max_slots, int(items["slot_ptr"][-1]))
             else:
                 self.class_rows.append(None)
+            k1_long = (db > self.k1_threshold) & ~(is_class if self.class_k1 else np.zeros_like(is_class)) \
+                if self.k1_threshold > 0 else np.zeros_like(is_class)
+            self.k1_long_rows.append(to_dev(np.nonzero(k1_long)[0]))
             self.hub_rows.append(to_dev(np.nonzero(is_hub)[0]))
             rows_s = np.nonzero(is_split)[0]
             if rows_s.size:
@@ -322,8 +339,10 @@ class SweepEngine:
         # segment sums of the split hub rows: one slab per launch stream (blocks on a stream run in order)
         slab_len = max(1, self.k.spmm_split_slab_len(max_segments, max(self.d, 1)))
         if max_slots:
-            slab_len = max(slab_len, self.k.spmm_class_slab_len(max_slots, self.d))
-        self.slabs = [torch.zeros(slab_len, dtype=self.acc_dtype, device=dev) for _ in range(2)]
+            slab_len = max(slab_len, self.k.spmm_class_slab_len(max_slots, self.d), 2 * max_slots)   # K1: 2 stats per slot
+        # one slab per launch stream: blocks alternate between two side streams when there are several
+        self.slabs = [torch.zeros(slab_len, dtype=self.acc_dtype, device=dev)
+                      for _ in range(2 if len(self.blocks) > 1 else 1)]
 
         # ---- halo exchange: send lists and send buffers (one per own chunk) -----------------
         # The kernel that finishes a row also stores it to its slots of the send buffer (`mirrors`: row -> slots,
@@ -579,13 +598,23 @@ class SweepEngine:
                 rp = self.rowptr[b.local_start:]
                 # K1 soft-maxes every row it scores: one wave in registers / online, a listed row by its workgroup
                 k.edge_score(rp, self.colidx, b.nrows, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
-                             self.score_threshold, self.long_rows[i], fuse_softmax=True)
+                             self.k1_threshold, self.k1_long_rows[i], fuse_softmax=True)
+                if self.class_k1 and self.class_rows[i] is not None:
+                    rows_c, slot_ptr, it_e0, it_len, it_slot, it_row = self.class_rows[i]
+                    k.edge_score_class(rp, self.colidx, it_e0, it_len, it_slot, it_row, CLASS_ITEMS_PER_BLOCK, rows_c,
+                                       slot_ptr, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
+                                       self.slabs[i % len(self.slabs)], fuse_softmax=True)
         elif self.E_loc > 0:
             # column split: dot products of the owned columns, summed over the GPUs, then denominators + softmax
             if busy:
                 for i, b in enumerate(self.blocks):
                     k.edge_score(self.rowptr[b.local_start:], self.colidx, b.nrows, b.row0, Z, self.d,
-                                 _hip.SCORE_RAW_DOT, None, None, self.P, self.score_threshold, self.long_rows[i])
+                                 _hip.SCORE_RAW_DOT, None, None, self.P, self.k1_threshold, self.k1_long_rows[i])
+                    if self.class_k1 and self.class_rows[i] is not None:
+                        rows_c, slot_ptr, it_e0, it_len, it_slot, it_row = self.class_rows[i]
+                        k.edge_score_class(self.rowptr[b.local_start:], self.colidx, it_e0, it_len, it_slot, it_row,
+                                           CLASS_ITEMS_PER_BLOCK, rows_c, slot_ptr, b.row0, Z, self.d,
+                                           _hip.SCORE_RAW_DOT, None, None, self.P)
             else:
                 self.P.zero_()
             self._all_reduce(self.P)
@@ -634,16 +663,16 @@ class SweepEngine:
                     per_block.append(steps + [("event", i, e) for e in (4, 1, 2, 3)])
                     continue
                 if self.class_rows[i] is not None:
-                    rows_c, slot_ptr, it_e0, it_len, it_slot = self.class_rows[i]
+                    rows_c, slot_ptr, it_e0, it_len, it_slot, _ = self.class_rows[i]
                     steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
                                                      CLASS_ITEMS_PER_BLOCK, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
-                                                     Zn, self.d, self.slabs[i % 2], self.partials[po_class:],
+                                                     Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:],
                                                      mirror=mir)))
                 if self.split_rows[i] is not None:
                     rows_s, seg_ptr, seg_row = self.split_rows[i]
                     steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
                                                      seg_row, self.segment_edges, b.row0, Zold, Xb, gamma, Zn, self.d,
-                                                     self.slabs[i % 2], self.partials[po_split:], mirror=mir)))
+                                                     self.slabs[i % len(self.slabs)], self.partials[po_split:], mirror=mir)))
                 steps.append(("event", i, 4))
                 if self.hub_rows[i] is not None:
                     steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
@@ -794,7 +823,7 @@ class SweepEngine:
                 "long_threshold": self.long_threshold, "score_threshold": self.score_threshold,
                 "hub_threshold": self.hub_threshold,
                 "split_edges": self.split_edges, "segment_edges": self.segment_edges,
-                "class_threshold": self.class_threshold, "class_chunk": self.class_chunk,
+                "class_threshold": self.class_threshold, "class_chunk": self.class_chunk, "class_k1": self.class_k1,
                 "class_of_row": "(row / 8) % 8" if self.class_threshold else None,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 

@@ -187,6 +187,25 @@ def xcd_class(position):
     return (position >> 3) & (XCD_CLASSES - 1)
 
 
+def edge_order(row_of, cols, cls, table_rows: int, two_pass: Optional[bool] = None):
+    """Permutation (torch) that sorts edges by (row, class, column) -- `cls` None: by (row, column).  (row, column)
+    pairs are unique, so any sort gives THE order.  One sort of a fused int64 key while it fits; two stable sorts
+    beyond that (rows x 8 x table rows >= 2^62: more than ~7e8 vertices on one GPU)."""
+    import torch
+    n_rows = int(row_of.max()) + 1 if row_of.numel() else 1
+    width = table_rows * (XCD_CLASSES if cls is not None else 1)
+    if two_pass is None:
+        two_pass = n_rows * width >= 2 ** 62
+    if not two_pass:
+        key = row_of * width + cols
+        if cls is not None:
+            key = key + cls * table_rows
+        return torch.argsort(key)
+    first = torch.argsort(cols, stable=True)
+    major = row_of if cls is None else row_of * XCD_CLASSES + cls
+    return first[torch.argsort(major[first], stable=True)]
+
+
 def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int = 0) -> LocalCSR:
     """Slice + relabel the global CSR for one rank.  The one heavy step -- re-sorting every row's edges by their
     new column -- is a single sort of unique (row, column) keys; with ``device`` = a GPU it runs there (40M edges:
@@ -219,10 +238,7 @@ def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int
     # original edge id of every local edge: start-of-row + offset within the row
     origin = t(csr.rowptr[safe])[row_of] + (torch.arange(int(rowptr[-1]), device=dev) - rowptr_t[:-1][row_of])
     cols = t(pos)[t(csr.colidx.astype(np.int64))[origin]]
-    key = row_of * part.padded_vertices + cols                           # keys are unique: any sort is THE order
-    if by_class.any():
-        key = row_of * (XCD_CLASSES * part.padded_vertices) + cols + torch.where(
-            t(by_class)[row_of], xcd_class(cols) * part.padded_vertices, torch.zeros_like(cols))
-    order = torch.argsort(key)
+    cls = xcd_class(cols) * t(by_class).to(cols.dtype)[row_of] if by_class.any() else None
+    order = edge_order(row_of, cols, cls, part.padded_vertices)
     cols, origin = cols[order], origin[order]
     return LocalCSR(rowptr, cols.to(torch.int32).cpu().numpy(), indeg, verts, origin.cpu().numpy())

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CLANE_ABI_VERSION 2 /* 2: + clane_build_info, clane_spmm_update_class_* */
+#define CLANE_ABI_VERSION 2 /* 2: + clane_build_info, clane_spmm_update_class_*, clane_edge_score_class_* */
 
 #define CLANE_OK 0
 #define CLANE_ERR_INVALID_ARGUMENT (-1)
@@ -222,6 +222,33 @@ int clane_spmm_update_split_bf16(const int64_t *rowptr, const int32_t *colidx, c
                                  const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
                                  uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
                                  double *delta_partials, void *stream);
+
+/*  clane_edge_score_class_* : K1 (graph.py:119-123 + similarity.py:26-37) over the listed long rows with XCD-affine
+ *                             gathers -- the build_P counterpart of clane_spmm_update_class_* below, over the SAME item
+ *                             arrays plus item_row (local row id of each item's source row).  A wave scores the edges
+ *                             of one item (modes and `sums2` / `sq` as clane_edge_score_*).  With
+ *                             CLANE_SCORE_FUSE_SOFTMAX every item leaves {max, sum exp} in stats[2 * slot] (2 *
+ *                             n_slots accumulate-type elements) and each listed row is then soft-maxed from its
+ *                             slots, combined in slot order; without it rowptr / class_rows / slot_ptr / stats may be
+ *                             NULL and the raw scores stay (column-split runs all-reduce them first). */
+int clane_edge_score_class_f32(const int64_t *rowptr, const int32_t *colidx, const int64_t *item_e0,
+                               const int32_t *item_len, const int32_t *item_slot, const int32_t *item_row,
+                               int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,
+                               const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const float *Z, int64_t ldz,
+                               int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
+                               int32_t flags, float *stats, void *stream);
+int clane_edge_score_class_f64(const int64_t *rowptr, const int32_t *colidx, const int64_t *item_e0,
+                               const int32_t *item_len, const int32_t *item_slot, const int32_t *item_row,
+                               int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,
+                               const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const double *Z, int64_t ldz,
+                               int32_t d, int32_t mode, const double *sums2, const double *sq, double *scores,
+                               int32_t flags, double *stats, void *stream);
+int clane_edge_score_class_bf16(const int64_t *rowptr, const int32_t *colidx, const int64_t *item_e0,
+                                const int32_t *item_len, const int32_t *item_slot, const int32_t *item_row,
+                                int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,
+                                const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const uint16_t *Z, int64_t ldz,
+                                int32_t d, int32_t mode, const double *sums2, const float *sq, float *scores,
+                                int32_t flags, float *stats, void *stream);
 
 /*  clane_spmm_update_class_* : long rows whose gathers are kept XCD-affine (no reference counterpart: the reference's
  *                             loop is embedder.py:84-92 for every row alike).  MI355X has 8 XCDs with a private 4 MiB

@@ -50,6 +50,31 @@ class OracleKernels:
                 if rp[r + 1] > rp[r]:
                     scores[rp[r]:rp[r + 1]] = torch.softmax(scores[rp[r]:rp[r + 1]], 0)
 
+    def edge_score_class(self, rowptr, colidx, item_e0, item_len, item_slot, item_row, items_per_block, class_rows,
+                         slot_ptr, row0, Z, d, mode, sums2, sq, scores, stats=None, fuse_softmax=False):
+        """K1 over the class rows' items; checks the same layout contract as spmm_update_class."""
+        e0, ln, rw = _np(item_e0), _np(item_len), _np(item_row)
+        assert 4 <= items_per_block <= 64 and e0.size % items_per_block == 0 and e0.size // items_per_block % 8 == 0
+        Zf = Z[:, :d].to(scores.dtype)
+        listed = set(class_rows.tolist())
+        for k in range(e0.size):
+            if ln[k] == 0:
+                continue
+            a, b = int(e0[k]), int(e0[k]) + int(ln[k])
+            cols = colidx[a:b].long()
+            assert bool((xcd_class(cols) == (k // items_per_block) % 8).all()) and int(rw[k]) in listed
+            src = row0 + int(rw[k])
+            dots = (Zf[src].unsqueeze(0) * Zf[cols]).sum(1)
+            if mode == 0:
+                dots = dots / (sums2[0].to(scores.dtype).sqrt() * sums2[1].to(scores.dtype).sqrt())
+            elif mode == 1:
+                dots = dots / (sq[src].sqrt() * sq[cols].sqrt())
+            scores[a:b] = dots
+        if fuse_softmax:
+            rp = _np(rowptr)
+            for r in class_rows.tolist():
+                scores[rp[r]:rp[r + 1]] = torch.softmax(scores[rp[r]:rp[r + 1]], 0)
+
     def edge_score_finalize(self, rowptr, colidx, nrows, row0, mode, sums2, sq, scores):
         rp = _np(rowptr[:nrows + 1])
         if rp[-1] == rp[0] or mode == 2:

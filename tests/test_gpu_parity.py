@@ -762,6 +762,66 @@ def test_spmm_class_affine_rows(dev, k, dtype, d, pad, chunk):
 
 
 @pytest.mark.parametrize("dtype,d,pad", [(torch.float32, 256, True), (torch.float32, 100, True), (torch.float64, 64, True),
+                                         (torch.bfloat16, 128, True), (torch.float32, 32, True), (torch.float32, 37, False),
+                                         (torch.float32, 1433, True)])
+def test_edge_score_class_affine_rows(dev, k, dtype, d, pad):
+    """clane_edge_score_class_*: K1 over the class rows' work items (chunks of one XCD class per wave): raw dots,
+    reference-mode and per-edge scores == the row kernels' bit for bit (the same exchange tree per edge); with the
+    fused softmax every listed row == the oracle's P and == K1 raw + K2; other rows are not written."""
+    from clane_amd.engine import class_items
+    from clane_amd.partition import xcd_class
+    csr0 = ragged_csr(900, seed=3, hubs=(700, 129, 64, 900, 385, 65))
+    V, acc = csr0.num_vertices, _hip.acc_dtype(dtype)
+    deg = np.diff(csr0.rowptr)
+    rows = np.nonzero(deg > 100)[0]
+    colidx = csr0.colidx.copy()
+    for r in rows:
+        a, b = csr0.rowptr[r], csr0.rowptr[r + 1]
+        c = colidx[a:b]
+        colidx[a:b] = c[np.lexsort((c, xcd_class(c)))]
+    Zc = synth.gaussian_X(V, d, seed=5).to(dtype)
+    Zd = padded(Zc, dtype, dev, None if pad else d)
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    rp_d, ci_d, rows_d = t(csr0.rowptr), t(colidx), t(rows.astype(np.int32))
+    items = class_items(csr0.rowptr, colidx, rows, 64, 8)
+    it = [t(items[key]) for key in ("e0", "len", "slot", "row")]
+    n_slots = int(items["slot_ptr"][-1])
+    sq = torch.empty(V, dtype=acc, device=dev)
+    k.row_sqnorm(Zd, d, sq)
+    ws = torch.zeros(k.reduce_ws_len(), dtype=torch.float64, device=dev)
+    sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    k.degree_weighted_sums(sq, rp_d, t(np.bincount(colidx, minlength=V).astype(np.int32)), V, ws, sums2)
+    listed = np.zeros(csr0.num_edges, dtype=bool)
+    for r in rows:
+        listed[csr0.rowptr[r]:csr0.rowptr[r + 1]] = True
+    listed_d = t(listed)
+    stats = torch.full((2 * n_slots,), float("nan"), dtype=acc, device=dev)
+    for mode, s2, sqv in ((_hip.SCORE_RAW_DOT, None, None), (_hip.SCORE_REFERENCE, sums2, None),
+                          (_hip.SCORE_PER_EDGE, None, sq)):
+        ref = torch.zeros(csr0.num_edges, dtype=acc, device=dev)
+        k.edge_score(rp_d, ci_d, V, 0, Zd, d, mode, s2, sqv, ref)                    # every row by one (sub-)wave
+        got = torch.full_like(ref, 7.0)
+        k.edge_score_class(rp_d, ci_d, *it, 8, rows_d, t(items["slot_ptr"]), 0, Zd, d, mode, s2, sqv, got)
+        assert torch.equal(got[listed_d], ref[listed_d])
+        assert bool((got[~listed_d] == 7.0).all())                                   # only the listed rows' edges
+        if mode != _hip.SCORE_RAW_DOT:
+            fused = torch.full_like(ref, 7.0)
+            k.edge_score_class(rp_d, ci_d, *it, 8, rows_d, t(items["slot_ptr"]), 0, Zd, d, mode, s2, sqv, fused, stats,
+                               fuse_softmax=True)
+            k.segment_softmax(rp_d, V, ref)
+            assert rel(fused[listed_d], ref[listed_d]) < (1e-14 if dtype == torch.float64 else 3e-7)
+            P_or = O.build_P_values(csr0.rowptr, colidx, Zc.to(acc).double(),
+                                    mode="per_edge" if mode == _hip.SCORE_PER_EDGE else "reference")
+            assert rel(fused[listed_d], P_or[torch.from_numpy(listed)]) < max(TOL[dtype], 1e-6) \
+                if dtype != torch.bfloat16 else 1e-4
+            for r in rows:
+                assert float(fused[csr0.rowptr[r]:csr0.rowptr[r + 1]].double().sum()) == pytest.approx(1.0, abs=1e-5)
+    with pytest.raises(ValueError, match="stats"):
+        k.edge_score_class(rp_d, ci_d, *it, 8, rows_d, t(items["slot_ptr"]), 0, Zd, d, _hip.SCORE_PER_EDGE, None, sq,
+                           got, None, fuse_softmax=True)
+
+
+@pytest.mark.parametrize("dtype,d,pad", [(torch.float32, 256, True), (torch.float32, 100, True), (torch.float64, 64, True),
                                          (torch.bfloat16, 128, True), (torch.float32, 37, False)])
 def test_spmm_mirror_packs_send_buffer(dev, k, dtype, d, pad):
     """clane_mirror_t: each finished row is also stored to its slots of a second buffer (0, 1 or several slots

@@ -153,7 +153,7 @@ def test_k1_scores_at_scale(dev, k, d):
     assert big.size >= 20                                               # multi-chunk rows exist at this size
     X = synth.gaussian_X(V, d, seed=2)
     eng = SweepEngine(csr, X, dev, cosine_mode="per_edge")
-    assert eng.score_threshold == (32 if d == 256 else 128) and eng.long_rows[0] is not None
+    assert eng.score_threshold == (64 if d == 256 else 128) and eng.class_k1 and eng.class_rows[0] is not None
     eng.build_P()
     P_gpu = eng.P_global()
     P_ref = O.build_P_values(csr.rowptr, csr.colidx, X, mode="per_edge")
@@ -163,7 +163,10 @@ def test_k1_scores_at_scale(dev, k, d):
     # raw dots with the engine's own structure (its vertex order, its long-row list)
     raw = torch.full((eng.E_loc,), float("nan"), dtype=torch.float32, device=dev)
     k.edge_score(eng.rowptr, eng.colidx, eng.part.n_local, 0, eng.Zcur, eng.d, _hip.SCORE_RAW_DOT, None, None, raw,
-                 eng.score_threshold, eng.long_rows[0])
+                 eng.k1_threshold, eng.k1_long_rows[0])
+    rows_c, slot_ptr, it_e0, it_len, it_slot, it_row = eng.class_rows[0]         # ... and its class rows' work items
+    k.edge_score_class(eng.rowptr, eng.colidx, it_e0, it_len, it_slot, it_row, 32, rows_c, slot_ptr, 0, eng.Zcur, eng.d,
+                       _hip.SCORE_RAW_DOT, None, None, raw)
     dots = torch.empty(E)
     dots[torch.from_numpy(eng.local.edge_origin)] = raw.cpu()
     dots_ref = O.edge_dots(csr.rowptr, csr.colidx, X)
@@ -174,6 +177,11 @@ def test_k1_scores_at_scale(dev, k, d):
     eng.cosine_mode, eng.P_valid = "reference", False
     eng.build_P()
     assert rel(eng.P_global(), O.build_P_values(csr.rowptr, csr.colidx, X)) < 2e-6
+    # the long-row kernels of round 1 (no class pass anywhere) give the same per-edge P
+    old = SweepEngine(csr, X, dev, cosine_mode="per_edge", class_threshold=0)
+    assert old.long_rows[0] is not None and not old.class_k1
+    old.build_P()
+    assert rel(old.P_global(), P_ref) < 2e-6 and rel(old.P_global(), P_gpu) < 1e-6
 
 
 # ---- (b) config 3 at full size: per-edge P on sampled rows + the heaviest hubs -----------------------------------------

@@ -682,6 +682,16 @@ def test_class_affine_rows_layout_and_result(chunks, hot):
                                                                        class_threshold=0).kernel_bytes().values())
     with pytest.raises(ValueError, match="class_chunk"):
         SweepEngine(csr, X, "cpu", OracleKernels(), class_threshold=8, class_chunk=100)
+    # the edge order has a two-pass form for key ranges beyond int64: same permutation
+    from clane_amd.partition import edge_order
+    g = torch.Generator().manual_seed(0)
+    rows_t = torch.sort(torch.randint(0, 50, (4000,), generator=g)).values
+    cols_t = torch.randperm(4000, generator=g) % 977 + 977 * (torch.arange(4000) % 4)        # unique per row: distinct values
+    cls_t = ((cols_t >> 3) & 7) * (rows_t % 2)
+    for c in (None, cls_t):
+        one, two = edge_order(rows_t, cols_t, c, 4000, two_pass=False), edge_order(rows_t, cols_t, c, 4000, two_pass=True)
+        k = rows_t * 10**8 + (0 if c is None else c) * 10**5 + cols_t
+        assert torch.equal(k[one], k[two]) and bool((k[one][1:] >= k[one][:-1]).all())
     # the item builder refuses rows that are not in class order
     with pytest.raises(AssertionError, match="sorted by"):
         class_items(csr.rowptr, csr.colidx, np.array([5]), 64, 8)
