@@ -423,6 +423,9 @@ def main():
             result["cpu_baseline"] = base
             result["cpu_baseline_torch"] = cpu_baseline_torch(csr, Xf, P_host, args.gamma)
         else:                       # P from the oracle's own build_P when the ranks hold only their rows of it
+            if world > 1:           # torchrun gives every rank OMP_NUM_THREADS=1; the others are idle at the barrier now
+                from oracle import clane_oracle_c as OC
+                OC.set_threads(os.cpu_count() or 1)
             P_host = eng.P_global() if (world == 1 or eng.columns) else None
             Zo, _, _, _, _ = oracle_first_sweep(csr, X, P_host, args.gamma)
             parity = O.rel_l2(Z1.float(), Zo)

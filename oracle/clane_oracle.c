@@ -31,6 +31,15 @@ int clane_c_threads(void) {
 #endif
 }
 
+/* Under torchrun every rank gets OMP_NUM_THREADS=1; the rank that runs the check may ask for the box's cores back. */
+void clane_c_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* Z_new = X + gamma * P Z_old (rows without out-edges: Z_new = Z_old); returns sum |Z_new - Z_old|. */
 double clane_c_sweep_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t V, int32_t d,
                          const float *X, const float *Zold, float gamma, float *Znew) {

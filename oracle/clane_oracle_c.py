@@ -23,6 +23,7 @@ def lib():
         L = C.CDLL(str(so))
         p, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
         L.clane_c_threads.restype = C.c_int
+        L.clane_c_set_threads.argtypes = [C.c_int]
         L.clane_c_sweep_f32.restype = C.c_double
         L.clane_c_sweep_f32.argtypes = [p, p, p, i64, i32, p, p, C.c_float, p]
         L.clane_c_build_P_f32.restype = C.c_double
@@ -33,6 +34,11 @@ def lib():
 
 def threads() -> int:
     return int(lib().clane_c_threads())
+
+
+def set_threads(n: int) -> None:
+    """OpenMP threads of the following calls (torchrun starts every rank with OMP_NUM_THREADS=1)."""
+    lib().clane_c_set_threads(int(n))
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
