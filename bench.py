@@ -153,14 +153,14 @@ def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=8.0):
                                      f"torch.set_num_threads(1)"}}
 
 
-def traffic_entry(workload: str, world: int, eng, dom: str):
+def traffic_entry(workload: str, world: int, eng, dom: str, slice_of=None):
     """PMC traffic of kernel `dom` from profiles/traffic.json -- only if it was measured with THIS kernel
     configuration (thresholds, launch blocks, compile-time tuning, ...); else (None, why)."""
     tfile = ROOT / "profiles" / "traffic.json"
     if not tfile.exists():
         return None, "no profiles/traffic.json"
     table = json.loads(tfile.read_text())
-    key = f"{workload}_n{world}"
+    key = f"{workload}_column_slice_of_{slice_of}" if slice_of else f"{workload}_n{world}"
     entry = table.get(key)
     if entry is None and world > 1 and eng.columns:          # measured on one GPU over the same column slice
         key = f"{workload}_column_slice_of_{world}"
@@ -203,15 +203,22 @@ def main():
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (RCCL refuses that: use --backend gloo)")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="opt-in (SURVEY H5): launch sweep t+1 before the host has read sweep t's delta "
-                         "(SweepEngine.sweep_launch / sweep_wait); every delta is still read, one sweep later")
+    ap.add_argument("--host-sync", default="auto", choices=["auto", "every-sweep", "pipelined"],
+                    help="every-sweep: the host reads a sweep's delta before launching the next (the reference's literal "
+                         "order); pipelined (SURVEY H5): sweep t+1 is launched before the delta of sweep t is read -- every "
+                         "delta is still read, one sweep later (SweepEngine.sweep_launch / sweep_wait; Embedder's "
+                         "lagged_check, bit-identical results); auto (default) = what Embedder does by default: pipelined "
+                         "when a sweep is estimated below 1 ms (SweepEngine.estimated_sweep_seconds), else every-sweep")
+    ap.add_argument("--pipelined", action="store_true", help="same as --host-sync pipelined")
     ap.add_argument("--iterate", action="store_true",
                     help="after the timed sweeps also run the WHOLE algorithm from Z = X -- Embedder.iterate() to "
                          "tolerance (build_P + propagate per outer round) -- and report rounds, sweeps, wall time")
     ap.add_argument("--tolerence", type=int, default=10, help="(reference spelling) for --iterate")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines (the parity check stays)")
     ap.add_argument("--no-parity", action="store_true", help="skip the first-sweep check against the C oracle too")
+    ap.add_argument("--column-slice-of", type=int, default=None, metavar="N",
+                    help="one-GPU rehearsal of ONE rank of the N-GPU column split: sweep only the first d/N columns "
+                         "(what every rank of `--gpus N` does); for profiling that rank's kernels, not a headline number")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch l1_distance over two [V,d] matrices (known bytes) -- PMC calibration")
     args = ap.parse_args()
@@ -254,6 +261,12 @@ def main():
         csr = synth.powerlaw_csr(V, E, seed=gseed, device=str(dev))
     E = csr.num_edges
     X = synth.gaussian_X(V, d, seed=xseed).to(DTYPES[dname])
+    if args.column_slice_of:
+        if world != 1:
+            raise SystemExit("--column-slice-of is a one-GPU rehearsal")
+        from clane_amd.engine import column_slice
+        c0, c1 = column_slice(d, X.dtype, args.column_slice_of, 0)
+        X = X[:, c0:c1].contiguous()
     if world > 1:       # every rank generated the graph on its own GPU from the same seed: make sure they agree
         mine = (E, int(csr.colidx.astype(np.int64).sum()), int(csr.rowptr[::997].sum()), float(X[::9973].double().sum()))
         everyone = [None] * world
@@ -315,11 +328,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pipelined:
+        args.host_sync = "pipelined"
+    pipelined = args.host_sync == "pipelined" or (args.host_sync == "auto" and eng.estimated_sweep_seconds() < 1e-3)
     eng.time_kernels = True
     eng.kernel_events = []
     barrier()
     t0 = time.perf_counter()
-    if args.pipelined:
+    if pipelined:
         ticket = eng.sweep_launch(args.gamma)
         for _ in range(args.steps - 1):
             following = eng.sweep_launch(args.gamma)
@@ -360,7 +376,7 @@ def main():
     pass_bytes = sum(kbytes.values())
     pass_traffic = 0.0
     for name, pk in per_kernel.items():
-        tr, why = traffic_entry(args.workload, world, eng, name)
+        tr, why = traffic_entry(args.workload, world, eng, name, args.column_slice_of)
         alg = pk["algorithmic_bytes_per_launch"]
         pk["traffic"] = tr
         counted = min(alg, tr) if tr is not None else alg
@@ -380,7 +396,10 @@ def main():
         f"no valid PMC traffic for this configuration ({pd['traffic_missing']}): frac is the algorithmic rate, capped "
         f"at the roof -- rates above 8 TB/s mean rows served from L2 / the Infinity Cache, not HBM")
 
-    if world == 1:
+    if args.column_slice_of:
+        parallelism = (f"REHEARSAL on 1 GPU of one rank of the column split x{args.column_slice_of}: columns "
+                       f"[0:{X.shape[1]}) of X and Z, whole graph; not a headline number")
+    elif world == 1:
         parallelism = f"1 GPU, {chunks} launch block(s)/sweep"
     elif eng.columns:
         parallelism = (f"column split x{world}: every GPU holds the whole graph and columns [{eng.col0}:{eng.col1}) "
@@ -400,8 +419,8 @@ def main():
                                f"gamma={args.gamma}, CosineSimilarity "
                                f"(reference mode), seeds {gseed}/{xseed}",
                    "parallelism": parallelism,
-                   "host_sync": ("pipelined: the delta of sweep t is read while sweep t+1 runs" if args.pipelined
-                                 else "after every sweep (reference semantics)")},
+                   "host_sync": (f"pipelined ({args.host_sync}): the delta of sweep t is read while sweep t+1 runs"
+                                 if pipelined else f"after every sweep ({args.host_sync}; the reference's order)")},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": pd["achieved"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": pd["frac"], "traffic": pd["traffic"],
                      "achieved_algorithmic": pd["achieved_algorithmic"],

@@ -72,7 +72,8 @@ class Embedder(object):
         # is discarded (the ping-pong partner still holds the right embeddings) -- counts, deltas and embeddings are
         # bit-identical either way.  It costs one discarded sweep per propagate and saves the host round trip of
         # every sweep, so it pays when sweeps are short.  None (default): on one GPU, switched on inside a propagate
-        # once a sweep has taken less than LAGGED_BELOW_S; True / False: always / never.  Off with save_history.
+        # once a sweep has taken less than LAGGED_BELOW_S; on several GPUs, on when the engine's estimate of a sweep
+        # (the same number on every rank) is below it; True / False: always / never.  Off with save_history.
         self.lagged_check = lagged_check
         self.sweeps_launched = 0
         self._round_was_idle = False
@@ -161,7 +162,12 @@ class Embedder(object):
         self._round_was_idle = False
         can_lag = not self.save_history and hasattr(engine, "sweep_launch")
         ahead = bool(self.lagged_check) and can_lag
-        auto = self.lagged_check is None and can_lag and getattr(engine, "world", 1) == 1
+        world = getattr(engine, "world", 1)
+        auto = self.lagged_check is None and can_lag and world == 1
+        if self.lagged_check is None and can_lag and world > 1 and hasattr(engine, "estimated_sweep_seconds"):
+            # several ranks must decide alike, so not by a stopwatch: by the same estimate on every rank.  Lagging also
+            # hides the latency of the per-sweep scalar all-reduce.
+            ahead = engine.estimated_sweep_seconds() < self.LAGGED_BELOW_S
         fastest = math.inf                          # shortest synchronous sweep seen in this propagate (auto mode)
         ticket = None                               # the launched sweep whose delta has not been read yet
         if ahead and not idle:

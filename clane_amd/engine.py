@@ -209,6 +209,7 @@ class SweepEngine:
         self.exchange = exchange if divided else "none"
         self.columns = divided and exchange == "columns"
         self.V, self.d_full = csr.num_vertices, int(X.shape[1])
+        self.E_total = csr.num_edges
         self.col0, self.col1 = column_slice(self.d_full, X.dtype, self.world, rank) if self.columns else (0, self.d_full)
         X_all = X
         if self.columns:
@@ -811,6 +812,15 @@ class SweepEngine:
                 "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>",
                 "split": "spmm_class_chunk_kernel+combine" if self.class_threshold > 0
                 else "spmm_split_segment_kernel+combine"}
+
+    def estimated_sweep_seconds(self) -> float:
+        """Rough time of one sweep on this division, the SAME number on every rank (it feeds decisions all ranks
+        must take alike, e.g. whether the host check lags one sweep): the whole graph's gather-model bytes / ranks
+        at the HBM peak."""
+        s = self.Zcur.element_size()
+        d = self.d_full
+        total = self.E_total * (d * s + 8) + self.V * 3 * d * s
+        return total / max(self.world, 1) / 8e12
 
     def kernel_config(self) -> dict:
         """Everything that decides which K3 kernels a sweep launches over which rows, and with which compile-time

@@ -8,6 +8,7 @@
 #   tools/profile_bench.sh <workload> <tag> [extra bench.py arguments]
 set -e
 W=${1:-rmat2m}; TAG=${2:-r02}; shift 2 || true
+KEY=${CLANE_PROFILE_KEY:-${W}_n1}        # name of the traffic.json entry (e.g. rmat2m_column_slice_of_8 with --column-slice-of 8)
 R="$(cd "$(dirname "$0")/.." && pwd)"
 RAW="/tmp/clane_prof_${TAG}_${W}"; rm -rf "$RAW"; mkdir -p "$RAW" "$R/gpurun_out/profiles"
 cd /tmp && export TMPDIR=/tmp
@@ -20,7 +21,7 @@ echo "[profile] FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$RAW/write" -- python3 "$R/bench.py" --workload $W --steps 10 \
     --warmup 2 --no-cpu-baseline --calibrate "$@" > "$RAW/bench_write.json" 2> "$RAW/bench_write.err" || { tail -20 "$RAW/bench_write.err"; exit 1; }
 echo "[profile] WRITE_SIZE pass done"
-python3 "$R/tools/pmc_summary.py" "$RAW/fetch" "$RAW/write" --tag $TAG --workload ${W}_n1 \
+python3 "$R/tools/pmc_summary.py" "$RAW/fetch" "$RAW/write" --tag $TAG --workload ${KEY} \
     --bench-json "$RAW/bench_fetch.json" --stats "$RAW/stats" --out "$R/gpurun_out/profiles"
-cp "$RAW/bench_stats.json" "$R/gpurun_out/profiles/${TAG}_bench_under_rocprof_${W}_n1.json"
-cp "$RAW/bench_fetch.json" "$R/gpurun_out/profiles/${TAG}_bench_under_pmc_fetch_${W}_n1.json"
+cp "$RAW/bench_stats.json" "$R/gpurun_out/profiles/${TAG}_bench_under_rocprof_${KEY}.json"
+cp "$RAW/bench_fetch.json" "$R/gpurun_out/profiles/${TAG}_bench_under_pmc_fetch_${KEY}.json"
