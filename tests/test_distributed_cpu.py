@@ -88,8 +88,8 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         emb.iterate()
         assert O.rel_l2(g2.Z, torch.from_numpy(gold["Z_final"])) < 1e-6
         counts = [None] * world
-        dist.all_gather_object(counts, emb.sweep_counts)
-        assert all(c == counts[0] for c in counts)
+        dist.all_gather_object(counts, (emb.sweep_counts, eng.estimated_sweep_seconds()))
+        assert all(c == counts[0] for c in counts)      # same decisions, and the estimate behind the lagged check agrees
         (Path(out_dir) / f"ok{rank}").write_text("ok")
         dist.barrier()              # leave together: a rank tearing gloo down while others still talk can abort
     finally:

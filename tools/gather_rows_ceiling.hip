@@ -31,7 +31,7 @@ typedef float nt_f4 __attribute__((ext_vector_type(4)));
 // the hot ones out of L2); groups are pure (all hot or all cold) in the lists used with it.
 template <int LPR, int U>
 __global__ __launch_bounds__(256) void gather(const float4 *__restrict__ Z, const int *__restrict__ idx,
-                                              long n_groups, int nb, float4 *__restrict__ out, int nt_from = -1) {
+                                              long n_groups, int nb, float4 *__restrict__ out, int nt_from = -1, int policy = 1) {
     constexpr int EPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane / LPR, sl = lane % LPR;
     const long wave_in_bucket = (long)(blockIdx.x / nb) * 4 + (threadIdx.x >> 6);
@@ -45,12 +45,23 @@ __global__ __launch_bounds__(256) void gather(const float4 *__restrict__ Z, cons
         for (int j = 0; j < 64; j += EPW * U) {
             float4 z[U];
             if (cold) {
+                const float4 *ptr[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = __shfl(my, j + u * EPW + sub, 64);
-                    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(Z + (long)c * LPR + sl));
-                    z[u] = float4{v.x, v.y, v.z, v.w};
-                }
+                for (int u = 0; u < U; ++u) ptr[u] = Z + (long)__shfl(my, j + u * EPW + sub, 64) * LPR + sl;
+                // cache policy of the cold gathers: the bits are instruction modifiers, hence inline asm (the compiler
+                // does not count these loads: explicit s_waitcnt below)
+#define CLANE_COLD_LOADS(MOD)                                                                              \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) asm volatile("global_load_dwordx4 %0, %1, off " MOD     \
+                                                               : "=v"(z[u])                               \
+                                                               : "v"(ptr[u])                              \
+                                                               : "memory");
+                if (policy == 1) { CLANE_COLD_LOADS("nt") }
+                else if (policy == 2) { CLANE_COLD_LOADS("sc0") }
+                else if (policy == 3) { CLANE_COLD_LOADS("sc1") }
+                else if (policy == 4) { CLANE_COLD_LOADS("sc0 sc1") }
+                else if (policy == 5) { CLANE_COLD_LOADS("sc1 nt") }
+                else { CLANE_COLD_LOADS("sc0 sc1 nt") }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -71,14 +82,14 @@ __global__ __launch_bounds__(256) void gather(const float4 *__restrict__ Z, cons
 }
 
 template <int LPR>
-float run(const float4 *Z, const int *idx, long n_groups, int nb, float4 *out, int grid, int nt_from = -1) {
+float run(const float4 *Z, const int *idx, long n_groups, int nb, float4 *out, int grid, int nt_from = -1, int policy = 1) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
     float best = 1e9;
     for (int rep = 0; rep < 4; ++rep) {
         CK(hipEventRecord(a));
-        gather<LPR, 8><<<grid, 256>>>(Z, idx, n_groups, nb, out, nt_from);
+        gather<LPR, 8><<<grid, 256>>>(Z, idx, n_groups, nb, out, nt_from, policy);
         CK(hipEventRecord(b));
         CK(hipEventSynchronize(b));
         float ms;
@@ -97,7 +108,7 @@ static inline int cls_of(int r) {
 
 int run_all();
 int main() {
-    for (g_class_mode = 0; g_class_mode < 3; ++g_class_mode) {
+    for (g_class_mode = 2; g_class_mode < 3; ++g_class_mode) {
         printf("== class of a row: %s\n", g_class_mode == 0 ? "r % 8" : g_class_mode == 1 ? "xor-fold(r) % 8" : "(r / 8) % 8");
         run_all();
     }
@@ -188,15 +199,14 @@ int run_all() {
     int *idx_pure;
     CK(hipMalloc(&idx_pure, pure.size() * sizeof(int)));
     CK(hipMemcpy(idx_pure, pure.data(), pure.size() * sizeof(int), hipMemcpyHostToDevice));
-    for (int nt : {-1}) {
+    for (int pol = 0; pol <= 6; ++pol) {
+        const int nt = pol == 0 ? -1 : H;
         const long np = (long)pure.size(), ng = np / 64;
         const int grid = 8192;
-        const float t128 = run<8>(Z, idx_pure, ng, 8, out, grid, nt), t256 = run<16>(Z, idx_pure, ng, 8, out, grid, nt);
-        const float t512 = run<32>(Z, idx_pure, ng, 8, out, grid, nt), t1k = run<64>(Z, idx_pure, ng, 8, out, grid, nt);
-        printf("%-12s grid %5d | 128 B rows %6.3f ms %7.1f GB/s | 256 B %6.3f ms %7.1f | 512 B %6.3f ms %7.1f | "
-               "1 KiB %6.3f ms %7.1f   (pure hot / cold groups, %ld reads)\n",
-               nt < 0 ? "affine,pure" : "affine,pure,NT cold", grid, t128, np * 128.0 / t128 / 1e6, t256,
-               np * 256.0 / t256 / 1e6, t512, np * 512.0 / t512 / 1e6, t1k, np * 1024.0 / t1k / 1e6, np);
+        const float t256 = run<16>(Z, idx_pure, ng, 8, out, grid, nt, pol), t1k = run<64>(Z, idx_pure, ng, 8, out, grid, nt, pol);
+        const char *names[] = {"default", "nt", "sc0", "sc1", "sc0 sc1", "sc1 nt", "sc0 sc1 nt"};
+        printf("affine, pure groups, cold rows read with [%-10s] | 256 B %6.3f ms %7.1f GB/s | 1 KiB %6.3f ms %7.1f GB/s\n",
+               names[pol], t256, np * 256.0 / t256 / 1e6, t1k, np * 1024.0 / t1k / 1e6);
         fflush(stdout);
     }
     for (int variant = 0; variant < 2; ++variant) {
