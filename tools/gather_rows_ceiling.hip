@@ -199,7 +199,7 @@ int run_all() {
     int *idx_pure;
     CK(hipMalloc(&idx_pure, pure.size() * sizeof(int)));
     CK(hipMemcpy(idx_pure, pure.data(), pure.size() * sizeof(int), hipMemcpyHostToDevice));
-    for (int pol = 0; pol <= 6; ++pol) {
+    for (int pol = 0; pol <= 0; ++pol) {
         const int nt = pol == 0 ? -1 : H;
         const long np = (long)pure.size(), ng = np / 64;
         const int grid = 8192;
@@ -208,6 +208,35 @@ int run_all() {
         printf("affine, pure groups, cold rows read with [%-10s] | 256 B %6.3f ms %7.1f GB/s | 1 KiB %6.3f ms %7.1f GB/s\n",
                names[pol], t256, np * 256.0 / t256 / 1e6, t1k, np * 1024.0 / t1k / 1e6);
         fflush(stdout);
+    }
+    // XCD-affine AND phased in time: the rows of an XCD class are split into P sub-classes ((r / 64) % P) and all the
+    // reads of sub-class 0 come before those of sub-class 1, ...: at any moment an XCD's hot working set is 1/P of its
+    // class (1-KiB rows: the 4096 hottest rows of a class are the WHOLE 4 MiB L2 -- with P = 2 they are half of it).
+    for (int P : {1, 2, 4, 8}) {
+        std::vector<std::vector<int>> lists(8 * P);
+        for (int b = 0; b < 8; ++b)
+            for (size_t i = 0; i < per; ++i) lists[((by[b][i] >> 6) % P) * 8 + b].push_back(by[b][i]);
+        std::vector<int> phased;
+        for (int ph = 0; ph < P; ++ph) {
+            size_t g = 0;
+            for (int b = 0; b < 8; ++b) g = std::max(g, (lists[ph * 8 + b].size() + 63) / 64);
+            for (int b = 0; b < 8; ++b) lists[ph * 8 + b].resize(g * 64, lists[ph * 8 + b].back());
+            for (size_t k = 0; k < g; ++k)
+                for (int b = 0; b < 8; ++b)
+                    phased.insert(phased.end(), lists[ph * 8 + b].begin() + k * 64, lists[ph * 8 + b].begin() + (k + 1) * 64);
+        }
+        int *idx_ph;
+        CK(hipMalloc(&idx_ph, phased.size() * sizeof(int)));
+        CK(hipMemcpy(idx_ph, phased.data(), phased.size() * sizeof(int), hipMemcpyHostToDevice));
+        const long np = (long)phased.size(), ng = np / 64;
+        for (int grid : {2048, 8192}) {
+            const float t256 = run<16>(Z, idx_ph, ng, 8, out, grid), t512 = run<32>(Z, idx_ph, ng, 8, out, grid);
+            const float t1k = run<64>(Z, idx_ph, ng, 8, out, grid);
+            printf("XCD-affine, %d phase(s), grid %5d | 256 B %6.3f ms %7.1f GB/s | 512 B %6.3f ms %7.1f | 1 KiB %6.3f ms %7.1f\n",
+                   P, grid, t256, np * 256.0 / t256 / 1e6, t512, np * 512.0 / t512 / 1e6, t1k, np * 1024.0 / t1k / 1e6);
+            fflush(stdout);
+        }
+        CK(hipFree(idx_ph));
     }
     for (int variant = 0; variant < 2; ++variant) {
         CK(hipMemcpy(idx, variant ? bucketed.data() : plain.data(), n * sizeof(int), hipMemcpyHostToDevice));
