@@ -717,6 +717,8 @@ def test_spmm_class_affine_rows(dev, k, dtype, d, pad, chunk):
     rp_d = torch.from_numpy(csr0.rowptr).to(dev)
     items = class_items(csr0.rowptr, colidx, rows, chunk, 8)
     assert int(items["slot_ptr"][-1]) == int((items["len"] > 0).sum()) >= 8 * rows.size - 8
+    on_card = class_items(csr0.rowptr, colidx, rows, chunk, 8, colidx_dev=ci_d)     # the O(E) part on the GPU: same items
+    assert all(np.array_equal(items[key], on_card[key]) for key in items)
     t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
     rows_d = t(rows.astype(np.int32))
     slab = torch.full((k.spmm_class_slab_len(int(items["slot_ptr"][-1]), d),), float("nan"), dtype=acc, device=dev)
