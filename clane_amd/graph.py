@@ -408,7 +408,10 @@ class Graph(torch.utils.data.Dataset):
                         f"CosineSimilarity) has to come as one call.")
                 scores = similarity(Zd[src_pos], Zd[dst_pos]).detach().to(eng.acc_dtype).reshape(-1)
                 eng.P[:eng.E_loc].copy_(scores)
-            eng.k.segment_softmax(eng.rowptr, eng.part.n_local, eng.P)
+            for i, b in enumerate(eng.blocks):        # rows above the engine's threshold: a workgroup per row
+                lr = eng.long_rows[i]
+                eng.k.segment_softmax(eng.rowptr[b.local_start:], b.nrows, eng.P, 0,
+                                      eng.score_threshold if lr is not None else 0, lr)
             eng.P_valid = True
         values = self._gather_P(eng)
         return torch.sparse_coo_tensor(self._edge_index(), values, size=(len(self), len(self)), is_coalesced=True)

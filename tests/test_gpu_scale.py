@@ -363,3 +363,28 @@ def test_f1_harness_on_gpu_embeddings(tmp_path):
     assert t_gpu.shape == (9, 3) and np.isfinite(t_gpu).all() and (t_gpu[:, 1:] >= 0).all() and (t_gpu[:, 1:] <= 1).all()
     np.testing.assert_allclose(t_gpu, t_or, rtol=0, atol=1e-12)
     np.testing.assert_allclose(t_gpu, t_ref, rtol=0, atol=1e-12)          # and the reference's own embeddings
+
+
+def test_plugin_similarity_in_chunks_at_scale(dev):
+    """A `batchwise` plug-in callable on a graph with hub rows: the gathered pair batches come 4 MiB at a time, the
+    rows above the engine's threshold are soft-maxed by a workgroup each, and P equals the oracle's literal
+    gather-and-call (graph.py:119-123); a batch-global callable above the size limit is refused."""
+    V, E, d = 50_000, 1_000_000, 64
+    csr = synth.rmat_csr(V, E, seed=21)
+    X = synth.gaussian_X(V, d, seed=22)
+    g = Graph.from_csr(csr, X)
+    calls = []
+
+    def dot_sim(a, b):
+        calls.append(a.shape[0])
+        return (a * b).sum(1) / 8.0
+    dot_sim.batchwise = True
+    g.PLUGIN_CHUNK_BYTES = 4 << 20
+    P = g.build_P(dot_sim)
+    assert len(calls) == -(-E // ((4 << 20) // (2 * d * 4))) and sum(calls) == E and max(calls) * 2 * d * 4 <= 4 << 20
+    assert g._engine.long_rows[0] is not None and int(np.diff(csr.rowptr).max()) > g._engine.score_threshold
+    ref = O.build_P_values(csr.rowptr, csr.colidx, X, similarity=lambda a, b: (a * b).sum(1) / 8.0)
+    assert rel(P.values(), ref) < 2e-6
+    g.PLUGIN_SINGLE_CALL_MAX_BYTES = 1 << 20
+    with pytest.raises(ValueError, match="batchwise = True"):
+        g.build_P(lambda a, b: (a * b).sum(1))
