@@ -34,10 +34,13 @@ from .comm import TorchComm
 from .halo import build_halo_layout
 from .partition import XCD_CLASSES, Block, HostCSR, LocalCSR, RowPartition, localize, xcd_class
 
-# Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md):
-#   deg <= T   one (sub-)wave per row, rows claimed dynamically inside a workgroup
-#              (spmm_update_kernel when a row fills a wave, spmm_update_subrow_kernel otherwise)
-#   deg >  T   16-wave workgroup per row, 64-aligned slices, idle waves exit at once (spmm_long_kernel)
+# Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md, r02_class_threshold_sweep.md):
+#   deg <= T                 one (sub-)wave per row, rows claimed dynamically inside a workgroup
+#                            (spmm_update_kernel when a row fills a wave, spmm_update_subrow_kernel otherwise)
+#   deg >  class threshold   XCD-affine chunks + fixed-order combine (spmm_class_chunk_kernel; below)
+#   in between               16-wave workgroup per row, 64-aligned slices, idle waves exit at once (spmm_long_kernel);
+#                            rows above SPLIT_EDGES cut into segments -- only without the class pass
+# The thresholds below are those of the row kernels on their own (class pass off):
 # Measured on MI355X: a single wave walking a 65..1024-edge row of 1-KiB rows streams at a fraction of
 # what the multi-wave kernel reaches, so T is small when a row fills a wave (d=256 fp32: T=32); with
 # narrow rows (d=128 bf16: 4 rows per wave-instruction) the sub-wave kernel is the efficient one and a
@@ -55,13 +58,14 @@ SPLIT_EDGES = 4096
 MIN_SEGMENT_EDGES = 1024
 TARGET_SEGMENTS = 512                   # two workgroups per CU
 # Rows above CLASS_THRESHOLD edges are gathered XCD-affine (csrc/spmm_update.h, spmm_class_chunk_kernel): their edges
-# are sorted by (class of the column, column) -- partition.xcd_class --, cut into chunks of at most CLASS_CHUNK edges of one class, and the chunks of
-# class b run on the workgroups 8 j + b = XCD b, so each XCD's 4 MiB L2 caches its own eighth of the hot rows instead
-# of all eight caching the same ones.  Costs one partial sum (d accumulators, written + read once) per chunk, which
-# is why short rows stay with the row kernels.  Threshold by rows per wave-instruction, 0 = off; measured
-# (profiles/r02_class_threshold_sweep.md), sweep ms without -> with: config 3 (1 KiB rows) 5.36 -> 4.38 at 64;
-# its column slices: 512-B rows 2.55 -> 2.09 at 64, 256-B rows 1.26 -> 1.09 at 128..256, 128-B rows 0.716 -> 0.679
-# at 256; config 4's shape (bf16, 256-B rows) 8.24 -> 7.79 at 256; config 2 (Z fits the Infinity Cache) unchanged.
+# are sorted by (class of the column, column) -- partition.xcd_class --, cut into chunks of at most CLASS_CHUNK edges
+# of one class, and the chunks of class b run on the workgroups 8 j + b = XCD b, so each XCD's 4 MiB L2 caches its own
+# eighth of the hot rows instead of all eight caching the same ones.  Costs one partial sum (d accumulators, written +
+# read once) per chunk, which is why short rows stay with the row kernels.  Threshold by rows per wave-instruction,
+# 0 = off; measured (profiles/r02_class_threshold_sweep.md), sweep ms without -> with: config 3 (1-KiB rows)
+# 5.36 -> 4.36 at 64; its column slices: 512-B rows 2.55 -> 1.99 at 64, 256-B rows 1.26 -> 1.04 at 128..256, 128-B rows
+# 0.716 -> 0.632 at 256; config 4's shape (bf16, 256-B rows) 8.24 -> 7.44 at 256; config 2 (Z fits the Infinity Cache)
+# 0.257 -> 0.249.  build_P scores these rows over the same chunks (class_k1: 5.7 -> 4.7 ms at config 3).
 CLASS_THRESHOLD_BY_ROWS_PER_WAVE = {1: 64, 2: 64, 4: 256, 8: 256}
 CLASS_CHUNK = 256
 CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
