@@ -158,6 +158,13 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "slot_ptr": slot_ptr}
 
 
+def items_per_block_for(n_items: int) -> int:
+    """Chunks per workgroup of the class kernels: CLASS_ITEMS_PER_BLOCK when there are plenty, fewer (down to one per
+    wave) when a launch holds few chunks -- a launch wants >= ~4096 workgroups to fill 256 CUs (a rank's quarter of
+    the halo split at 8 GPUs holds 21k chunks: 650 workgroups of 32 ran at a third of the rate of 2 600 of 8)."""
+    return int(min(CLASS_ITEMS_PER_BLOCK, max(4, 4 * -(-n_items // (4 * 4096)))))
+
+
 class StagedZ:
     """The embeddings of one moment on their way to the host (``SweepEngine.stage_Z``): the sweeps go on while
     the copy drains over PCIe; ``result()`` waits for it and returns a fresh ``[V, d]`` CPU tensor in vertex order."""
@@ -238,10 +245,8 @@ class SweepEngine:
         self.hot_rows_first = bool(hot_rows_first)
         self.halo = row_world > 1 and exchange in ("halo", "halo_p2p")
         rows_per_wave = 64 // lanes_per_row(self.d, X.dtype) if self.d > 0 else 1
-        if class_threshold is None:         # XCD-affine long rows: not with the halo tables (their own relabelling)
-            class_threshold = 0 if self.halo else CLASS_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
-        elif class_threshold and self.halo:
-            raise ValueError("class_threshold: the XCD-affine row kernels are not available with exchange='halo'")
+        if class_threshold is None:         # XCD-affine long rows, whatever the division
+            class_threshold = CLASS_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
         self.class_threshold = int(class_threshold)
         self.class_chunk = int(class_chunk)
         self.class_k1 = bool(class_k1) and self.class_threshold > 0    # build_P scores the class rows XCD-affine too
@@ -252,7 +257,7 @@ class SweepEngine:
             raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
         if self.halo:
             self.part = build_halo_layout(csr, self.world, rank, chunks, shuffle=shuffle is not False, seed=seed,
-                                          hot_rows_first=hot_rows_first)
+                                          hot_rows_first=hot_rows_first, class_threshold=self.class_threshold)
             self.blocks: List[Block] = self.part.blocks
             self.local: LocalCSR = self.part.local
         else:
@@ -328,9 +333,14 @@ class SweepEngine:
                 rows_abs = rows_c + b.local_start
                 items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk,
                                     CLASS_ITEMS_PER_BLOCK, row_ids=rows_c, colidx_dev=self.colidx)
+                ipb = items_per_block_for(int(items["slot_ptr"][-1]))
+                if ipb != CLASS_ITEMS_PER_BLOCK:    # few chunks in this launch (a chunk of a rank's rows): smaller workgroups
+                    items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk, ipb,
+                                        row_ids=rows_c, colidx_dev=self.colidx)
                 self.class_rows.append((to_dev(rows_c), torch.from_numpy(items["slot_ptr"]).to(dev),
                                         torch.from_numpy(items["e0"]).to(dev), torch.from_numpy(items["len"]).to(dev),
-                                        torch.from_numpy(items["slot"]).to(dev), torch.from_numpy(items["row"]).to(dev)))
+                                        torch.from_numpy(items["slot"]).to(dev), torch.from_numpy(items["row"]).to(dev),
+                                        ipb))
                 max_slots = max(max_slots, int(items["slot_ptr"][-1]))
             else:
                 self.class_rows.append(None)
@@ -615,8 +625,8 @@ class SweepEngine:
                 k.edge_score(rp, self.colidx, b.nrows, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
                              self.k1_threshold, self.k1_long_rows[i], fuse_softmax=True)
                 if self.class_k1 and self.class_rows[i] is not None:
-                    rows_c, slot_ptr, it_e0, it_len, it_slot, it_row = self.class_rows[i]
-                    k.edge_score_class(rp, self.colidx, it_e0, it_len, it_slot, it_row, CLASS_ITEMS_PER_BLOCK, rows_c,
+                    rows_c, slot_ptr, it_e0, it_len, it_slot, it_row, ipb = self.class_rows[i]
+                    k.edge_score_class(rp, self.colidx, it_e0, it_len, it_slot, it_row, ipb, rows_c,
                                        slot_ptr, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
                                        self.slabs[i % len(self.slabs)], fuse_softmax=True)
         elif self.E_loc > 0:
@@ -626,9 +636,9 @@ class SweepEngine:
                     k.edge_score(self.rowptr[b.local_start:], self.colidx, b.nrows, b.row0, Z, self.d,
                                  _hip.SCORE_RAW_DOT, None, None, self.P, self.k1_threshold, self.k1_long_rows[i])
                     if self.class_k1 and self.class_rows[i] is not None:
-                        rows_c, slot_ptr, it_e0, it_len, it_slot, it_row = self.class_rows[i]
+                        rows_c, slot_ptr, it_e0, it_len, it_slot, it_row, ipb = self.class_rows[i]
                         k.edge_score_class(self.rowptr[b.local_start:], self.colidx, it_e0, it_len, it_slot, it_row,
-                                           CLASS_ITEMS_PER_BLOCK, rows_c, slot_ptr, b.row0, Z, self.d,
+                                           ipb, rows_c, slot_ptr, b.row0, Z, self.d,
                                            _hip.SCORE_RAW_DOT, None, None, self.P)
             else:
                 self.P.zero_()
@@ -678,9 +688,9 @@ class SweepEngine:
                     per_block.append(steps + [("event", i, e) for e in (4, 1, 2, 3)])
                     continue
                 if self.class_rows[i] is not None:
-                    rows_c, slot_ptr, it_e0, it_len, it_slot, _ = self.class_rows[i]
+                    rows_c, slot_ptr, it_e0, it_len, it_slot, _, ipb = self.class_rows[i]
                     steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
-                                                     CLASS_ITEMS_PER_BLOCK, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
+                                                     ipb, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
                                                      Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:],
                                                      mirror=mir)))
                 if self.split_rows[i] is not None:
@@ -848,7 +858,7 @@ class SweepEngine:
                 "hub_threshold": self.hub_threshold,
                 "split_edges": self.split_edges, "segment_edges": self.segment_edges,
                 "class_threshold": self.class_threshold, "class_chunk": self.class_chunk, "class_k1": self.class_k1,
-                "class_of_row": "(row / 8) % 8" if self.class_threshold else None,
+                "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 
     def exchange_bytes_per_sweep(self) -> int:

@@ -26,7 +26,7 @@ from typing import List
 
 import numpy as np
 
-from .partition import Block, HostCSR, LocalCSR
+from .partition import Block, HostCSR, LocalCSR, xcd_class
 
 
 @dataclass
@@ -61,7 +61,9 @@ class HaloLayout:
 
 
 def build_halo_layout(csr: HostCSR, world_size: int, rank: int, chunks: int = 4, shuffle: bool = True,
-                      seed: int = 0, hot_rows_first: bool = True) -> HaloLayout:
+                      seed: int = 0, hot_rows_first: bool = True, class_threshold: int = 0) -> HaloLayout:
+    """``class_threshold`` > 0: rows with more edges than that keep their edges sorted by (XCD class of the table
+    row, table row) instead of by table row (engine: class-affine rows)."""
     V, W = csr.num_vertices, world_size
     if W < 2 or not (0 <= rank < W) or chunks < 1:
         raise ValueError(f"halo layout needs world_size >= 2 (got {W}), 0 <= rank < W, chunks >= 1")
@@ -145,7 +147,11 @@ def build_halo_layout(csr: HostCSR, world_size: int, rank: int, chunks: int = 4,
     cols = table_index[csr.colidx[origin]]
     if cols.size and cols.min() < 0:
         raise AssertionError("a column read by this rank is missing from its table")
-    order = np.lexsort((cols, row_of))
+    if class_threshold > 0:
+        cls = np.where(deg[row_of] > class_threshold, xcd_class(cols), 0)
+        order = np.lexsort((cols, cls, row_of))
+    else:
+        order = np.lexsort((cols, row_of))
     cols, origin = cols[order], origin[order]
     indeg = np.where(valid, csr.indeg()[safe], 0).astype(np.int32)
     local = LocalCSR(rowptr, cols.astype(np.int32), indeg, verts, origin)

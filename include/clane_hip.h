@@ -253,8 +253,8 @@ int clane_edge_score_class_bf16(const int64_t *rowptr, const int32_t *colidx, co
 /*  clane_spmm_update_class_* : long rows whose gathers are kept XCD-affine (no reference counterpart: the reference's
  *                             loop is embedder.py:84-92 for every row alike).  MI355X has 8 XCDs with a private 4 MiB
  *                             L2 each and deals workgroups to them round-robin (workgroup w -> XCD w % 8).  The caller
- *                             gives every table row a CLASS 0..7 (the engine: (row / 8) % 8 -- not row % 8, which would
- *                             pin low address bits and use only part of an L2), sorts the edges of each listed row by
+ *                             gives every table row a CLASS 0..7 (the engine: an xor-fold of the row number's 3-bit groups -- not row % 8,
+ *                             which would pin low address bits and use only part of an L2), sorts the edges of each listed row by
  *                             (class of the column, column) and cuts every class segment
  *                             into ITEMS of a few hundred edges; item arrays are laid out in blocks of
  *                             `items_per_block` (4..64) items of ONE class, block j of class b at block index

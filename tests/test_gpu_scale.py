@@ -164,8 +164,8 @@ def test_k1_scores_at_scale(dev, k, d):
     raw = torch.full((eng.E_loc,), float("nan"), dtype=torch.float32, device=dev)
     k.edge_score(eng.rowptr, eng.colidx, eng.part.n_local, 0, eng.Zcur, eng.d, _hip.SCORE_RAW_DOT, None, None, raw,
                  eng.k1_threshold, eng.k1_long_rows[0])
-    rows_c, slot_ptr, it_e0, it_len, it_slot, it_row = eng.class_rows[0]         # ... and its class rows' work items
-    k.edge_score_class(eng.rowptr, eng.colidx, it_e0, it_len, it_slot, it_row, 32, rows_c, slot_ptr, 0, eng.Zcur, eng.d,
+    rows_c, slot_ptr, it_e0, it_len, it_slot, it_row, ipb = eng.class_rows[0]    # ... and its class rows' work items
+    k.edge_score_class(eng.rowptr, eng.colidx, it_e0, it_len, it_slot, it_row, ipb, rows_c, slot_ptr, 0, eng.Zcur, eng.d,
                        _hip.SCORE_RAW_DOT, None, None, raw)
     dots = torch.empty(E)
     dots[torch.from_numpy(eng.local.edge_origin)] = raw.cpu()

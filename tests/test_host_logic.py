@@ -356,8 +356,8 @@ def test_every_division_on_random_graphs():
 
         def run(rank):
             try:
-                # every other case of the non-halo divisions: rows above 3 edges take the XCD-affine class pass
-                ct = 3 if (case % 2 and not mode.startswith("halo")) else None
+                # every other case: rows above 3 edges take the XCD-affine class pass (any division)
+                ct = 3 if case % 2 else None
                 eng = SweepEngine(csr, X, "cpu", OracleKernels(), comm=shared.comm(rank), chunks=chunks, exchange=mode,
                                   seed=case, class_threshold=ct, class_chunk=64)
                 eng.build_P()

@@ -48,6 +48,7 @@ ap.add_argument("--natural-order", action="store_true")
 ap.add_argument("--no-split-hubs", action="store_true")
 ap.add_argument("--no-overlap", action="store_true")
 ap.add_argument("--no-fused-pack", action="store_true")
+ap.add_argument("--class-threshold", type=int, default=None, help="0 = no XCD-affine class pass")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
 gen, V, E, d, dname, gseed, xseed = bench.WORKLOADS[args.workload]
@@ -63,7 +64,7 @@ for W in args.world:
         del lays
     eng = SweepEngine(csr, X, dev, comm=comm, chunks=args.chunks, exchange=args.exchange,
                       hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs, overlap_chunks=not args.no_overlap,
-                      fused_pack=not args.no_fused_pack)
+                      fused_pack=not args.no_fused_pack, class_threshold=args.class_threshold)
     eng.build_P()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -78,7 +79,17 @@ for W in args.world:
         eng.sweep(0.76)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    print(json.dumps({"world": W, "exchange": args.exchange, "rank0_compute_ms_per_sweep": round(ms, 3),
+    eng.time_kernels = True
+    for _ in range(5):
+        eng.sweep(0.76)
+    torch.cuda.synchronize()
+    kt = {k: round(v, 3) for k, v in eng.kernel_times_ms().items()}
+    eng.time_kernels = False
+    n_class = sum(0 if c is None else c[0].numel() for c in eng.class_rows)
+    n_items = sum(0 if c is None else int((c[3] > 0).sum()) for c in eng.class_rows)
+    print(json.dumps({"world": W, "kernels_ms_summed_over_chunks": kt, "class_rows": n_class, "class_items": n_items,
+                      "thresholds": [eng.long_threshold, eng.class_threshold],
+                      "items_per_workgroup": [c[6] for c in eng.class_rows if c is not None][:1], "exchange": args.exchange, "rank0_compute_ms_per_sweep": round(ms, 3),
                       "rank0_build_P_ms_without_collectives": round(build_ms, 3),
                       "recv_MB_per_sweep": round(eng.exchange_bytes_per_sweep() / 1e6), "table_rows": eng.part.padded_vertices, "d_local": eng.d,
                       "n_local": eng.part.n_local, "E_loc": eng.E_loc, "hot_rows_first": not args.natural_order,
