@@ -388,3 +388,18 @@ def test_plugin_similarity_in_chunks_at_scale(dev):
     g.PLUGIN_SINGLE_CALL_MAX_BYTES = 1 << 20
     with pytest.raises(ValueError, match="batchwise = True"):
         g.build_P(lambda a, b: (a * b).sum(1))
+
+
+def test_loader_sorts_large_edge_lists_on_the_card():
+    """csr_from_edges with >= 2^20 edge lines takes the GPU for its one sort: same coalesced adjacency (sorted,
+    duplicates merged, self-loops kept: graph.py:104-110) as the oracle's numpy restatement."""
+    from clane_amd.graph import GPU_SORT_MIN_EDGES, csr_from_edges
+    rng = np.random.default_rng(3)
+    V, n = 300_000, 3_000_000
+    assert n >= GPU_SORT_MIN_EDGES
+    src, dst = rng.integers(0, V, n), rng.integers(0, V, n)
+    src[:1000], dst[:1000] = src[1000:2000], dst[1000:2000]          # duplicates
+    dst[2000:2100] = src[2000:2100]                                   # self-loops
+    got = csr_from_edges(V, src, dst)
+    rowptr, colidx = O.build_csr(V, src, dst)
+    assert np.array_equal(got.rowptr, rowptr) and np.array_equal(got.colidx, colidx) and got.num_edges < n
