@@ -27,6 +27,10 @@ ap.add_argument("--min-degree", type=int, nargs="+", default=[32, 128])
 ap.add_argument("--chunk", type=int, nargs="+", default=[64, 128, 256])
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--block-class", action="store_true", help="class = (row / 8) % 8 instead of row % 8")
+ap.add_argument("--phases", type=int, default=1,
+                help="P > 1: every class is split into P sub-classes (an xor-fold of higher position bits) and the chunk "
+                     "blocks are laid out phase-major: all chunks of sub-class 0 before those of sub-class 1, ... "
+                     "(XCD-affine in space AND phased in time, profiles/r02_gather_rows_ceiling.md)")
 ap.add_argument("--cols", type=int, default=None, help="use only the first COLS columns (a column slice)")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
@@ -84,36 +88,45 @@ for dmin in args.min_degree:
     idx = np.repeat(a - start, sizes) + np.arange(n_edges)
     cols = colidx[idx]
     rid = np.repeat(np.arange(n, dtype=np.int64), sizes)
-    cls = (cols >> 3) & 7 if args.block_class else cols % 8
-    order = np.lexsort((cols, cls, rid))
-    cols, idx, rid, cls = cols[order], idx[order], rid[order], cls[order]
+    from clane_amd.partition import xcd_class
+    cls = xcd_class(cols) if not args.block_class else (cols >> 3) & 7
+    NP = args.phases
+    phase = ((cols >> 12) ^ (cols >> 14) ^ (cols >> 16)) % NP if NP > 1 else np.zeros_like(cols)
+    sub = phase * 8 + cls                                              # 8 * NP sub-classes; XCD = sub % 8
+    order = np.lexsort((cols, sub, rid))
+    cols, idx, rid, cls, sub = cols[order], idx[order], rid[order], cls[order], sub[order]
     Pv = P[torch.from_numpy(idx).to(dev)]
-    seg_key = rid * 8 + cls
-    seg_len = np.bincount(seg_key, minlength=n * 8)
+    NS = 8 * NP
+    seg_key = rid * NS + sub
+    seg_len = np.bincount(seg_key, minlength=n * NS)
     seg_start = np.concatenate([[0], np.cumsum(seg_len)[:-1]])
     for C in args.chunk:
         nchunk = -(-seg_len // C)                                   # chunks per (row, class) segment
         tot = int(nchunk.sum())
-        seg_of = np.repeat(np.arange(n * 8), nchunk)
+        seg_of = np.repeat(np.arange(n * NS), nchunk)
         within = np.arange(tot) - np.repeat(np.concatenate([[0], np.cumsum(nchunk)[:-1]]), nchunk)
         c_e0 = seg_start[seg_of] + within * C
         c_e1 = np.minimum(c_e0 + C, seg_start[seg_of] + seg_len[seg_of])
-        c_cls = seg_of % 8
-        # blocks of rpb chunks of one class; block j of class b -> workgroup 8 j + b
-        per_class = [np.nonzero(c_cls == b)[0] for b in range(8)]
+        c_sub = seg_of % NS
+        # blocks of rpb chunks of one sub-class; phase-major: for every phase, block j of class b -> workgroup 8 j + b
+        per_sub = [np.nonzero(c_sub == q)[0] for q in range(NS)]
         rpb = rows_per_block(tot)
-        for _ in range(3):                                          # fixed point: padding changes the row count
-            J = max(-(-len(pc) // rpb) for pc in per_class)
-            rpb_new = rows_per_block(8 * J * rpb)
+        for _ in range(4):                                          # fixed point: padding changes the row count
+            Jp = [max(-(-len(per_sub[ph * 8 + b]) // rpb) for b in range(8)) for ph in range(NP)]
+            rpb_new = rows_per_block(8 * sum(Jp) * rpb)
             if rpb_new == rpb:
                 break
             rpb = rpb_new
-        nv = 8 * J * rpb
+        nv = 8 * sum(Jp) * rpb
         v_e0 = np.zeros(nv, dtype=np.int64)
         v_e1 = np.zeros(nv, dtype=np.int64)
-        for b, pc in enumerate(per_class):
-            slots = (np.arange(len(pc)) // rpb) * 8 * rpb + b * rpb + np.arange(len(pc)) % rpb
-            v_e0[slots], v_e1[slots] = c_e0[pc], c_e1[pc]
+        base = 0
+        for ph in range(NP):
+            for b in range(8):
+                pc = per_sub[ph * 8 + b]
+                slots = base + (np.arange(len(pc)) // rpb) * 8 * rpb + b * rpb + np.arange(len(pc)) % rpb
+                v_e0[slots], v_e1[slots] = c_e0[pc], c_e1[pc]
+            base += 8 * Jp[ph] * rpb
         assert rows_per_block(nv) == rpb, (nv, rpb)
 
         def virtual_csr(e0, e1):
@@ -126,7 +139,7 @@ for dmin in args.min_degree:
         Xv = torch.zeros(nv, eng.ld, dtype=Zold.dtype, device=dev)
         Znv = torch.zeros(nv, eng.ld, dtype=Zold.dtype, device=dev)
         pv = torch.zeros(k.spmm_partials_len(nv, 0), dtype=torch.float64, device=dev)
-        extra = {"min_degree": dmin, "chunk": C, "virtual_rows": tot, "padded": nv, "rows_per_block": rpb,
+        extra = {"min_degree": dmin, "chunk": C, "phases": NP, "virtual_rows": tot, "padded": nv, "rows_per_block": rpb,
                  "slab_GB_write_plus_read": round(2 * tot * d * 4 / 1e9, 2)}
         rp_v, ci_v, P_v = virtual_csr(v_e0, v_e1)
         # Z_old rows are read at [row0 + r]: virtual rows have no Z_old row of their own -> row0 = 0 reads rows 0..nv
