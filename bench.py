@@ -71,7 +71,7 @@ def launch_ranks(n: int) -> int:
 
 def oracle_first_sweep(csr, X, P_host, gamma):
     """The C oracle's first sweep from Z = X (oracle/clane_oracle.c); P from the GPU when given, else the oracle's
-    own build_P (graph.py:118-128).  Returns (Z1, seconds of the sweep, threads)."""
+    own build_P (graph.py:118-128).  Returns (Z1, seconds of the sweep, threads, the P used, X as fp32)."""
     from oracle import clane_oracle_c as OC
     Xf = X.float() if X.dtype != torch.float32 else X    # the oracle computes in fp32 on the (bf16-)rounded inputs
     if P_host is None:
