@@ -283,6 +283,59 @@ def test_k3_and_k1_random_shapes(dev, k):
         assert float(out) == pytest.approx(want, rel=1e-6, abs=1e-12), tag
 
 
+def test_class_pass_random_engines(dev):
+    """48 seeded random graphs through the WHOLE engine with tiny class thresholds, so that most rows take the
+    XCD-affine pass (K1 and K3): V from 1 to 900, d from 1 to 300, fp32 / fp64 / bf16, 1 or 3 launch blocks, natural or
+    hot-first order, rows whose edges all fall into one class, dense rows, empty rows -- build_P (reference and
+    per-edge) and three sweeps against the oracle."""
+    rng = np.random.default_rng(77)
+    for case in range(48):
+        dtype = [torch.float32, torch.float64, torch.bfloat16][case % 3]
+        V = int(rng.choice([1, 2, 7, 8, 9, 33, 64, 100, 257, 900]))
+        d = int(rng.choice([1, 2, 4, 8, 16, 24, 64, 100, 128, 256, 300]))
+        deg = rng.integers(0, min(V, 12) + 1, size=V)
+        deg[rng.random(V) < 0.2] = 0
+        for h in rng.integers(1, V + 1, size=3):
+            deg[int(rng.integers(V))] = int(h)
+        cols = []
+        for r, kdeg in enumerate(deg):
+            if case % 8 == 5 and kdeg and V >= 64:          # every neighbour in ONE 8-row block of the table order
+                pool = np.arange(0, V, 1)
+                c = np.sort(rng.choice(pool[pool % 64 < 8], size=min(kdeg, int((pool % 64 < 8).sum())), replace=False))
+                deg[r] = c.size
+            else:
+                c = np.sort(rng.choice(V, size=kdeg, replace=False))
+            cols.append(c)
+        rowptr = np.zeros(V + 1, dtype=np.int64)
+        np.cumsum(deg, out=rowptr[1:])
+        csr = HostCSR(V, rowptr, np.concatenate(cols + [np.empty(0, int)]).astype(np.int32))
+        acc = _hip.acc_dtype(dtype)
+        X = synth.gaussian_X(V, d, seed=case).to(dtype)
+        ct, chunk = int(rng.choice([1, 2, 5, 8])), int(rng.choice([64, 128, 256]))
+        mode = "per_edge" if case % 2 else "reference"
+        eng = SweepEngine(csr, X, dev, chunks=1 if case % 4 else 3, hot_rows_first=bool(case % 3), cosine_mode=mode,
+                          class_threshold=ct, class_chunk=chunk)
+        tag = f"case {case}: V={V} d={d} {dtype} class_threshold={ct} chunk={chunk} E={csr.num_edges} {mode}"
+        assert sum(0 if c is None else c[0].numel() for c in eng.class_rows) == int((deg > ct).sum()), tag
+        Xf = X.to(acc).double()
+        if csr.num_edges == 0:
+            continue
+        eng.build_P()
+        P_or = O.build_P_values(csr.rowptr, csr.colidx, Xf, mode=mode)
+        tol_p = 1e-12 if dtype == torch.float64 else 2e-5 if dtype == torch.bfloat16 else 5e-6
+        assert rel(eng.P_global(), P_or) < tol_p, tag
+        Z, P_used = Xf.clone(), eng.P_global().double()
+        for _ in range(3):
+            delta = eng.sweep(0.6)
+            Z_next, d_or = O.sweep(csr.rowptr, csr.colidx, P_used, Xf, Z, 0.6)
+            got = eng.get_Z().double()
+            assert rel(got, Z_next) < TOL[dtype], tag
+            assert delta == pytest.approx(float((got - Z).abs().sum()), rel=1e-5 if dtype != torch.bfloat16 else 2e-2,
+                                          abs=1e-9), tag
+            Z = got                                  # follow the GPU's (bf16-rounded) trajectory
+        del eng
+
+
 def test_spmm_row_block_with_row0_offset(dev, k):
     """A rank's row block: local rowptr/X/Z_new, global columns, row0 != 0."""
     csr = ragged_csr(400, seed=9, hubs=(300,))
