@@ -32,7 +32,9 @@ import torch
 from . import _hip
 from .comm import TorchComm
 from .halo import build_halo_layout
-from .partition import XCD_CLASSES, Block, HostCSR, LocalCSR, RowPartition, localize, xcd_class
+from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
+from .xcd import (CLASS_CHUNK, CLASS_ITEMS_PER_BLOCK, CLASS_THRESHOLD_BY_ROWS_PER_WAVE, class_items,
+                  items_per_block_for)
 
 # Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md, r02_class_threshold_sweep.md):
 #   deg <= T                 one (sub-)wave per row, rows claimed dynamically inside a workgroup
@@ -57,20 +59,6 @@ HUB_FACTOR = 1
 SPLIT_EDGES = 4096
 MIN_SEGMENT_EDGES = 1024
 TARGET_SEGMENTS = 512                   # two workgroups per CU
-# Rows above CLASS_THRESHOLD edges are gathered XCD-affine (csrc/spmm_update.h, spmm_class_chunk_kernel): their edges
-# are sorted by (class of the column, column) -- partition.xcd_class --, cut into chunks of at most CLASS_CHUNK edges
-# of one class, and the chunks of class b run on the workgroups 8 j + b = XCD b, so each XCD's 4 MiB L2 caches its own
-# eighth of the hot rows instead of all eight caching the same ones.  Costs one partial sum (d accumulators, written +
-# read once) per chunk, which is why short rows stay with the row kernels.  Threshold by rows per wave-instruction,
-# 0 = off; measured (profiles/r02_class_threshold_sweep.md), sweep ms without -> with: config 3 (1-KiB rows)
-# 5.36 -> 4.36 at 64; its column slices: 512-B rows 2.55 -> 1.99 at 64, 256-B rows 1.26 -> 1.04 at 128..256, 128-B rows
-# 0.716 -> 0.632 at 256; config 4's shape (bf16, 256-B rows) 8.24 -> 7.44 at 256; config 2 (Z fits the Infinity Cache)
-# 0.257 -> 0.249.  build_P scores these rows over the same chunks (class_k1: 5.7 -> 4.7 ms at config 3).
-CLASS_THRESHOLD_BY_ROWS_PER_WAVE = {1: 64, 2: 64, 4: 256, 8: 256}
-CLASS_CHUNK = 256
-CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
-
-
 def lanes_per_row(d: int, dtype: torch.dtype) -> int:
     """Lanes that cover one row with 16-byte packs (mirrors pick_layout in csrc/clane_abi.hip)."""
     packs = -(-d // _hip.VEC_ELEMS[dtype])
@@ -101,68 +89,6 @@ def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
     p0 = rank * base + min(rank, rem)
     p1 = p0 + base + (1 if rank < rem else 0)
     return min(d, p0 * vec), min(d, p1 * vec)
-
-
-def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int,
-                row_ids: Optional[np.ndarray] = None, colidx_dev: Optional[torch.Tensor] = None) -> dict:
-    """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
-    (xcd_class(column), column)): every class segment of a row is cut into chunks of at most `chunk` edges.
-    Slots -- where the partial sums go -- are numbered row by row, class by class, chunk by chunk, so a row's slots
-    are contiguous (`slot_ptr`) and summed in that order.  Items are laid out for the kernel: blocks of
-    `items_per_block` items of ONE class, block j of class b at block index 8 j + b, padded with empty items
-    (len 0, slot -1).  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
-    item's row, default `rows` itself) and int64 slot_ptr [rows + 1]."""
-    n = rows.size
-    sizes = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
-    start = np.concatenate([[0], np.cumsum(sizes)[:-1]])
-    if colidx_dev is not None and colidx_dev.is_cuda:        # the O(E) part on the card (40M edges: 0.3 s on the host)
-        dev = colidx_dev.device
-        sizes_t = torch.from_numpy(sizes).to(dev)
-        rid = torch.repeat_interleave(torch.arange(n, device=dev), sizes_t)
-        idx = torch.from_numpy(rowptr[rows] - start).to(dev)[rid] + torch.arange(int(sizes.sum()), device=dev)
-        key = rid * XCD_CLASSES + xcd_class(colidx_dev[idx].long())
-        unsorted = bool((key[1:] < key[:-1]).any()) if key.numel() > 1 else False
-        seg_len = torch.bincount(key, minlength=n * XCD_CLASSES).cpu().numpy()
-    else:
-        idx = np.repeat(rowptr[rows] - start, sizes) + np.arange(int(sizes.sum()), dtype=np.int64)
-        cls = xcd_class(colidx[idx].astype(np.int64))
-        rid = np.repeat(np.arange(n, dtype=np.int64), sizes)
-        unsorted = idx.size > 1 and bool((np.diff(rid * XCD_CLASSES + cls) < 0).any())
-        seg_len = np.bincount(rid * XCD_CLASSES + cls, minlength=n * XCD_CLASSES)
-    if unsorted:
-        raise AssertionError("class rows must have their edges sorted by (xcd_class(column), column)")
-    seg_e0 = np.repeat(rowptr[rows], XCD_CLASSES) + (np.cumsum(seg_len) - seg_len
-                                                      - np.repeat(start, XCD_CLASSES))
-    nchunk = -(-seg_len // chunk)
-    tot = int(nchunk.sum())
-    seg_of = np.repeat(np.arange(n * XCD_CLASSES), nchunk)
-    within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
-    e0 = seg_e0[seg_of] + within * chunk
-    ln = np.minimum(chunk, seg_len[seg_of] - within * chunk)
-    slot_ptr = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(nchunk.reshape(n, XCD_CLASSES).sum(1), out=slot_ptr[1:])
-    item_cls = seg_of % XCD_CLASSES
-    per_class = [np.nonzero(item_cls == c)[0] for c in range(XCD_CLASSES)]
-    nblk = max(1, max(-(-len(pc) // items_per_block) for pc in per_class))
-    flat = XCD_CLASSES * nblk * items_per_block
-    out_e0 = np.zeros(flat, dtype=np.int64)
-    out_len = np.zeros(flat, dtype=np.int32)
-    out_slot = np.full(flat, -1, dtype=np.int32)
-    out_row = np.zeros(flat, dtype=np.int32)
-    ids = (rows if row_ids is None else row_ids).astype(np.int32)
-    item_row = ids[seg_of // XCD_CLASSES]
-    for c, pc in enumerate(per_class):
-        t = np.arange(len(pc))
-        where = (t // items_per_block) * (XCD_CLASSES * items_per_block) + c * items_per_block + t % items_per_block
-        out_e0[where], out_len[where], out_slot[where], out_row[where] = e0[pc], ln[pc], pc, item_row[pc]
-    return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "slot_ptr": slot_ptr}
-
-
-def items_per_block_for(n_items: int) -> int:
-    """Chunks per workgroup of the class kernels: CLASS_ITEMS_PER_BLOCK when there are plenty, fewer (down to one per
-    wave) when a launch holds few chunks -- a launch wants >= ~4096 workgroups to fill 256 CUs (a rank's quarter of
-    the halo split at 8 GPUs holds 21k chunks: 650 workgroups of 32 ran at a third of the rate of 2 600 of 8)."""
-    return int(min(CLASS_ITEMS_PER_BLOCK, max(4, 4 * -(-n_items // (4 * 4096)))))
 
 
 class StagedZ:

@@ -26,7 +26,8 @@ from typing import List
 
 import numpy as np
 
-from .partition import Block, HostCSR, LocalCSR, xcd_class
+from .partition import Block, HostCSR, LocalCSR
+from .xcd import xcd_class
 
 
 @dataclass

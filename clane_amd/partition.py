@@ -30,6 +30,8 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
+from .xcd import XCD_CLASSES, xcd_class
+
 
 @dataclass
 class HostCSR:
@@ -174,22 +176,6 @@ class LocalCSR:
     indeg: np.ndarray           # int32 [n_local]  global in-degree of the vertex in each local row
     vertex: np.ndarray          # int64 [n_local]  vertex id of each local row, -1 for padding rows
     edge_origin: np.ndarray     # int64 [E_local]  index of each local edge in the global CSR order
-
-
-XCD_CLASSES = 8          # MI355X: 8 XCDs, one private L2 each
-
-
-def xcd_class(position):
-    """XCD class (0..7) of the table row at `position` (numpy array, torch tensor or int): an xor-fold of the
-    position's 3-bit groups.  Two things matter.  (1) NOT position % 8: that pins three low address bits of every
-    row an XCD gathers, and only part of its L2's channels / sets get used -- measured on the pure gather
-    (profiles/r02_gather_rows_ceiling.md): 128-byte rows 13.4 TB/s with % 8, 19.4 TB/s with this; 256-byte rows
-    17.1 -> 19.5; 1-KiB rows the same.  (2) Heat must be dealt evenly whatever the layout: 8 consecutive rows go to 8
-    different classes, so the hottest rows of every sorted run of a table (hot-rows-first Z, but also each
-    (chunk, source rank) list of a halo table) are spread over all XCDs.  ((position / 8) % 8 is as fast on the
-    hot-first layout and 40 % slower on a halo table, whose runs each start with their 8 hottest rows.)"""
-    p = position
-    return (p ^ (p >> 3) ^ (p >> 6) ^ (p >> 9)) & (XCD_CLASSES - 1)
 
 
 def edge_order(row_of, cols, cls, table_rows: int, two_pass: Optional[bool] = None):

@@ -1,0 +1,108 @@
+"""XCD affinity -- host side of the class-affine row kernels (csrc/spmm_update.h, csrc/edge_score.h).
+
+MI355X has 8 XCDs with a private 4 MiB L2 each and deals the workgroups of a launch to them round-robin (workgroup w
+runs on XCD w % 8; tools/xcc_map.hip).  When any workgroup may gather any row of Z, all eight L2s cache the same few
+thousand hottest rows.  The class-affine kernels keep every gathered row on ONE XCD instead: each table row gets a
+class 0..7 (`xcd_class`), the edges of a long row are sorted by (class of the column, column) -- `partition.localize`,
+`halo.build_halo_layout` -- and cut into work items of one class (`class_items`), laid out so that the items of
+class b run on the workgroups 8 j + b.  No counterpart in the reference (its loop is embedder.py:84-92 for every row
+alike); measurements in profiles/r02_gather_rows_ceiling.md and r02_class_threshold_sweep.md.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+XCD_CLASSES = 8          # MI355X: 8 XCDs, one private L2 each
+
+
+def xcd_class(position):
+    """XCD class (0..7) of the table row at `position` (numpy array, torch tensor or int): an xor-fold of the
+    position's 3-bit groups.  Two things matter.  (1) NOT position % 8: that pins three low address bits of every
+    row an XCD gathers, and only part of its L2's channels / sets get used -- measured on the pure gather
+    (profiles/r02_gather_rows_ceiling.md): 128-byte rows 13.4 TB/s with % 8, 19.4 TB/s with this; 256-byte rows
+    17.1 -> 19.5; 1-KiB rows the same.  (2) Heat must be dealt evenly whatever the layout: 8 consecutive rows go to 8
+    different classes, so the hottest rows of every sorted run of a table (hot-rows-first Z, but also each
+    (chunk, source rank) list of a halo table) are spread over all XCDs.  ((position / 8) % 8 is as fast on the
+    hot-first layout and 40 % slower on a halo table, whose runs each start with their 8 hottest rows.)"""
+    p = position
+    return (p ^ (p >> 3) ^ (p >> 6) ^ (p >> 9)) & (XCD_CLASSES - 1)
+
+
+# Rows above CLASS_THRESHOLD edges are gathered XCD-affine (csrc/spmm_update.h, spmm_class_chunk_kernel): their edges
+# are sorted by (class of the column, column) -- xcd_class above --, cut into chunks of at most CLASS_CHUNK edges
+# of one class, and the chunks of class b run on the workgroups 8 j + b = XCD b, so each XCD's 4 MiB L2 caches its own
+# eighth of the hot rows instead of all eight caching the same ones.  Costs one partial sum (d accumulators, written +
+# read once) per chunk, which is why short rows stay with the row kernels.  Threshold by rows per wave-instruction,
+# 0 = off; measured (profiles/r02_class_threshold_sweep.md), sweep ms without -> with: config 3 (1-KiB rows)
+# 5.36 -> 4.36 at 64; its column slices: 512-B rows 2.55 -> 1.99 at 64, 256-B rows 1.26 -> 1.04 at 128..256, 128-B rows
+# 0.716 -> 0.632 at 256; config 4's shape (bf16, 256-B rows) 8.24 -> 7.44 at 256; config 2 (Z fits the Infinity Cache)
+# 0.257 -> 0.249.  build_P scores these rows over the same chunks (class_k1: 5.7 -> 4.7 ms at config 3).
+CLASS_THRESHOLD_BY_ROWS_PER_WAVE = {1: 64, 2: 64, 4: 256, 8: 256}
+CLASS_CHUNK = 256
+CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
+
+
+
+def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int,
+                row_ids: Optional[np.ndarray] = None, colidx_dev: Optional[torch.Tensor] = None) -> dict:
+    """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
+    (xcd_class(column), column)): every class segment of a row is cut into chunks of at most `chunk` edges.
+    Slots -- where the partial sums go -- are numbered row by row, class by class, chunk by chunk, so a row's slots
+    are contiguous (`slot_ptr`) and summed in that order.  Items are laid out for the kernel: blocks of
+    `items_per_block` items of ONE class, block j of class b at block index 8 j + b, padded with empty items
+    (len 0, slot -1).  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
+    item's row, default `rows` itself) and int64 slot_ptr [rows + 1]."""
+    n = rows.size
+    sizes = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    if colidx_dev is not None and colidx_dev.is_cuda:        # the O(E) part on the card (40M edges: 0.3 s on the host)
+        dev = colidx_dev.device
+        sizes_t = torch.from_numpy(sizes).to(dev)
+        rid = torch.repeat_interleave(torch.arange(n, device=dev), sizes_t)
+        idx = torch.from_numpy(rowptr[rows] - start).to(dev)[rid] + torch.arange(int(sizes.sum()), device=dev)
+        key = rid * XCD_CLASSES + xcd_class(colidx_dev[idx].long())
+        unsorted = bool((key[1:] < key[:-1]).any()) if key.numel() > 1 else False
+        seg_len = torch.bincount(key, minlength=n * XCD_CLASSES).cpu().numpy()
+    else:
+        idx = np.repeat(rowptr[rows] - start, sizes) + np.arange(int(sizes.sum()), dtype=np.int64)
+        cls = xcd_class(colidx[idx].astype(np.int64))
+        rid = np.repeat(np.arange(n, dtype=np.int64), sizes)
+        unsorted = idx.size > 1 and bool((np.diff(rid * XCD_CLASSES + cls) < 0).any())
+        seg_len = np.bincount(rid * XCD_CLASSES + cls, minlength=n * XCD_CLASSES)
+    if unsorted:
+        raise AssertionError("class rows must have their edges sorted by (xcd_class(column), column)")
+    seg_e0 = np.repeat(rowptr[rows], XCD_CLASSES) + (np.cumsum(seg_len) - seg_len
+                                                      - np.repeat(start, XCD_CLASSES))
+    nchunk = -(-seg_len // chunk)
+    tot = int(nchunk.sum())
+    seg_of = np.repeat(np.arange(n * XCD_CLASSES), nchunk)
+    within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
+    e0 = seg_e0[seg_of] + within * chunk
+    ln = np.minimum(chunk, seg_len[seg_of] - within * chunk)
+    slot_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(nchunk.reshape(n, XCD_CLASSES).sum(1), out=slot_ptr[1:])
+    item_cls = seg_of % XCD_CLASSES
+    per_class = [np.nonzero(item_cls == c)[0] for c in range(XCD_CLASSES)]
+    nblk = max(1, max(-(-len(pc) // items_per_block) for pc in per_class))
+    flat = XCD_CLASSES * nblk * items_per_block
+    out_e0 = np.zeros(flat, dtype=np.int64)
+    out_len = np.zeros(flat, dtype=np.int32)
+    out_slot = np.full(flat, -1, dtype=np.int32)
+    out_row = np.zeros(flat, dtype=np.int32)
+    ids = (rows if row_ids is None else row_ids).astype(np.int32)
+    item_row = ids[seg_of // XCD_CLASSES]
+    for c, pc in enumerate(per_class):
+        t = np.arange(len(pc))
+        where = (t // items_per_block) * (XCD_CLASSES * items_per_block) + c * items_per_block + t % items_per_block
+        out_e0[where], out_len[where], out_slot[where], out_row[where] = e0[pc], ln[pc], pc, item_row[pc]
+    return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "slot_ptr": slot_ptr}
+
+
+def items_per_block_for(n_items: int) -> int:
+    """Chunks per workgroup of the class kernels: CLASS_ITEMS_PER_BLOCK when there are plenty, fewer (down to one per
+    wave) when a launch holds few chunks -- a launch wants >= ~4096 workgroups to fill 256 CUs (a rank's quarter of
+    the halo split at 8 GPUs holds 21k chunks: 650 workgroups of 32 ran at a third of the rate of 2 600 of 8)."""
+    return int(min(CLASS_ITEMS_PER_BLOCK, max(4, 4 * -(-n_items // (4 * 4096)))))

@@ -8,7 +8,7 @@ substitutes it: ``SweepEngine`` only gets it when a test passes it in explicitly
 import numpy as np
 import torch
 
-from clane_amd.partition import xcd_class
+from clane_amd.xcd import xcd_class
 from oracle import clane_oracle as O
 
 

@@ -751,8 +751,8 @@ def test_spmm_class_affine_rows(dev, k, dtype, d, pad, chunk):
     class, chunk blocks of class b at block index 8 j + b, partial sums added per row in slot order == the oracle,
     == the one-workgroup-per-row kernel up to summation order; only the listed rows are written; two launches are
     bitwise equal; the mirror gets the finished rows."""
-    from clane_amd.engine import class_items
-    from clane_amd.partition import xcd_class
+    from clane_amd.xcd import class_items
+    from clane_amd.xcd import xcd_class
     csr0 = ragged_csr(900, seed=3, hubs=(700, 129, 64, 900, 385, 65))
     V, acc, gamma = csr0.num_vertices, _hip.acc_dtype(dtype), 0.76
     deg = np.diff(csr0.rowptr)
@@ -823,8 +823,8 @@ def test_edge_score_class_affine_rows(dev, k, dtype, d, pad):
     """clane_edge_score_class_*: K1 over the class rows' work items (chunks of one XCD class per wave): raw dots,
     reference-mode and per-edge scores == the row kernels' bit for bit (the same exchange tree per edge); with the
     fused softmax every listed row == the oracle's P and == K1 raw + K2; other rows are not written."""
-    from clane_amd.engine import class_items
-    from clane_amd.partition import xcd_class
+    from clane_amd.xcd import class_items
+    from clane_amd.xcd import xcd_class
     csr0 = ragged_csr(900, seed=3, hubs=(700, 129, 64, 900, 385, 65))
     V, acc = csr0.num_vertices, _hip.acc_dtype(dtype)
     deg = np.diff(csr0.rowptr)

@@ -13,7 +13,8 @@ from clane_amd import _hip
 from clane_amd.embedder import Embedder, IterativeEmbedder
 from clane_amd.engine import SweepEngine
 from clane_amd.graph import Graph
-from clane_amd.partition import HostCSR, RowPartition, localize, xcd_class
+from clane_amd.partition import HostCSR, RowPartition, localize
+from clane_amd.xcd import xcd_class
 from clane_amd.similarity import AsymmertricSimilarity, CosineSimilarity, Similarity
 from oracle import clane_oracle as O
 
@@ -644,7 +645,7 @@ def test_class_affine_rows_layout_and_result(chunks, hot):
     """Rows above `class_threshold` edges: edges sorted by (XCD class of the column, column), cut into chunks of one class, chunk
     blocks of class b at block index 8 j + b (the test double asserts that contract), slots contiguous per row --
     and the sweep equals the oracle's whatever the thresholds."""
-    from clane_amd.engine import class_items
+    from clane_amd.xcd import class_items
     rng = np.random.default_rng(5)
     V, d = 700, 12
     deg = rng.integers(0, 9, size=V)

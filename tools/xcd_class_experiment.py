@@ -88,7 +88,7 @@ for dmin in args.min_degree:
     idx = np.repeat(a - start, sizes) + np.arange(n_edges)
     cols = colidx[idx]
     rid = np.repeat(np.arange(n, dtype=np.int64), sizes)
-    from clane_amd.partition import xcd_class
+    from clane_amd.xcd import xcd_class
     cls = xcd_class(cols) if not args.block_class else (cols >> 3) & 7
     NP = args.phases
     phase = ((cols >> 12) ^ (cols >> 14) ^ (cols >> 16)) % NP if NP > 1 else np.zeros_like(cols)
