@@ -4,6 +4,9 @@
 // best -- and what XCD-AFFINE reads would add: workgroup i runs on XCD i % 8 (round-robin dispatch), so if it only
 // reads rows r with r % 8 == i % 8, each XCD's 4 MiB L2 caches a DIFFERENT eighth of the hot rows (32 MiB of
 // distinct hot rows on the chip instead of 8 copies of the same 4 MiB).
+// Also in one run: three ways of forming the classes (row % 8 pins address bits and wastes L2), the cache-policy bits
+// of the cold rows' loads, and reads that are XCD-affine in space AND phased in time.  Results: profiles/
+// r02_gather_rows_ceiling.md.
 //   hipcc --offload-arch=gfx950 -O3 -o build/gather_rows_ceiling tools/gather_rows_ceiling.hip
 #include <hip/hip_runtime.h>
 
@@ -108,7 +111,7 @@ static inline int cls_of(int r) {
 
 int run_all();
 int main() {
-    for (g_class_mode = 2; g_class_mode < 3; ++g_class_mode) {
+    for (g_class_mode = 0; g_class_mode < 3; ++g_class_mode) {
         printf("== class of a row: %s\n", g_class_mode == 0 ? "r % 8" : g_class_mode == 1 ? "xor-fold(r) % 8" : "(r / 8) % 8");
         run_all();
     }
@@ -199,7 +202,7 @@ int run_all() {
     int *idx_pure;
     CK(hipMalloc(&idx_pure, pure.size() * sizeof(int)));
     CK(hipMemcpy(idx_pure, pure.data(), pure.size() * sizeof(int), hipMemcpyHostToDevice));
-    for (int pol = 0; pol <= 0; ++pol) {
+    for (int pol = 0; pol <= (g_class_mode == 1 ? 6 : -1); ++pol) {   // cache-policy table: once, with the adopted class
         const int nt = pol == 0 ? -1 : H;
         const long np = (long)pure.size(), ng = np / 64;
         const int grid = 8192;
@@ -213,6 +216,7 @@ int run_all() {
     // reads of sub-class 0 come before those of sub-class 1, ...: at any moment an XCD's hot working set is 1/P of its
     // class (1-KiB rows: the 4096 hottest rows of a class are the WHOLE 4 MiB L2 -- with P = 2 they are half of it).
     for (int P : {1, 2, 4, 8}) {
+        if (g_class_mode != 1) break;                                // phased table: once, with the adopted class
         std::vector<std::vector<int>> lists(8 * P);
         for (int b = 0; b < 8; ++b)
             for (size_t i = 0; i < per; ++i) lists[((by[b][i] >> 6) % P) * 8 + b].push_back(by[b][i]);
