@@ -33,8 +33,8 @@ from . import _hip
 from .comm import TorchComm
 from .halo import build_halo_layout
 from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
-from .xcd import (CLASS_CHUNK, CLASS_ITEMS_PER_BLOCK, CLASS_THRESHOLD_BY_ROWS_PER_WAVE, class_items,
-                  items_per_block_for)
+from .xcd import (CLASS_CHUNK, CLASS_ITEMS_PER_BLOCK, CLASS_THRESHOLD_BY_ROWS_PER_WAVE, PHASE_THRESHOLD,
+                  PHASES_BY_ROWS_PER_WAVE, class_items, items_per_block_for)
 
 # Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md, r02_class_threshold_sweep.md):
 #   deg <= T                 one (sub-)wave per row, rows claimed dynamically inside a workgroup
@@ -119,7 +119,8 @@ class SweepEngine:
                  hub_threshold: Optional[int] = None, shuffle: Optional[bool] = None, seed: int = 0,
                  exchange: str = "auto", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
-                 class_chunk: int = CLASS_CHUNK, class_k1: bool = True):
+                 class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
+                 phase_threshold: int = PHASE_THRESHOLD):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
@@ -176,6 +177,13 @@ class SweepEngine:
         self.class_threshold = int(class_threshold)
         self.class_chunk = int(class_chunk)
         self.class_k1 = bool(class_k1) and self.class_threshold > 0    # build_P scores the class rows XCD-affine too
+        # heavy class rows are also phased in time (xcd.py): phases 1 = off
+        self.class_phases = int(PHASES_BY_ROWS_PER_WAVE[rows_per_wave] if class_phases is None else class_phases)
+        if self.class_threshold == 0 or self.class_phases < 1:
+            self.class_phases = 1
+        if self.class_phases & (self.class_phases - 1) or self.class_phases > 8:
+            raise ValueError("class_phases must be 1, 2, 4 or 8")
+        self.phase_threshold = max(int(phase_threshold), self.class_threshold) if self.class_phases > 1 else 0
         if self.class_threshold and not (64 <= self.class_chunk <= 4096 and self.class_chunk % 64 == 0):
             raise ValueError("class_chunk must be a multiple of 64 in [64, 4096]")
         self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
@@ -183,7 +191,8 @@ class SweepEngine:
             raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
         if self.halo:
             self.part = build_halo_layout(csr, self.world, rank, chunks, shuffle=shuffle is not False, seed=seed,
-                                          hot_rows_first=hot_rows_first, class_threshold=self.class_threshold)
+                                          hot_rows_first=hot_rows_first, class_threshold=self.class_threshold,
+                                          phase_threshold=self.phase_threshold, phases=self.class_phases)
             self.blocks: List[Block] = self.part.blocks
             self.local: LocalCSR = self.part.local
         else:
@@ -193,7 +202,8 @@ class SweepEngine:
             self.part = RowPartition.create(self.V, row_world, row_rank, chunks, live_mask=live, shuffle=shuffle,
                                             seed=seed, priority=hot)
             self.blocks = self.part.blocks(spans_for_one_rank=self._forced and not self.columns)
-            self.local = localize(csr, self.part, self.device, class_threshold=self.class_threshold)
+            self.local = localize(csr, self.part, self.device, class_threshold=self.class_threshold,
+                                  phase_threshold=self.phase_threshold, phases=self.class_phases)
         if self.part.padded_vertices >= 2 ** 31:
             raise ValueError(f"{self.part.padded_vertices} table rows: column indices are 32-bit (ABI v1); divide the "
                              "rows over more GPUs (exchange='halo') or wait for 64-bit indices")
@@ -257,12 +267,13 @@ class SweepEngine:
             rows_c = np.nonzero(is_class)[0]
             if rows_c.size:
                 rows_abs = rows_c + b.local_start
+                phased = dict(phase_threshold=self.phase_threshold, phases=self.class_phases)
                 items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk,
-                                    CLASS_ITEMS_PER_BLOCK, row_ids=rows_c, colidx_dev=self.colidx)
+                                    CLASS_ITEMS_PER_BLOCK, row_ids=rows_c, colidx_dev=self.colidx, **phased)
                 ipb = items_per_block_for(int(items["slot_ptr"][-1]))
                 if ipb != CLASS_ITEMS_PER_BLOCK:    # few chunks in this launch (a chunk of a rank's rows): smaller workgroups
                     items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk, ipb,
-                                        row_ids=rows_c, colidx_dev=self.colidx)
+                                        row_ids=rows_c, colidx_dev=self.colidx, **phased)
                 self.class_rows.append((to_dev(rows_c), torch.from_numpy(items["slot_ptr"]).to(dev),
                                         torch.from_numpy(items["e0"]).to(dev), torch.from_numpy(items["len"]).to(dev),
                                         torch.from_numpy(items["slot"]).to(dev), torch.from_numpy(items["row"]).to(dev),
@@ -784,6 +795,7 @@ class SweepEngine:
                 "hub_threshold": self.hub_threshold,
                 "split_edges": self.split_edges, "segment_edges": self.segment_edges,
                 "class_threshold": self.class_threshold, "class_chunk": self.class_chunk, "class_k1": self.class_k1,
+                "class_phases": self.class_phases, "phase_threshold": self.phase_threshold,
                 "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 

@@ -27,7 +27,7 @@ from typing import List
 import numpy as np
 
 from .partition import Block, HostCSR, LocalCSR
-from .xcd import xcd_class
+from .xcd import xcd_subclass
 
 
 @dataclass
@@ -62,7 +62,8 @@ class HaloLayout:
 
 
 def build_halo_layout(csr: HostCSR, world_size: int, rank: int, chunks: int = 4, shuffle: bool = True,
-                      seed: int = 0, hot_rows_first: bool = True, class_threshold: int = 0) -> HaloLayout:
+                      seed: int = 0, hot_rows_first: bool = True, class_threshold: int = 0, phase_threshold: int = 0,
+                      phases: int = 1) -> HaloLayout:
     """``class_threshold`` > 0: rows with more edges than that keep their edges sorted by (XCD class of the table
     row, table row) instead of by table row (engine: class-affine rows)."""
     V, W = csr.num_vertices, world_size
@@ -149,8 +150,7 @@ def build_halo_layout(csr: HostCSR, world_size: int, rank: int, chunks: int = 4,
     if cols.size and cols.min() < 0:
         raise AssertionError("a column read by this rank is missing from its table")
     if class_threshold > 0:
-        cls = np.where(deg[row_of] > class_threshold, xcd_class(cols), 0)
-        order = np.lexsort((cols, cls, row_of))
+        order = np.lexsort((cols, xcd_subclass(cols, deg[row_of], class_threshold, phase_threshold, phases), row_of))
     else:
         order = np.lexsort((cols, row_of))
     cols, origin = cols[order], origin[order]

@@ -30,7 +30,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-from .xcd import XCD_CLASSES, xcd_class
+from .xcd import XCD_CLASSES, xcd_subclass
 
 
 @dataclass
@@ -178,31 +178,33 @@ class LocalCSR:
     edge_origin: np.ndarray     # int64 [E_local]  index of each local edge in the global CSR order
 
 
-def edge_order(row_of, cols, cls, table_rows: int, two_pass: Optional[bool] = None):
-    """Permutation (torch) that sorts edges by (row, class, column) -- `cls` None: by (row, column).  (row, column)
-    pairs are unique, so any sort gives THE order.  One sort of a fused int64 key while it fits; two stable sorts
-    beyond that (rows x 8 x table rows >= 2^62: more than ~7e8 vertices on one GPU)."""
+def edge_order(row_of, cols, sub, table_rows: int, n_sub: int = XCD_CLASSES, two_pass: Optional[bool] = None):
+    """Permutation (torch) that sorts edges by (row, sub-class, column) -- `sub` None: by (row, column); `sub` in
+    [0, n_sub).  (row, column) pairs are unique, so any sort gives THE order.  One sort of a fused int64 key while it
+    fits; two stable sorts beyond that (rows x n_sub x table rows >= 2^62)."""
     import torch
     n_rows = int(row_of.max()) + 1 if row_of.numel() else 1
-    width = table_rows * (XCD_CLASSES if cls is not None else 1)
+    width = table_rows * (n_sub if sub is not None else 1)
     if two_pass is None:
         two_pass = n_rows * width >= 2 ** 62
     if not two_pass:
         key = row_of * width + cols
-        if cls is not None:
-            key = key + cls * table_rows
+        if sub is not None:
+            key = key + sub * table_rows
         return torch.argsort(key)
     first = torch.argsort(cols, stable=True)
-    major = row_of if cls is None else row_of * XCD_CLASSES + cls
+    major = row_of if sub is None else row_of * n_sub + sub
     return first[torch.argsort(major[first], stable=True)]
 
 
-def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int = 0) -> LocalCSR:
+def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int = 0, phase_threshold: int = 0,
+             phases: int = 1) -> LocalCSR:
     """Slice + relabel the global CSR for one rank.  The one heavy step -- re-sorting every row's edges by their
     new column -- is a single sort of unique (row, column) keys; with ``device`` = a GPU it runs there (40M edges:
     seconds on the host, milliseconds on the card).
-    ``class_threshold`` > 0: rows with more edges than that are sorted by (xcd_class(column), column) instead, so that the
-    edges to one XCD class are contiguous (engine: class-affine rows, csrc/spmm_update.h)."""
+    ``class_threshold`` > 0: rows with more edges than that are sorted by (xcd_subclass(column), column) instead, so
+    that the edges to one XCD class (of one phase, for rows above ``phase_threshold``) are contiguous (engine:
+    class-affine rows, csrc/spmm_update.h; clane_amd/xcd.py)."""
     V = csr.num_vertices
     if V != part.num_vertices:
         raise ValueError("partition built for a different vertex count")
@@ -229,7 +231,7 @@ def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int
     # original edge id of every local edge: start-of-row + offset within the row
     origin = t(csr.rowptr[safe])[row_of] + (torch.arange(int(rowptr[-1]), device=dev) - rowptr_t[:-1][row_of])
     cols = t(pos)[t(csr.colidx.astype(np.int64))[origin]]
-    cls = xcd_class(cols) * t(by_class).to(cols.dtype)[row_of] if by_class.any() else None
-    order = edge_order(row_of, cols, cls, part.padded_vertices)
+    sub = xcd_subclass(cols, deg_t[row_of], class_threshold, phase_threshold, phases) if by_class.any() else None
+    order = edge_order(row_of, cols, sub, part.padded_vertices, XCD_CLASSES * max(1, phases))
     cols, origin = cols[order], origin[order]
     return LocalCSR(rowptr, cols.to(torch.int32).cpu().numpy(), indeg, verts, origin.cpu().numpy())

@@ -31,6 +31,17 @@ def xcd_class(position):
     return (p ^ (p >> 3) ^ (p >> 6) ^ (p >> 9)) & (XCD_CLASSES - 1)
 
 
+def xcd_subclass(position, row_degree, class_threshold: int, phase_threshold: int = 0, phases: int = 1):
+    """Sort key of an edge inside its row, ahead of the column: 0 for rows of at most `class_threshold` edges (plain
+    column order); the XCD class of the column for class rows; `phase * 8 + class` for HEAVY rows (more than
+    `phase_threshold` edges, `phases` > 1), where phase = (column / 64) % phases.  Works on numpy arrays and torch
+    tensors alike (`position` and `row_degree` of equal shape)."""
+    cls = xcd_class(position)
+    if phases > 1 and phase_threshold > 0:
+        cls = cls + XCD_CLASSES * (((position >> 6) % phases) * (row_degree > phase_threshold))
+    return cls * (row_degree > class_threshold)
+
+
 # Rows above CLASS_THRESHOLD edges are gathered XCD-affine (csrc/spmm_update.h, spmm_class_chunk_kernel): their edges
 # are sorted by (class of the column, column) -- xcd_class above --, cut into chunks of at most CLASS_CHUNK edges
 # of one class, and the chunks of class b run on the workgroups 8 j + b = XCD b, so each XCD's 4 MiB L2 caches its own
@@ -42,20 +53,34 @@ def xcd_class(position):
 # 0.257 -> 0.249.  build_P scores these rows over the same chunks (class_k1: 5.7 -> 4.7 ms at config 3).
 CLASS_THRESHOLD_BY_ROWS_PER_WAVE = {1: 64, 2: 64, 4: 256, 8: 256}
 CLASS_CHUNK = 256
+# HEAVY class rows are additionally PHASED in time: the rows of a class are split into sub-classes ((column / 64) %
+# phases: every sub-class gets the same mix of hot and cold rows) and all chunks of sub-class 0 are scheduled before
+# those of sub-class 1, ... -- at any moment an XCD's hot working set is 1/phases of its class.  At 1-KiB rows the 4096
+# hottest rows of a class ARE the 4 MiB L2; halving / quartering that working set lifts the pure gather from 14.3 to
+# 15.5 / 16.7 TB/s (profiles/r02_gather_rows_ceiling.md).  Every phase multiplies a row's pieces and partial sums,
+# hence heavy rows only (above PHASE_THRESHOLD edges).  Measured (profiles/r02_class_threshold_sweep.md): config 3
+# 4.31 -> 4.01 ms with 4 phases (build_P 4.72 -> 4.44); its 512-byte column slice 1.98 -> 1.91 with 2; narrower rows
+# lose (their hot rows already fit).
+PHASES_BY_ROWS_PER_WAVE = {1: 4, 2: 2, 4: 1, 8: 1}
+PHASE_THRESHOLD = 512
 CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
 
 
 
 def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int,
-                row_ids: Optional[np.ndarray] = None, colidx_dev: Optional[torch.Tensor] = None) -> dict:
+                row_ids: Optional[np.ndarray] = None, colidx_dev: Optional[torch.Tensor] = None,
+                phase_threshold: int = 0, phases: int = 1) -> dict:
     """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
     (xcd_class(column), column)): every class segment of a row is cut into chunks of at most `chunk` edges.
     Slots -- where the partial sums go -- are numbered row by row, class by class, chunk by chunk, so a row's slots
     are contiguous (`slot_ptr`) and summed in that order.  Items are laid out for the kernel: blocks of
     `items_per_block` items of ONE class, block j of class b at block index 8 j + b, padded with empty items
-    (len 0, slot -1).  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
+    (len 0, slot -1).  With `phases` > 1 the rows above `phase_threshold` edges are cut by (phase, class) -- their
+    edges sorted by xcd_subclass -- and their blocks come first, phase by phase (each phase a whole number of
+    8-block rounds, so block index % 8 stays the class), then the blocks of the other rows.  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
     item's row, default `rows` itself) and int64 slot_ptr [rows + 1]."""
     n = rows.size
+    NS = XCD_CLASSES * max(1, phases)                       # sub-classes per row (phase-major)
     sizes = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
     start = np.concatenate([[0], np.cumsum(sizes)[:-1]])
     if colidx_dev is not None and colidx_dev.is_cuda:        # the O(E) part on the card (40M edges: 0.3 s on the host)
@@ -63,41 +88,55 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
         sizes_t = torch.from_numpy(sizes).to(dev)
         rid = torch.repeat_interleave(torch.arange(n, device=dev), sizes_t)
         idx = torch.from_numpy(rowptr[rows] - start).to(dev)[rid] + torch.arange(int(sizes.sum()), device=dev)
-        key = rid * XCD_CLASSES + xcd_class(colidx_dev[idx].long())
+        sub = xcd_subclass(colidx_dev[idx].long(), sizes_t[rid], 0, phase_threshold, phases)
+        key = rid * NS + sub
         unsorted = bool((key[1:] < key[:-1]).any()) if key.numel() > 1 else False
-        seg_len = torch.bincount(key, minlength=n * XCD_CLASSES).cpu().numpy()
+        seg_len = torch.bincount(key, minlength=n * NS).cpu().numpy()
     else:
         idx = np.repeat(rowptr[rows] - start, sizes) + np.arange(int(sizes.sum()), dtype=np.int64)
-        cls = xcd_class(colidx[idx].astype(np.int64))
         rid = np.repeat(np.arange(n, dtype=np.int64), sizes)
-        unsorted = idx.size > 1 and bool((np.diff(rid * XCD_CLASSES + cls) < 0).any())
-        seg_len = np.bincount(rid * XCD_CLASSES + cls, minlength=n * XCD_CLASSES)
+        sub = xcd_subclass(colidx[idx].astype(np.int64), sizes[rid], 0, phase_threshold, phases)
+        unsorted = idx.size > 1 and bool((np.diff(rid * NS + sub) < 0).any())
+        seg_len = np.bincount(rid * NS + sub, minlength=n * NS)
     if unsorted:
-        raise AssertionError("class rows must have their edges sorted by (xcd_class(column), column)")
-    seg_e0 = np.repeat(rowptr[rows], XCD_CLASSES) + (np.cumsum(seg_len) - seg_len
-                                                      - np.repeat(start, XCD_CLASSES))
+        raise AssertionError("class rows must have their edges sorted by (xcd_subclass(column), column)")
+    seg_e0 = np.repeat(rowptr[rows], NS) + (np.cumsum(seg_len) - seg_len - np.repeat(start, NS))
     nchunk = -(-seg_len // chunk)
     tot = int(nchunk.sum())
-    seg_of = np.repeat(np.arange(n * XCD_CLASSES), nchunk)
+    seg_of = np.repeat(np.arange(n * NS), nchunk)
     within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
     e0 = seg_e0[seg_of] + within * chunk
     ln = np.minimum(chunk, seg_len[seg_of] - within * chunk)
     slot_ptr = np.zeros(n + 1, dtype=np.int64)
-    np.cumsum(nchunk.reshape(n, XCD_CLASSES).sum(1), out=slot_ptr[1:])
-    item_cls = seg_of % XCD_CLASSES
-    per_class = [np.nonzero(item_cls == c)[0] for c in range(XCD_CLASSES)]
-    nblk = max(1, max(-(-len(pc) // items_per_block) for pc in per_class))
-    flat = XCD_CLASSES * nblk * items_per_block
-    out_e0 = np.zeros(flat, dtype=np.int64)
-    out_len = np.zeros(flat, dtype=np.int32)
-    out_slot = np.full(flat, -1, dtype=np.int32)
-    out_row = np.zeros(flat, dtype=np.int32)
+    np.cumsum(nchunk.reshape(n, NS).sum(1), out=slot_ptr[1:])
+    item_cls = (seg_of % NS) % XCD_CLASSES
+    heavy = sizes > phase_threshold if (phases > 1 and phase_threshold > 0) else np.zeros(n, dtype=bool)
+    # launch groups, in order: the heavy rows' items phase by phase, then everybody else's
+    item_group = np.where(heavy[seg_of // NS], (seg_of % NS) // XCD_CLASSES, max(1, phases))
     ids = (rows if row_ids is None else row_ids).astype(np.int32)
-    item_row = ids[seg_of // XCD_CLASSES]
-    for c, pc in enumerate(per_class):
-        t = np.arange(len(pc))
-        where = (t // items_per_block) * (XCD_CLASSES * items_per_block) + c * items_per_block + t % items_per_block
-        out_e0[where], out_len[where], out_slot[where], out_row[where] = e0[pc], ln[pc], pc, item_row[pc]
+    item_row = ids[seg_of // NS]
+    pieces = []
+    for g in range(max(1, phases) + 1):
+        in_group = item_group == g
+        if not in_group.any():
+            continue
+        per_class = [np.nonzero(in_group & (item_cls == c))[0] for c in range(XCD_CLASSES)]
+        nblk = max(-(-len(pc) // items_per_block) for pc in per_class)
+        flat = XCD_CLASSES * nblk * items_per_block
+        g_e0 = np.zeros(flat, dtype=np.int64)
+        g_len = np.zeros(flat, dtype=np.int32)
+        g_slot = np.full(flat, -1, dtype=np.int32)
+        g_row = np.zeros(flat, dtype=np.int32)
+        for c, pc in enumerate(per_class):
+            t = np.arange(len(pc))
+            where = (t // items_per_block) * (XCD_CLASSES * items_per_block) + c * items_per_block + t % items_per_block
+            g_e0[where], g_len[where], g_slot[where], g_row[where] = e0[pc], ln[pc], pc, item_row[pc]
+        pieces.append((g_e0, g_len, g_slot, g_row))
+    if not pieces:                                          # no edges at all: one round of empty blocks
+        flat = XCD_CLASSES * items_per_block
+        pieces.append((np.zeros(flat, dtype=np.int64), np.zeros(flat, dtype=np.int32),
+                       np.full(flat, -1, dtype=np.int32), np.zeros(flat, dtype=np.int32)))
+    out_e0, out_len, out_slot, out_row = (np.concatenate([p[i] for p in pieces]) for i in range(4))
     return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "slot_ptr": slot_ptr}
 
 

@@ -662,9 +662,9 @@ def test_class_affine_rows_layout_and_result(chunks, hot):
     for _ in range(3):
         Z_or, dl = O.sweep(csr.rowptr, csr.colidx, P_or, X, Z_or, 0.7)
         deltas_or.append(float(dl))
-    for ct, chunk, lt in ((8, 64, None), (64, 128, 4), (128, 64, 0)):
+    for ct, chunk, lt, phases in ((8, 64, None, 1), (64, 128, 4, 2), (128, 64, 0, 4), (8, 64, None, 4)):
         eng = SweepEngine(csr, X, "cpu", OracleKernels(), chunks=chunks, hot_rows_first=hot, class_threshold=ct,
-                          class_chunk=chunk, long_threshold=lt)
+                          class_chunk=chunk, long_threshold=lt, class_phases=phases, phase_threshold=200)
         n_class = sum(0 if c is None else c[0].numel() for c in eng.class_rows)
         assert n_class == int((deg > ct).sum()) and 0 < eng.long_threshold <= ct
         assert eng.kernel_names()["split"].startswith("spmm_class") and eng.kernel_config()["class_threshold"] == ct
@@ -672,8 +672,12 @@ def test_class_affine_rows_layout_and_result(chunks, hot):
         lr, lc = eng.local.rowptr, eng.local.colidx.astype(np.int64)
         for r in range(eng.part.n_local):
             c = lc[lr[r]:lr[r + 1]]
-            key = xcd_class(c) * 10**9 + c if c.size > ct else c
+            heavy = phases > 1 and c.size > max(200, ct)
+            sub = xcd_class(c) + (8 * ((c >> 6) % phases) if heavy else 0)
+            key = sub * 10**9 + c if c.size > ct else c
             assert (np.diff(key) > 0).all()
+        if phases > 1:          # the heavy rows' blocks come first, phase by phase; the test double checks the classes
+            assert eng.kernel_config()["class_phases"] == phases and eng.phase_threshold == max(200, ct)
         eng.build_P()
         assert O.rel_l2(eng.P_global(), P_or) < 1e-6
         deltas = [eng.sweep(0.7) for _ in range(3)]

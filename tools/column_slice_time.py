@@ -19,6 +19,8 @@ ap.add_argument("--chunks", type=int, default=1)
 ap.add_argument("--class-threshold", type=int, nargs="+", default=[None],
                 help="rows above this many edges take the XCD-affine pass (0 = off; default: the engine's choice)")
 ap.add_argument("--class-chunk", type=int, nargs="+", default=[256])
+ap.add_argument("--class-phases", type=int, default=None)
+ap.add_argument("--phase-threshold", type=int, default=512)
 ap.add_argument("--calibrate", action="store_true",
                 help="also launch l1_distance over two [V, d/N] matrices (known bytes) -- PMC calibration")
 args = ap.parse_args()
@@ -31,7 +33,8 @@ for W, ct, cc in [(W, ct, cc) for W in args.world for ct in args.class_threshold
         continue
     dl = d // W
     eng = SweepEngine(csr, X[:, :dl].contiguous(), dev, chunks=args.chunks, long_threshold=args.long_threshold,
-                      class_threshold=ct, class_chunk=cc)
+                      class_threshold=ct, class_chunk=cc, class_phases=args.class_phases,
+                      phase_threshold=args.phase_threshold)
     eng.build_P()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -60,6 +63,7 @@ for W, ct, cc in [(W, ct, cc) for W in args.world for ct in args.class_threshold
     nbytes = sum(kb.values())
     print(json.dumps({"world": W, "d_local": dl, "ms_per_sweep": round(ms, 3), "long_threshold": eng.long_threshold,
                       "class_threshold": eng.class_threshold, "class_chunk": eng.class_chunk,
+                      "class_phases": eng.class_phases, "phase_threshold": eng.phase_threshold,
                       "build_P_ms": round(build_ms, 3),
                       "algorithmic_GB": round(nbytes / 1e9, 2), "TBps": round(nbytes / ms / 1e9, 2),
                       "kernels_ms": {k: round(v, 3) for k, v in kt.items()},

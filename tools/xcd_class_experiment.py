@@ -31,6 +31,7 @@ ap.add_argument("--phases", type=int, default=1,
                 help="P > 1: every class is split into P sub-classes (an xor-fold of higher position bits) and the chunk "
                      "blocks are laid out phase-major: all chunks of sub-class 0 before those of sub-class 1, ... "
                      "(XCD-affine in space AND phased in time, profiles/r02_gather_rows_ceiling.md)")
+ap.add_argument("--phase-bits", default="granules", choices=["granules", "bands"])
 ap.add_argument("--cols", type=int, default=None, help="use only the first COLS columns (a column slice)")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
@@ -91,7 +92,12 @@ for dmin in args.min_degree:
     from clane_amd.xcd import xcd_class
     cls = xcd_class(cols) if not args.block_class else (cols >> 3) & 7
     NP = args.phases
-    phase = ((cols >> 12) ^ (cols >> 14) ^ (cols >> 16)) % NP if NP > 1 else np.zeros_like(cols)
+    if NP > 1 and args.phase_bits == "bands":       # 4096-row bands of the table, dealt to the phases
+        phase = ((cols >> 12) ^ (cols >> 14) ^ (cols >> 16)) % NP
+    elif NP > 1:                                     # 64-row granules: every phase gets the same mix of hot and cold rows
+        phase = (cols >> 6) % NP
+    else:
+        phase = np.zeros_like(cols)
     sub = phase * 8 + cls                                              # 8 * NP sub-classes; XCD = sub % 8
     order = np.lexsort((cols, sub, rid))
     cols, idx, rid, cls, sub = cols[order], idx[order], rid[order], cls[order], sub[order]
