@@ -262,7 +262,10 @@ int clane_edge_score_class_bf16(const int64_t *rowptr, const int32_t *colidx, co
  *                             of class b and the eight L2s cache different eighths of the hot rows.
  *                             item_e0 / item_len: edge range of an item in colidx / P; item_slot: where its partial
  *                             sum goes in `slab` (clane_spmm_class_slab_len(n_slots, d) accumulate-type elements,
- *                             16-byte aligned).  class_rows[n_rows] local row ids; slot_ptr[n_rows+1]: the slots of
+ *                             16-byte aligned).  The ORDER of the blocks is the caller's too: the engine puts the
+ *                             pieces of its heaviest rows first, sub-class by sub-class, so that an XCD's hot
+ *                             working set at any moment is a fraction of its class (clane_amd/xcd.py).
+ *                             class_rows[n_rows] local row ids; slot_ptr[n_rows+1]: the slots of
  *                             row i are [slot_ptr[i], slot_ptr[i+1]) and are added in that order (reproducible),
  *                             then the usual epilogue.  Writes n_rows doubles to delta_partials. */
 int64_t clane_spmm_class_slab_len(int64_t n_slots, int32_t d);
