@@ -313,9 +313,11 @@ def test_class_pass_random_engines(dev):
         X = synth.gaussian_X(V, d, seed=case).to(dtype)
         ct, chunk = int(rng.choice([1, 2, 5, 8])), int(rng.choice([64, 128, 256]))
         mode = "per_edge" if case % 2 else "reference"
+        phases, pt = int(rng.choice([1, 2, 4, 8])), int(rng.choice([2, 6, 20]))     # heavy rows phased in time as well
         eng = SweepEngine(csr, X, dev, chunks=1 if case % 4 else 3, hot_rows_first=bool(case % 3), cosine_mode=mode,
-                          class_threshold=ct, class_chunk=chunk)
-        tag = f"case {case}: V={V} d={d} {dtype} class_threshold={ct} chunk={chunk} E={csr.num_edges} {mode}"
+                          class_threshold=ct, class_chunk=chunk, class_phases=phases, phase_threshold=pt)
+        tag = (f"case {case}: V={V} d={d} {dtype} class_threshold={ct} chunk={chunk} phases={phases}>{pt} "
+               f"E={csr.num_edges} {mode}")
         assert sum(0 if c is None else c[0].numel() for c in eng.class_rows) == int((deg > ct).sum()), tag
         Xf = X.to(acc).double()
         if csr.num_edges == 0:
