@@ -78,6 +78,8 @@ def embedding(args):
 
     embedder_cls = IterativeEmbedder if hasattr(similarity_measure, 'parameters') else Embedder
     extra = {"num_workers": args.num_workers} if embedder_cls is IterativeEmbedder else {}
+    if world > 1 and getattr(args, "exchange", "auto") != "auto":
+        g.engine(device if device.type == "cuda" else None, exchange=args.exchange)     # first use fixes the division
     if args.init_Z is not None:                     # resume: start from saved embeddings instead of Z = X
         Z0 = torch.from_numpy(np.load(args.init_Z))
         if tuple(Z0.shape) != tuple(g.X.shape):
@@ -131,6 +133,11 @@ def get_parser():
     parser.add_argument("--init_Z", type=Path, default=None,
                         help="(extension) .npy of shape [V, d]: start from these embeddings instead of the content "
                              "embeddings, e.g. the Z.npy of an interrupted run.")
+    parser.add_argument("--exchange", default="auto",
+                        choices=["auto", "columns", "allgather_all", "allgather", "halo", "halo_p2p"],
+                        help="(extension, multi-GPU runs under torchrun) how the sweep is divided over the GPUs: columns of "
+                             "Z (no exchange per sweep; what auto picks for wide rows), rows with one all-gather of the "
+                             "updated rows per sweep (allgather_all), or the leaner row splits; see DESIGN.md section 6.")
     parser.add_argument("--gpu", action='store_true')
     return parser
 

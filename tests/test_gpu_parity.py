@@ -1163,6 +1163,12 @@ def test_cli_two_processes_on_one_gpu_match_one_process(tmp_path):
     Z1, Z2 = np.load(tmp_path / "o1" / "Z.npy"), np.load(tmp_path / "o2" / "Z.npy")
     assert Z1.shape == (34, 64) and np.linalg.norm(Z1 - Z2) <= 1e-5 * np.linalg.norm(Z1)
     assert two.stdout.count("Graph Loaded.") == 1                      # rank 0 talks, the other rank is silent
+    # --exchange (extension): north_star's row partition + all-gather per sweep gives the same embeddings
+    rows = subprocess.run(two.args[:-1] + [str(tmp_path / "o3"), "--exchange", "allgather_all"], capture_output=True,
+                          text=True, timeout=600, cwd=root, env=env)
+    assert rows.returncode == 0, rows.stderr[-2000:]
+    Z3 = np.load(tmp_path / "o3" / "Z.npy")
+    assert np.linalg.norm(Z1 - Z3) <= 1e-5 * np.linalg.norm(Z1)
 
 
 def test_config3_full_size_properties(dev):
