@@ -33,6 +33,7 @@ SIGNATURES = {
     "clane_abi_version": (C.c_int, []),
     "clane_last_error": (C.c_char_p, []),
     "clane_build_info": (C.c_char_p, []),
+    "clane_xcc_ids": (C.c_int, [_p, _i64, _i32, _p]),
     "clane_spmm_partials_len": (_i64, [_i64, _i64]),
     "clane_reduce_ws_len": (_i64, []),
     "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p, _p]),
@@ -285,6 +286,12 @@ class HipKernels:
     # -- sizes --------------------------------------------------------------------------
     def spmm_partials_len(self, nrows: int, n_long: int) -> int:
         return int(self.lib.clane_spmm_partials_len(nrows, n_long))
+
+    def xcc_ids(self, n_blocks: int, block_threads: int = 256, device=None) -> torch.Tensor:
+        """XCD each workgroup of an n_blocks-workgroup launch ran on (int32 tensor on the device)."""
+        out = torch.full((n_blocks,), -1, dtype=torch.int32, device=device if device is not None else "cuda")
+        self._check(self.lib.clane_xcc_ids(out.data_ptr(), n_blocks, block_threads, self._stream(out)), "clane_xcc_ids")
+        return out
 
     def build_info(self) -> str:
         return self.lib.clane_build_info().decode()

@@ -299,4 +299,9 @@ __global__ __launch_bounds__(kBlock) void edge_score_finalize_kernel(
     }
 }
 
+// out[w] = XCD that workgroup w of this launch ran on (diagnostic: see xcc_id()).
+__global__ void xcc_ids_kernel(int32_t *__restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+
 }  // namespace clane

@@ -453,6 +453,13 @@ const char *clane_build_info(void) {
         ";TARGET_GRID=" CLANE_STR(CLANE_TARGET_GRID) ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH);
 }
 
+int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *stream) {
+    if (!out || n_blocks <= 0 || n_blocks > INT32_MAX || block_threads < 64 || block_threads > 1024 || block_threads % 64)
+        return fail(CLANE_ERR_INVALID_ARGUMENT, "xcc_ids: bad arguments");
+    xcc_ids_kernel<<<unsigned(n_blocks), unsigned(block_threads), 0, (hipStream_t)stream>>>(out);
+    return check_launch("xcc_ids");
+}
+
 int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long) {
     return spmm_main_grid(nrows > 0 ? nrows : 1) + (n_long > 0 ? n_long : 0);
 }

@@ -173,6 +173,11 @@ __device__ __forceinline__ bool last_wave_of_block(int *s_done) {
     return ticket == kWavesPerBlock - 1;
 }
 
+// XCD (accelerator complex die) the calling wave runs on: HW_REG_XCC_ID[3:0].  The class-affine kernels do not
+// read it -- they rely on workgroup w of a launch running on XCD (w + c) % 8, c fixed for the launch -- but tests do, so that the assumption is
+// checked on every box (clane_xcc_ids).
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf; }
+
 template <typename A>
 __device__ __forceinline__ A exp_acc(A v);
 template <>

@@ -591,7 +591,7 @@ namespace clane {
 
 // ---- class-affine rows: every gathered row is read through ONE XCD's L2 --------------------------------------
 // The 256 CUs sit in 8 XCDs with a private 4 MiB L2 each, and workgroups are dealt to the XCDs round-robin
-// (workgroup w runs on XCD w % 8).  When any workgroup may gather any row, all eight L2s end up caching the SAME
+// (workgroup w runs on XCD (w + c) % 8, c fixed within a launch).  When any workgroup may gather any row, all eight L2s end up caching the SAME
 // few thousand hottest rows.  Here every table row has a class 0..7 (host side: clane_amd/xcd.py), the edges of
 // a long row are sorted by (class of the column, column) and cut into CHUNKS of at most
 // a few hundred edges of one class, and the chunks of class b are dealt to the workgroups w = 8 j + b: XCD b only

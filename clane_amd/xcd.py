@@ -1,7 +1,7 @@
 """XCD affinity -- host side of the class-affine row kernels (csrc/spmm_update.h, csrc/edge_score.h).
 
 MI355X has 8 XCDs with a private 4 MiB L2 each and deals the workgroups of a launch to them round-robin (workgroup w
-runs on XCD w % 8; tools/xcc_map.hip).  When any workgroup may gather any row of Z, all eight L2s cache the same few
+runs on XCD (w + c) % 8 with c fixed within a launch; tools/xcc_map.hip, clane_xcc_ids).  When any workgroup may gather any row of Z, all eight L2s cache the same few
 thousand hottest rows.  The class-affine kernels keep every gathered row on ONE XCD instead: each table row gets a
 class 0..7 (`xcd_class`), the edges of a long row are sorted by (class of the column, column) -- `partition.localize`,
 `halo.build_halo_layout` -- and cut into work items of one class (`class_items`), laid out so that the items of

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CLANE_ABI_VERSION 2 /* 2: + clane_build_info, clane_spmm_update_class_*, clane_edge_score_class_* */
+#define CLANE_ABI_VERSION 2 /* 2: + clane_build_info, clane_xcc_ids, clane_spmm_update_class_*, clane_edge_score_class_* */
 
 #define CLANE_OK 0
 #define CLANE_ERR_INVALID_ARGUMENT (-1)
@@ -76,6 +76,10 @@ const char *clane_last_error(void);
  * workgroup, non-temporal streams): measurements stored beside a benchmark (profiles/traffic.json) carry it, so a
  * number taken with another build is recognised as stale.  No reference counterpart. */
 const char *clane_build_info(void);
+/* Diagnostic: out[w] = the XCD (0..7, HW_REG_XCC_ID) that workgroup w of a launch of n_blocks workgroups of
+ * block_threads threads ran on.  clane_spmm_update_class_* / clane_edge_score_class_* get their speed -- not their
+ * results -- from workgroup w running on XCD (w + c) % 8 with c the same for the whole launch; the GPU test suite checks that with this call. */
+int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *stream);
 
 /* Doubles written by clane_spmm_update_*(nrows) plus clane_spmm_update_long_*(n_long). */
 int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long);
@@ -252,7 +256,7 @@ int clane_edge_score_class_bf16(const int64_t *rowptr, const int32_t *colidx, co
 
 /*  clane_spmm_update_class_* : long rows whose gathers are kept XCD-affine (no reference counterpart: the reference's
  *                             loop is embedder.py:84-92 for every row alike).  MI355X has 8 XCDs with a private 4 MiB
- *                             L2 each and deals workgroups to them round-robin (workgroup w -> XCD w % 8).  The caller
+ *                             L2 each and deals workgroups to them round-robin (workgroup w -> XCD (w + c) % 8, c fixed within a launch).  The caller
  *                             gives every table row a CLASS 0..7 (the engine: an xor-fold of the row number's 3-bit groups -- not row % 8,
  *                             which would pin low address bits and use only part of an L2), sorts the edges of each listed row by
  *                             (class of the column, column) and cuts every class segment

@@ -403,3 +403,23 @@ def test_loader_sorts_large_edge_lists_on_the_card():
     got = csr_from_edges(V, src, dst)
     rowptr, colidx = O.build_csr(V, src, dst)
     assert np.array_equal(got.rowptr, rowptr) and np.array_equal(got.colidx, colidx) and got.num_edges < n
+
+
+def test_workgroups_are_dealt_to_the_xcds_round_robin(dev, k):
+    """What the class-affine kernels rely on for their SPEED (never for their results): within one launch workgroup w
+    runs on XCD (w + c) % 8, c the same for the whole launch (it carries over from the dispatches before, so it is
+    not always 0) -- for small and large grids, 64 to 1024 threads per workgroup, on the default and a side stream.
+    All chunks of one class then share one L2 and the eight classes use eight different ones."""
+    side = torch.cuda.Stream(dev)
+    rotations = set()
+    for n, threads in ((8, 64), (64, 256), (2048, 256), (100_000, 256), (20_001, 1024), (333_333, 64)):
+        for stream in (torch.cuda.current_stream(dev), side):
+            with torch.cuda.stream(stream):
+                got = k.xcc_ids(n, threads, dev)
+            stream.synchronize()
+            assert int(got.min()) >= 0 and int(got.max()) <= 7
+            c = int(got[0])
+            rotations.add(c)
+            want = (torch.arange(n, device=dev, dtype=torch.int32) + c) % 8
+            assert torch.equal(got, want), (n, threads, c, int((got != want).sum()))
+    print("start XCDs seen:", sorted(rotations))
