@@ -225,6 +225,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher: be the launcher
         raise SystemExit(launch_ranks(args.gpus))
+    if os.environ.get("CLANE_BENCH_WATCHDOG_S"):                # debugging aid: every rank dumps its stack every S seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CLANE_BENCH_WATCHDOG_S"]), repeat=True, file=sys.stderr)
 
     import torch.distributed as dist
     from clane_amd import _hip, synth
@@ -246,7 +249,13 @@ def main():
     pg = None
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except dist.DistBackendError:
+                if masked:      # RCCL refuses two ranks on one device: most likely a one-GPU box, not a masking launcher
+                    print(f"[bench] rank {rank}: RCCL could not start with {world} ranks and ONE visible GPU; to rehearse "
+                          f"the N > 1 flow on a one-GPU box use --backend gloo --share-gpu", file=sys.stderr)
+                raise
         else:
             dist.init_process_group("gloo")
         pg = dist.group.WORLD
