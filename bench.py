@@ -238,6 +238,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+    if world > 1:       # torchrun starts every rank with OMP_NUM_THREADS=1: give each rank its share of the host cores
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     n_dev = torch.cuda.device_count()
     if world > 1 and not args.share_gpu and n_dev not in (1, world) and n_dev < world:
         raise SystemExit(f"--gpus {world} but this box shows {n_dev} GPU(s); a rehearsal on fewer GPUs needs "
