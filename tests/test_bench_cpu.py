@@ -7,7 +7,6 @@ import sys
 from pathlib import Path
 from types import SimpleNamespace
 
-import numpy as np
 import torch
 
 ROOT = Path(__file__).resolve().parent.parent

@@ -7,7 +7,7 @@ rows" per long row, listed so that virtual row (r, b) is workgroup 8*i + b: bloc
 the XCDs, so bucket b's 1-KiB rows (H KiB in all) are only ever gathered through one XCD's 4 MiB L2.
 Timed with the production spmm_long kernel on the virtual CSR (the partial sums land in dummy rows: this measures
 the gather, not the combine).  Usage: tools/xcd_bucket_experiment.py [--hot 3072 3584 4096] [--min-degree 256]"""
-import argparse, json, sys, time
+import argparse, json, sys
 from pathlib import Path
 import numpy as np
 import torch
