@@ -223,7 +223,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     __syncthreads();
 
     // next row of this block for the calling wave (wave-uniform)
-    auto claim = [&](int prev) -> int {
+    auto claim = [&]([[maybe_unused]] int prev) -> int {
 #if CLANE_SPMM_DYNAMIC
         int v = 0;
         if (lane == 0) v = atomicAdd(&s_next, 1);
