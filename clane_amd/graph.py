@@ -133,7 +133,7 @@ def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray) -> HostC
     on_card = key.numel() >= GPU_SORT_MIN_EDGES and torch.cuda.is_available()
     if on_card:
         key = key.cuda()
-    key = torch.unique(key)
+    key = _sorted_unique(key, 0, n * n)
     rows = torch.div(key, n, rounding_mode="floor")
     counts = torch.bincount(rows, minlength=n).cpu().numpy()
     rowptr = np.zeros(n + 1, dtype=np.int64)
@@ -141,7 +141,18 @@ def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray) -> HostC
     return HostCSR(n, rowptr, (key - rows * n).to(torch.int32).cpu().numpy())
 
 
+def _sorted_unique(key: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+    """torch.unique (sorted) of int64 keys in [lo, hi); lists beyond what one torch sort takes (2^31 - 1 elements)
+    are split at the middle of the key range and the halves done one after the other."""
+    if key.numel() <= SORT_MAX_ELEMENTS or hi - lo < 2:
+        return torch.unique(key)
+    mid = (lo + hi) // 2
+    low = key < mid
+    return torch.cat([_sorted_unique(key[low], lo, mid), _sorted_unique(key[~low], mid, hi)])
+
+
 GPU_SORT_MIN_EDGES = 1 << 20
+SORT_MAX_ELEMENTS = (1 << 31) - 1
 
 
 def _parse_dtype(dtype) -> torch.dtype:

@@ -30,7 +30,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-from .xcd import XCD_CLASSES, xcd_subclass
+from .xcd import XCD_CLASSES, row_pieces, xcd_subclass
 
 
 @dataclass
@@ -178,6 +178,9 @@ class LocalCSR:
     edge_origin: np.ndarray     # int64 [E_local]  index of each local edge in the global CSR order
 
 
+LOCALIZE_PIECE_EDGES = 1 << 28
+
+
 def edge_order(row_of, cols, sub, table_rows: int, n_sub: int = XCD_CLASSES, two_pass: Optional[bool] = None):
     """Permutation (torch) that sorts edges by (row, sub-class, column) -- `sub` None: by (row, column); `sub` in
     [0, n_sub).  (row, column) pairs are unique, so any sort gives THE order.  One sort of a fused int64 key while it
@@ -226,12 +229,27 @@ def localize(csr: HostCSR, part: RowPartition, device=None, class_threshold: int
     import torch
     dev = torch.device(device) if device is not None and torch.device(device).type == "cuda" else torch.device("cpu")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    deg_t, rowptr_t = t(deg), t(rowptr)
-    row_of = torch.repeat_interleave(torch.arange(part.n_local, device=dev), deg_t)
-    # original edge id of every local edge: start-of-row + offset within the row
-    origin = t(csr.rowptr[safe])[row_of] + (torch.arange(int(rowptr[-1]), device=dev) - rowptr_t[:-1][row_of])
-    cols = t(pos)[t(csr.colidx.astype(np.int64))[origin]]
-    sub = xcd_subclass(cols, deg_t[row_of], class_threshold, phase_threshold, phases) if by_class.any() else None
-    order = edge_order(row_of, cols, sub, part.padded_vertices, XCD_CLASSES * max(1, phases))
-    cols, origin = cols[order], origin[order]
-    return LocalCSR(rowptr, cols.to(torch.int32).cpu().numpy(), indeg, verts, origin.cpu().numpy())
+    pos_t, start_t = t(pos), t(csr.rowptr[safe])
+    colidx_t = t(csr.colidx)
+    E_loc = int(rowptr[-1])
+    cols_out = np.empty(E_loc, dtype=np.int32)
+    origin_out = np.empty(E_loc, dtype=np.int64)
+    # rows are independent and their edges contiguous: work through the rows in pieces of at most
+    # LOCALIZE_PIECE_EDGES edges (one sort each; torch sorts at most 2^31 - 1 elements, and the pieces bound the
+    # scratch memory: ~10 int64 vectors of the piece's length)
+    for a, b in row_pieces(rowptr, LOCALIZE_PIECE_EDGES):
+        e0, e1 = int(rowptr[a]), int(rowptr[b])
+        if e1 == e0:
+            continue
+        deg_t = t(deg[a:b])
+        row_of = torch.repeat_interleave(torch.arange(b - a, device=dev), deg_t)
+        # original edge id of every local edge: start-of-row + offset within the row
+        origin = start_t[a:b][row_of] + (torch.arange(e1 - e0, device=dev) - (t(rowptr[a:b]) - e0)[row_of])
+        cols = pos_t[colidx_t[origin].long()]
+        sub = (xcd_subclass(cols, deg_t[row_of], class_threshold, phase_threshold, phases)
+               if by_class[a:b].any() else None)
+        order = edge_order(row_of, cols, sub, part.padded_vertices, XCD_CLASSES * max(1, phases))
+        cols_out[e0:e1] = cols[order].to(torch.int32).cpu().numpy()
+        origin_out[e0:e1] = origin[order].cpu().numpy()
+    return LocalCSR(rowptr, cols_out, indeg, verts, origin_out)
+

@@ -63,8 +63,21 @@ CLASS_CHUNK = 256
 # lose (their hot rows already fit).
 PHASES_BY_ROWS_PER_WAVE = {1: 4, 2: 2, 4: 1, 8: 1}
 PHASE_THRESHOLD = 512
+CLASS_ITEMS_PIECE_EDGES = 1 << 28
 CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
 
+
+
+def row_pieces(rowptr: np.ndarray, max_edges: int):
+    """Consecutive row ranges [a, b) covering all rows, each with at most ``max_edges`` edges (a single row with more
+    is a piece of its own)."""
+    n = rowptr.size - 1
+    a = 0
+    while a < n:
+        b = int(np.searchsorted(rowptr, rowptr[a] + max_edges, side="right")) - 1
+        b = min(max(b, a + 1), n)
+        yield a, b
+        a = b
 
 
 def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int,
@@ -85,13 +98,21 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     start = np.concatenate([[0], np.cumsum(sizes)[:-1]])
     if colidx_dev is not None and colidx_dev.is_cuda:        # the O(E) part on the card (40M edges: 0.3 s on the host)
         dev = colidx_dev.device
-        sizes_t = torch.from_numpy(sizes).to(dev)
-        rid = torch.repeat_interleave(torch.arange(n, device=dev), sizes_t)
-        idx = torch.from_numpy(rowptr[rows] - start).to(dev)[rid] + torch.arange(int(sizes.sum()), device=dev)
-        sub = xcd_subclass(colidx_dev[idx].long(), sizes_t[rid], 0, phase_threshold, phases)
-        key = rid * NS + sub
-        unsorted = bool((key[1:] < key[:-1]).any()) if key.numel() > 1 else False
-        seg_len = torch.bincount(key, minlength=n * NS).cpu().numpy()
+        seg_len = np.empty(n * NS, dtype=np.int64)
+        unsorted = False
+        bounds = np.concatenate([[0], np.cumsum(sizes)])
+        for a, b in row_pieces(bounds, CLASS_ITEMS_PIECE_EDGES):    # pieces bound the scratch memory on the card
+            if bounds[b] == bounds[a]:
+                seg_len[a * NS:b * NS] = 0
+                continue
+            sizes_t = torch.from_numpy(sizes[a:b]).to(dev)
+            rid = torch.repeat_interleave(torch.arange(b - a, device=dev), sizes_t)
+            idx = (torch.from_numpy(rowptr[rows[a:b]] - (start[a:b] - bounds[a])).to(dev)[rid]
+                   + torch.arange(int(bounds[b] - bounds[a]), device=dev))
+            sub = xcd_subclass(colidx_dev[idx].long(), sizes_t[rid], 0, phase_threshold, phases)
+            key = rid * NS + sub
+            unsorted = unsorted or (bool((key[1:] < key[:-1]).any()) if key.numel() > 1 else False)
+            seg_len[a * NS:b * NS] = torch.bincount(key, minlength=(b - a) * NS).cpu().numpy()
     else:
         idx = np.repeat(rowptr[rows] - start, sizes) + np.arange(int(sizes.sum()), dtype=np.int64)
         rid = np.repeat(np.arange(n, dtype=np.int64), sizes)

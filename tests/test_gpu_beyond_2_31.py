@@ -1,0 +1,137 @@
+"""More than 2^31 edges on one MI355X: 64-bit edge indexing end to end ("int64_t rowptr (E may exceed
+2^31)").  Takes minutes and ~80 GB of host memory, so it only runs when asked for:
+
+    CLANE_BIG=1 python -m pytest tests/test_gpu_beyond_2_31.py -m gpu -q -s
+
+|V| = 2^25, |E| ~ 2.4e9 unique edges (uniform degrees 0..140, a tenth of the rows sinks, 256 hub rows of 1.2M edges),
+d = 32 fp32.  The graph is built so that uniqueness holds by construction (row r reaches h(r) + j * odd stride mod 2^25),
+no sort of the whole edge list anywhere.  Checked against the C oracle (64-bit clean, oracle/clane_oracle.c): all of P,
+all of Z after one sweep, the L1 delta, and separately the rows whose edges sit beyond index 2^31.
+"""
+import json
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from clane_amd import _hip
+from clane_amd.engine import SweepEngine
+from clane_amd.partition import HostCSR
+from clane_amd.xcd import row_pieces
+from oracle import clane_oracle as O
+from oracle import clane_oracle_c as OC
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("CLANE_BIG") != "1", reason="minutes + ~80 GB of host memory: set CLANE_BIG=1")]
+
+LOG2_V = int(os.environ.get("CLANE_BIG_LOG2_V", "25"))     # smaller values rehearse the test itself
+V = 1 << LOG2_V
+HUB_EDGES = min(1_200_000, V // 4)
+D = 32
+GAMMA = 0.76
+
+
+def big_csr(dev):
+    g = torch.Generator(device=dev).manual_seed(31)
+    deg = torch.randint(0, 141, (V,), generator=g, device=dev)
+    deg[torch.randperm(V, generator=g, device=dev)[:V // 10]] = 0
+    deg[torch.randperm(V, generator=g, device=dev)[:256]] = HUB_EDGES
+    rowptr_t = torch.zeros(V + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=rowptr_t[1:])
+    rowptr = rowptr_t.cpu().numpy()
+    E = int(rowptr[-1])
+    assert E > 2 ** 31 or LOG2_V < 25, E
+    first = torch.randint(0, V, (V,), generator=g, device=dev)
+    stride = 2 * torch.randint(0, V // 2, (V,), generator=g, device=dev) + 1      # odd: j * stride mod 2^25 never repeats
+    colidx = np.empty(E, dtype=np.int32)
+    for a, b in row_pieces(rowptr, 1 << 27):
+        e0, e1 = int(rowptr[a]), int(rowptr[b])
+        if e1 == e0:
+            continue
+        row_of = torch.repeat_interleave(torch.arange(b - a, device=dev), deg[a:b])
+        j = torch.arange(e1 - e0, device=dev) - (rowptr_t[a:b] - e0)[row_of]
+        cols = (first[a:b][row_of] + j * stride[a:b][row_of]) % V
+        key = torch.sort(row_of * V + cols).values                                 # per row: columns ascending
+        colidx[e0:e1] = (key % V).to(torch.int32).cpu().numpy()
+    return HostCSR(V, rowptr, colidx)
+
+
+def test_more_than_2_31_edges():
+    dev = _hip.require_gpu("cuda:0")
+    clock = {}
+    t0 = time.perf_counter()
+    csr = big_csr(dev)
+    X = torch.randn(V, D, generator=torch.Generator(device=dev).manual_seed(32), device=dev).cpu()
+    clock["generate_s"] = time.perf_counter() - t0
+    E = csr.num_edges
+    print(f"|V|={V} |E|={E} ({E / 2 ** 31:.3f} x 2^31) generated in {clock['generate_s']:.0f}s", flush=True)
+
+    t0 = time.perf_counter()
+    eng = SweepEngine(csr, X, dev)
+    torch.cuda.synchronize()
+    clock["engine_up_s"] = time.perf_counter() - t0
+    print(f"engine up in {clock['engine_up_s']:.0f}s: {eng.kernel_config()}", flush=True)
+    n_class = sum(0 if c is None else c[0].numel() for c in eng.class_rows)
+    assert n_class >= 200                                  # the hub rows take the class pass
+
+    t0 = time.perf_counter()
+    eng.build_P()
+    torch.cuda.synchronize()
+    clock["build_P_s"] = time.perf_counter() - t0
+    P = eng.P_global().cpu()
+    assert P.numel() == E
+    OC.set_threads(os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    Po, _ = OC.build_P(csr.rowptr, csr.colidx, X)
+    clock["oracle_build_P_s"] = time.perf_counter() - t0
+    print(f"build_P {clock['build_P_s']:.2f}s on the card, {clock['oracle_build_P_s']:.0f}s by the oracle", flush=True)
+    parity_P = O.rel_l2(P, Po)
+    edge_mark = 2 ** 31 if LOG2_V >= 25 else E // 2
+    beyond = int(np.searchsorted(csr.rowptr, edge_mark, side="left"))     # first row whose edges start beyond 2^31
+    assert beyond < V - 1000
+    tail = slice(int(csr.rowptr[beyond]), E)
+    parity_P_tail = O.rel_l2(P[tail], Po[tail])
+    assert parity_P < 1e-5 and parity_P_tail < 1e-5, (parity_P, parity_P_tail)
+    del Po
+
+    t0 = time.perf_counter()
+    delta = eng.sweep(GAMMA)
+    torch.cuda.synchronize()
+    clock["first_sweep_s"] = time.perf_counter() - t0
+    Z1 = eng.get_Z().cpu()
+    t0 = time.perf_counter()
+    Zo, delta_o = OC.sweep(csr.rowptr, csr.colidx, P, X, X, GAMMA)
+    clock["oracle_sweep_s"] = time.perf_counter() - t0
+    parity_Z = O.rel_l2(Z1, Zo)
+    parity_Z_tail = O.rel_l2(Z1[beyond:], Zo[beyond:])
+    hubs = np.nonzero(np.diff(csr.rowptr) >= HUB_EDGES)[0]
+    parity_Z_hubs = O.rel_l2(Z1[hubs], Zo[hubs])
+    print(f"sweep: delta {delta} (oracle {delta_o}); rel-L2 Z {parity_Z:.2e}, rows beyond 2^31 {parity_Z_tail:.2e}, "
+          f"hub rows {parity_Z_hubs:.2e}", flush=True)
+    assert parity_Z < 1e-6 and parity_Z_tail < 1e-6 and parity_Z_hubs < 1e-6
+    assert abs(delta - delta_o) <= 1e-6 * abs(delta_o)
+
+    for _ in range(2):
+        eng.sweep(GAMMA)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        eng.sweep(GAMMA)
+    torch.cuda.synchronize()
+    clock["ms_per_sweep"] = (time.perf_counter() - t0) / 5 * 1e3
+    out = Path("gpurun_out/profiles")
+    out.mkdir(parents=True, exist_ok=True)
+    line = {"V": V, "E": E, "E_over_2_31": E / 2 ** 31, "d": D, "dtype": "f32", "class_rows": n_class,
+            "rows_with_edges_beyond_2_31": V - beyond,
+            "parity_rel_l2": {"P": parity_P, "P_beyond_2_31": parity_P_tail, "Z_after_1_sweep": parity_Z,
+                              "Z_rows_beyond_2_31": parity_Z_tail, "Z_hub_rows": parity_Z_hubs},
+            "note": "reference-mode scores are dot / (two global Frobenius norms) ~ 1e-10 here, so every row's softmax is "
+                    "1/deg to the last bit on both sides (P parity exactly 0); Z and the delta carry the check",
+            "delta": delta, "delta_oracle": delta_o, "oracle_threads": OC.threads(),
+            **{k: round(v, 3) for k, v in clock.items()}}
+    if LOG2_V >= 25:
+        (out / "r02_edges_beyond_2_31.json").write_text(json.dumps(line) + "\n")
+    print(json.dumps(line), flush=True)

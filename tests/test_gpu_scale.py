@@ -423,3 +423,22 @@ def test_workgroups_are_dealt_to_the_xcds_round_robin(dev, k):
             want = (torch.arange(n, device=dev, dtype=torch.int32) + c) % 8
             assert torch.equal(got, want), (n, threads, c, int((got != want).sum()))
     print("start XCDs seen:", sorted(rotations))
+
+
+def test_class_items_in_pieces_on_the_card(dev, k, monkeypatch):
+    """The O(E) part of the class-pass layout runs on the card in pieces of rows (bounded scratch, no tensor beyond
+    what torch sorts / indexes comfortably): tiny pieces give the items of one piece, and of the host path."""
+    from clane_amd import xcd
+    csr = synth.rmat_csr(20_000, 600_000, seed=11, device=str(dev))
+    X = synth.gaussian_X(20_000, 64, seed=12)
+    eng = SweepEngine(csr, X, dev, class_threshold=32, class_phases=2, phase_threshold=128)
+    rows = eng.class_rows[0][0].cpu().numpy().astype(np.int64)
+    assert rows.size > 100
+    args = (eng.local.rowptr, eng.local.colidx, rows, 64, 8)
+    kw = dict(phase_threshold=128, phases=2)
+    whole = xcd.class_items(*args, colidx_dev=eng.colidx, **kw)
+    host = xcd.class_items(*args, **kw)
+    monkeypatch.setattr(xcd, "CLASS_ITEMS_PIECE_EDGES", 1000)
+    pieces = xcd.class_items(*args, colidx_dev=eng.colidx, **kw)
+    for name in whole:
+        assert np.array_equal(whole[name], pieces[name]) and np.array_equal(whole[name], host[name]), name

@@ -700,3 +700,29 @@ def test_class_affine_rows_layout_and_result(chunks, hot):
     # the item builder refuses rows that are not in class order
     with pytest.raises(AssertionError, match="sorted by"):
         class_items(csr.rowptr, csr.colidx, np.array([5]), 64, 8)
+
+
+def test_preprocessing_in_pieces_gives_the_same_layout(monkeypatch):
+    """Graphs beyond one torch sort (2^31 - 1 elements) are laid out in pieces of rows / halves of the key range:
+    with tiny piece sizes the result is the one-piece result."""
+    from clane_amd import graph as G, partition, synth, xcd
+    from clane_amd.partition import RowPartition, localize
+    csr = synth.rmat_csr(3000, 60000, seed=1, device="cpu")
+    for world, rank, chunks in ((1, 0, 1), (3, 1, 2)):
+        part = RowPartition.create(3000, world, rank, chunks, live_mask=csr.live_mask(), priority=csr.indeg(),
+                                   shuffle=False)
+        for kw in (dict(), dict(class_threshold=16, phase_threshold=64, phases=2)):
+            whole = localize(csr, part, None, **kw)
+            monkeypatch.setattr(partition, "LOCALIZE_PIECE_EDGES", 37)
+            pieces = localize(csr, part, None, **kw)
+            monkeypatch.undo()
+            for name in ("rowptr", "colidx", "edge_origin", "vertex", "indeg"):
+                assert np.array_equal(getattr(whole, name), getattr(pieces, name)), (world, kw, name)
+    assert list(xcd.row_pieces(np.array([0, 3, 3, 10, 11, 11, 30, 31]), 8)) == [(0, 2), (2, 5), (5, 6), (6, 7)]
+    assert list(xcd.row_pieces(np.array([0, 0, 0]), 8)) == [(0, 2)]
+    rng = np.random.default_rng(0)
+    src, dst = rng.integers(0, 50, 5000), rng.integers(0, 50, 5000)
+    whole = G.csr_from_edges(50, src, dst)
+    monkeypatch.setattr(G, "SORT_MAX_ELEMENTS", 100)
+    halves = G.csr_from_edges(50, src, dst)
+    assert np.array_equal(whole.rowptr, halves.rowptr) and np.array_equal(whole.colidx, halves.colidx)
