@@ -726,3 +726,16 @@ def test_preprocessing_in_pieces_gives_the_same_layout(monkeypatch):
     monkeypatch.setattr(G, "SORT_MAX_ELEMENTS", 100)
     halves = G.csr_from_edges(50, src, dst)
     assert np.array_equal(whole.rowptr, halves.rowptr) and np.array_equal(whole.colidx, halves.colidx)
+
+
+def test_host_native_code_is_clean_under_asan_and_ubsan():
+    """tests/sanitize_host.sh: the V/E parser (16 threads) and the C oracle (OpenMP) under AddressSanitizer + UBSan."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = Path(__file__).resolve().parent.parent
+    run = subprocess.run([str(root / "tests" / "sanitize_host.sh")], capture_output=True, text=True, timeout=300)
+    if "cannot find -lasan" in run.stderr or "cannot find -lubsan" in run.stderr:
+        pytest.skip("sanitizer runtimes not installed")
+    assert run.returncode == 0 and "sanitize_host: ok" in run.stdout, run.stdout[-2000:] + run.stderr[-4000:]
