@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
         e += "v1\tnobody\n";
         CHECK(parse(dir, v, e, s, d, msg) == -3);
     }
-    {   // the C oracle on a small graph with an empty row, a self-loop and a hub
+    if (argc < 3) {   // the C oracle on a small graph (skipped in the ThreadSanitizer build: libgomp is not instrumented) with an empty row, a self-loop and a hub
         const int64_t V = 6;
         const int32_t dd = 5;
         const int64_t rowptr[] = {0, 2, 2, 3, 8, 9, 10};
