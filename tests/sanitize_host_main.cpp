@@ -60,6 +60,19 @@ int main(int argc, char **argv) {
     CHECK(parse(dir, "a\nb", "a\tz", s, d, msg) == -3 && msg.find("'z'") != std::string::npos);
     CHECK(parse(dir, "a\na\nb", "a\tb", s, d, msg) == 1 && s[0] == 0);                          // first occurrence wins
     CHECK(parse(dir, "a", "", s, d, msg) == -2);                                               // empty E: one empty line
+    CHECK(parse(dir, "", "x\ty", s, d, msg) == -3);                                            // empty V file: one vertex named ""
+    CHECK(parse(dir, "", "\t", s, d, msg) == -2);                                              // E strips to one empty line
+    CHECK(parse(dir, "a\n\nb", "a\t\n\tb", s, d, msg) == 2 && d[0] == 1 && s[1] == 1 && d[1] == 2);   // the empty id
+    CHECK(parse(dir, "a b\nc", "a b\tc", s, d, msg) == 1 && s[0] == 0 && d[0] == 1);            // a space is part of an id
+    {                                                                                          // ids of 1..40 bytes (hash: 8-byte words + tail)
+        std::string v, e;
+        const int n = 41;
+        for (int i = 0; i < n; ++i) v += std::string(size_t(i + 1), char('a' + i % 26)) + "\n";
+        v += "last";
+        for (int i = 0; i < n; ++i) e += std::string(size_t(i + 1), char('a' + i % 26)) + "\tlast\n";
+        CHECK(parse(dir, v, e, s, d, msg) == n);
+        for (int i = 0; i < n; ++i) CHECK(s[size_t(i)] == i && d[size_t(i)] == n);
+    }
     {                                                                                          // big enough for 16 threads
         std::string v, e;
         const int n = 200000;
