@@ -40,6 +40,7 @@ class HostCSR:
     num_vertices: int
     rowptr: np.ndarray   # int64 [V+1]
     colidx: np.ndarray   # int32 [E]
+    _indeg: Optional[np.ndarray] = field(default=None, repr=False, compare=False)
 
     @property
     def num_edges(self) -> int:
@@ -49,7 +50,16 @@ class HostCSR:
         return np.diff(self.rowptr)
 
     def indeg(self) -> np.ndarray:
-        return np.bincount(self.colidx, minlength=self.num_vertices).astype(np.int32)
+        """In-degree of every vertex (int32 [V]), counted once (on the card when there is one: 40M edges take 0.1 s on
+        the host) and kept; the CSR is not meant to be edited afterwards."""
+        if self._indeg is None:
+            import torch
+            if self.colidx.size >= (1 << 22) and torch.cuda.is_available():
+                cols = torch.from_numpy(self.colidx).cuda()
+                self._indeg = torch.bincount(cols, minlength=self.num_vertices).to(torch.int32).cpu().numpy()
+            else:
+                self._indeg = np.bincount(self.colidx, minlength=self.num_vertices).astype(np.int32)
+        return self._indeg
 
     def live_mask(self) -> np.ndarray:
         """Rows that change during sweeps AND are read by some row: the only ones worth exchanging."""
