@@ -57,15 +57,21 @@ __device__ __forceinline__ A finalize_score(A dot, int mode, A D, A nsrc, const 
 // Scores of edges [ea, eb) of the row whose source is global row `src_row` (a whole row, or one
 // wave's slice of a long row).  `softmax`: [ea, eb) is a WHOLE row -- normalise it (in registers when it
 // fits one 64-edge chunk, else with a running max / sum and a second pass over the stored scores).
-// `stats` (a slice of a long row): leave the raw scores and hand back {max, sum of exp(score - max)} of the
-// slice, for the workgroup to combine.  Must be called by all 64 lanes.
+// `want_stats` (a slice of a long row): leave the raw scores and hand back {max, sum of exp(score - max)} of the
+// slice, for the workgroup to combine (returned by value: a pointer that may be null kept the pair in scratch).
+// Must be called by all 64 lanes.
+template <typename A>
+struct RangeStats {
+    A max, sum;
+};
+
 template <typename T, int VEC, int LPR, int U>
-__device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ colidx, int64_t ea, int64_t eb,
+__device__ __forceinline__ RangeStats<typename Elem<T>::acc_t> score_edge_range(const int32_t *__restrict__ colidx, int64_t ea, int64_t eb,
                                                  int64_t src_row, const T *__restrict__ Z, int64_t ldz, int d,
                                                  int mode, typename Elem<T>::acc_t D,
                                                  const typename Elem<T>::acc_t *__restrict__ sq,
                                                  typename Elem<T>::acc_t *__restrict__ scores, bool softmax,
-                                                 typename Elem<T>::acc_t *stats = nullptr) {
+                                                 bool want_stats = false) {
     using A = typename Elem<T>::acc_t;
     constexpr int EPW = kWave / LPR;
     constexpr bool kTransposed = (U == 8 && LPR >= 8);
@@ -145,7 +151,7 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
             const A got = lane_get(serve, src);
             if (take) mine = got;
         }
-        if (softmax || stats) {  // graph.py:122-123; running max / sum over the row's chunks (online softmax)
+        if (softmax || want_stats) {  // graph.py:122-123; running max / sum over the row's chunks (online softmax)
             const bool in = lane < n;
             const A v = in ? mine : -A(INFINITY);
             const A new_m = fmax(run_m, group_max<kWave>(v));
@@ -160,10 +166,7 @@ __device__ __forceinline__ void score_edge_range(const int32_t *__restrict__ col
     if (softmax && eb - ea > kWave) {  // second pass over this wave's own stores (each lane re-reads what it wrote)
         for (int64_t e = ea + lane; e < eb; e += kWave) scores[e] = exp_acc<A>(scores[e] - run_m) / run_s;
     }
-    if (stats) {
-        stats[0] = run_m;
-        stats[1] = run_s;
-    }
+    return RangeStats<A>{run_m, run_s};
 }
 
 template <typename A>
@@ -300,13 +303,12 @@ __global__ __launch_bounds__(WAVES *kWave) void edge_score_long_kernel(
     const A D = global_denominator<A>(mode, sums2);
     const bool whole_row_here = e1 - e0 <= kWave;
     const bool combine = fuse_softmax && !whole_row_here;
-    A stats[2];
-    score_edge_range<T, VEC, LPR, U>(colidx, a, b, row0 + r, Z, ldz, d, mode, D, sq, scores,
-                                     fuse_softmax && whole_row_here, combine ? stats : nullptr);
+    const RangeStats<A> stats = score_edge_range<T, VEC, LPR, U>(colidx, a, b, row0 + r, Z, ldz, d, mode, D, sq, scores,
+                                                                 fuse_softmax && whole_row_here, combine);
     if (!combine) return;
     if (lane_id() == 0) {
-        s_max[wave] = stats[0];
-        s_sum[wave] = stats[1];
+        s_max[wave] = stats.max;
+        s_sum[wave] = stats.sum;
     }
     __syncthreads();
     const int active = int(ceil_div(e1 - e0, seg));
@@ -341,13 +343,12 @@ __global__ __launch_bounds__(kBlock) void edge_score_class_kernel(
         const int64_t e0 = item_e0[base + cur];
         const int len = item_len[base + cur];
         if (len > 0) {
-            A st[2];
-            score_edge_range<T, VEC, LPR, U>(colidx, e0, e0 + len, row0 + item_row[base + cur], Z, ldz, d, mode, D, sq,
-                                             scores, false, stats ? st : nullptr);
+            const RangeStats<A> st = score_edge_range<T, VEC, LPR, U>(
+                colidx, e0, e0 + len, row0 + item_row[base + cur], Z, ldz, d, mode, D, sq, scores, false, stats != nullptr);
             if (stats && lane_id() == 0) {
                 const int64_t slot = item_slot[base + cur];
-                stats[2 * slot] = st[0];
-                stats[2 * slot + 1] = st[1];
+                stats[2 * slot] = st.max;
+                stats[2 * slot + 1] = st.sum;
             }
         }
         int v = 0;
