@@ -208,7 +208,8 @@ def main():
                          "order); pipelined (SURVEY H5): sweep t+1 is launched before the delta of sweep t is read -- every "
                          "delta is still read, one sweep later (SweepEngine.sweep_launch / sweep_wait; Embedder's "
                          "lagged_check, bit-identical results); auto (default) = what Embedder does by default: pipelined "
-                         "when a sweep is estimated below 1 ms (SweepEngine.estimated_sweep_seconds), else every-sweep")
+                         "when a sweep is estimated below 1 ms (2 ms at N > 1, where the scalar all-reduce adds to the round trip; "
+                         "SweepEngine.estimated_sweep_seconds), else every-sweep")
     ap.add_argument("--pipelined", action="store_true", help="same as --host-sync pipelined")
     ap.add_argument("--iterate", action="store_true",
                     help="after the timed sweeps also run the WHOLE algorithm from Z = X -- Embedder.iterate() to "
@@ -341,7 +342,10 @@ def main():
 
     if args.pipelined:
         args.host_sync = "pipelined"
-    pipelined = args.host_sync == "pipelined" or (args.host_sync == "auto" and eng.estimated_sweep_seconds() < 1e-3)
+    from clane_amd.embedder import Embedder
+    pipelined = args.host_sync == "pipelined" or (
+        args.host_sync == "auto" and eng.estimated_sweep_seconds() < (Embedder.LAGGED_BELOW_ESTIMATE_S if world > 1
+                                                                       else Embedder.LAGGED_BELOW_S))
     eng.time_kernels = True
     eng.kernel_events = []
     barrier()

@@ -23,6 +23,10 @@ from .similarity import CosineSimilarity, Similarity
 
 class Embedder(object):
     LAGGED_BELOW_S = 1e-3
+    # Several ranks decide by the engine's ESTIMATE of a sweep (gather-model bytes at the HBM peak), which measured
+    # sweeps undercut by cache hits (config 3: 0.65-0.85 of it at N = 1..8): 2 ms of estimate is ~1.3-1.7 ms of sweep,
+    # where the host round trip plus the scalar all-reduce (~50 us) is 3 % or more.
+    LAGGED_BELOW_ESTIMATE_S = 2e-3
 
     def __init__(
         self,
@@ -73,7 +77,7 @@ class Embedder(object):
         # bit-identical either way.  It costs one discarded sweep per propagate and saves the host round trip of
         # every sweep, so it pays when sweeps are short.  None (default): on one GPU, switched on inside a propagate
         # once a sweep has taken less than LAGGED_BELOW_S; on several GPUs, on when the engine's estimate of a sweep
-        # (the same number on every rank) is below it; True / False: always / never.  Off with save_history.
+        # (the same number on every rank) is below LAGGED_BELOW_ESTIMATE_S; True / False: always / never.  Off with save_history.
         self.lagged_check = lagged_check
         self.sweeps_launched = 0
         self._round_was_idle = False
@@ -167,7 +171,7 @@ class Embedder(object):
         if self.lagged_check is None and can_lag and world > 1 and hasattr(engine, "estimated_sweep_seconds"):
             # several ranks must decide alike, so not by a stopwatch: by the same estimate on every rank.  Lagging also
             # hides the latency of the per-sweep scalar all-reduce.
-            ahead = engine.estimated_sweep_seconds() < self.LAGGED_BELOW_S
+            ahead = engine.estimated_sweep_seconds() < self.LAGGED_BELOW_ESTIMATE_S
         fastest = math.inf                          # shortest synchronous sweep seen in this propagate (auto mode)
         ticket = None                               # the launched sweep whose delta has not been read yet
         if ahead and not idle:
