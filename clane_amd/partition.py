@@ -55,8 +55,11 @@ class HostCSR:
         if self._indeg is None:
             import torch
             if self.colidx.size >= (1 << 22) and torch.cuda.is_available():
-                cols = torch.from_numpy(self.colidx).cuda()
-                self._indeg = torch.bincount(cols, minlength=self.num_vertices).to(torch.int32).cpu().numpy()
+                total = torch.zeros(self.num_vertices, dtype=torch.int64, device="cuda")
+                for a in range(0, self.colidx.size, 1 << 28):            # pieces: bounded scratch on the card
+                    total += torch.bincount(torch.from_numpy(self.colidx[a:a + (1 << 28)]).cuda(),
+                                            minlength=self.num_vertices)
+                self._indeg = total.to(torch.int32).cpu().numpy()
             else:
                 self._indeg = np.bincount(self.colidx, minlength=self.num_vertices).astype(np.int32)
         return self._indeg
