@@ -5,6 +5,7 @@ mounted read-only at /root/reference; it never travels to the GPU box.  Only
 the resulting data (inputs + the reference's outputs) is committed.
 
     python oracle/make_goldens.py            # rewrites tests/golden/
+    CLANE_GOLDEN_OUT=/tmp/g python oracle/make_goldens.py    # elsewhere, e.g. to compare with the committed fixtures
 
 The reference needs one in-process alias to import under NumPy 2
 (``from numpy import Inf`` at clane/embedder.py:1): ``numpy.Inf = numpy.inf``.
@@ -22,7 +23,7 @@ from pathlib import Path
 import numpy as np
 
 REF = Path("/root/reference")
-OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+OUT = Path(os.environ.get("CLANE_GOLDEN_OUT") or Path(__file__).resolve().parent.parent / "tests" / "golden")
 
 
 def _import_reference():
