@@ -38,6 +38,9 @@
 #ifndef CLANE_SPMM_DYNAMIC
 #define CLANE_SPMM_DYNAMIC 1      // waves claim rows from an LDS counter (0: static interleave)
 #endif
+#ifndef CLANE_COMBINE_WAVES
+#define CLANE_COMBINE_WAVES 2     // waves that share the slots of one class row in spmm_class_combine_kernel (profiles/r02_ab_combine_waves.md)
+#endif
 #ifndef CLANE_SPMM_PREFETCH
 #define CLANE_SPMM_PREFETCH 1     // request the next row's colidx/P before gathering the current row
 #endif
@@ -675,37 +678,69 @@ __global__ __launch_bounds__(kBlock) void spmm_class_chunk_kernel(
     }
 }
 
-// One wave per class row: its slots summed in order, then  z = x + gamma * sum,  delta, store.
+// One workgroup of kCombineWaves waves per class row.  Wave w adds the w-th contiguous share of the row's slots IN ORDER;
+// wave 0 then adds the waves' sums in wave order (through LDS) and runs the usual epilogue:  z = x + gamma * sum,
+// delta, store.  The association is fixed by (slot count, kCombineWaves) alone -- reproducible, no atomics -- and a
+// heavy row's chain of dependent loads is a kCombineWaves-th of what one wave would walk (config 3's heaviest row:
+// 280 slots; the 2.4e9-edge test's hubs: 4 688).
+constexpr int kCombineWaves = CLANE_COMBINE_WAVES;
+
 template <typename T, int VEC>
-__global__ __launch_bounds__(kWave) void spmm_class_combine_kernel(
+__global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kernel(
     const int32_t *__restrict__ class_rows, const int64_t *__restrict__ slot_ptr, int64_t row0,
     const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
     Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
+    __shared__ A s_part[kCombineWaves > 1 ? kCombineWaves - 1 : 1][kWave][VEC];
     const int i = blockIdx.x;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int64_t r = class_rows[i];
     const int64_t s0 = slot_ptr[i], s1 = slot_ptr[i + 1];
+    const int64_t share = ceil_div(s1 - s0, int64_t(kCombineWaves));
+    const int64_t a = s0 + wave * share < s1 ? s0 + wave * share : s1;
+    const int64_t b = a + share < s1 ? a + share : s1;
     A rsum = A(0);
-    for (int t0 = 0; t0 < d; t0 += kWave * VEC) {
-        const int c0 = t0 + lane_id() * VEC;
-        if (c0 < d) {
-            const Pack<T, VEC> x = load_pack_stream<T, VEC>(X + r * ldx + c0);
-            const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
-            A acc[VEC];
+    for (int t0 = 0; t0 < d; t0 += kWave * VEC) {       // the same trip count in every wave (barriers inside)
+        const int c0 = t0 + lane * VEC;
+        const bool ok = c0 < d;
+        A acc[VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+        for (int k = 0; k < VEC; ++k) acc[k] = A(0);
+        if (ok) {
 #pragma unroll 4
-            for (int64_t s = s0; s < s1; ++s) {
+            for (int64_t s = a; s < b; ++s) {
                 const Pack<A, VEC> part = load_pack<A, VEC>(slab + s * ld_slab + c0);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] += part.v[k];
             }
+        }
+        if constexpr (kCombineWaves > 1) {
+            if (t0 > 0) __syncthreads();                 // wave 0 has read the previous pass's sums
+            if (wave > 0) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) s_part[wave - 1][lane][k] = acc[k];
+            }
+            __syncthreads();
+        }
+        if (wave == 0 && ok) {
+            if constexpr (kCombineWaves > 1) {
+#pragma unroll
+                for (int w = 1; w < kCombineWaves; ++w) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += s_part[w - 1][lane][k];
+                }
+            }
+            const Pack<T, VEC> x = load_pack_stream<T, VEC>(X + r * ldx + c0);
+            const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
             rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0);
         }
     }
-    rsum = group_sum<kWave>(rsum);
-    if (lane_id() == 0) partials[i] = double(rsum);
+    if (wave == 0) {
+        rsum = group_sum<kWave>(rsum);
+        if (lane == 0) partials[i] = double(rsum);
+    }
 }
 
 }  // namespace clane
