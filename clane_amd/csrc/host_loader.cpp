@@ -82,13 +82,47 @@ class FileText {
     std::string_view text_;
 };
 
-inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+// str.strip() without arguments removes every character with str.isspace(): the ASCII ones (\t \n \v \f \r,
+// 0x1c-0x1f, space) and, in UTF-8, U+0085, U+00A0, U+1680, U+2000-U+200A, U+2028, U+2029, U+202F, U+205F, U+3000.
+// Length in bytes of the whitespace character that STARTS at s[0] / ENDS at s[n-1], or 0.
+inline bool is_ascii_space(unsigned char c) { return (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x20); }
+
+inline bool is_space_2(unsigned char a, unsigned char b) {            // U+0085, U+00A0
+    return a == 0xc2 && (b == 0x85 || b == 0xa0);
+}
+
+inline bool is_space_3(unsigned char a, unsigned char b, unsigned char c) {
+    if (a == 0xe1) return b == 0x9a && c == 0x80;                                              // U+1680
+    if (a == 0xe2) {
+        if (b == 0x80) return (c >= 0x80 && c <= 0x8a) || c == 0xa8 || c == 0xa9 || c == 0xaf;  // U+2000-200A, 2028, 2029, 202F
+        return b == 0x81 && c == 0x9f;                                                          // U+205F
+    }
+    return a == 0xe3 && b == 0x80 && c == 0x80;                                                // U+3000
+}
+
+inline size_t space_at_front(std::string_view s) {
+    const auto u = [&](size_t i) { return static_cast<unsigned char>(s[i]); };
+    if (s.empty()) return 0;
+    if (is_ascii_space(u(0))) return 1;
+    if (s.size() >= 2 && is_space_2(u(0), u(1))) return 2;
+    if (s.size() >= 3 && is_space_3(u(0), u(1), u(2))) return 3;
+    return 0;
+}
+
+inline size_t space_at_back(std::string_view s) {
+    const size_t n = s.size();
+    const auto u = [&](size_t i) { return static_cast<unsigned char>(s[i]); };
+    if (n == 0) return 0;
+    if (is_ascii_space(u(n - 1))) return 1;
+    if (n >= 2 && is_space_2(u(n - 2), u(n - 1))) return 2;
+    if (n >= 3 && is_space_3(u(n - 3), u(n - 2), u(n - 1))) return 3;
+    return 0;
+}
 
 std::string_view stripped(std::string_view s) {
-    size_t a = 0, b = s.size();
-    while (a < b && is_space(s[a])) ++a;
-    while (b > a && is_space(s[b - 1])) --b;
-    return s.substr(a, b - a);
+    for (size_t k; (k = space_at_front(s)) != 0;) s.remove_prefix(k);
+    for (size_t k; (k = space_at_back(s)) != 0;) s.remove_suffix(k);
+    return s;
 }
 
 template <typename F>

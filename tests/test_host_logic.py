@@ -742,3 +742,32 @@ def test_host_native_code_is_clean_under_asan_and_ubsan():
     if "cannot find -ltsan" in run.stderr:
         pytest.skip("sanitizer runtimes not installed")
     assert run.returncode == 0 and run.stdout.count("sanitize_host: ok") == 2, run.stdout[-2000:] + run.stderr[-4000:]
+
+
+def test_native_loader_strips_what_python_strips(tmp_path):
+    """`read().strip()` (graph.py:44, :73) removes every str.isspace() character -- 0x1c-0x1f and the Unicode spaces
+    too, and a lone '\\r' reads as '\\n' -- while the same characters INSIDE the file stay part of the ids: the native
+    parser and the line-by-line Python restatement agree on 300 seeded files."""
+    import random
+    from clane_amd import graph as G
+    if G._host_lib() is None:
+        pytest.skip("libclane_host.so not built")
+    ws = [chr(c) for c in (9, 10, 11, 12, 13, 0x1c, 0x1d, 0x1e, 0x1f, 32, 0x85, 0xa0, 0x1680, 0x2000, 0x2003, 0x200a,
+                           0x2028, 0x2029, 0x202f, 0x205f, 0x3000)]
+    assert all(c.isspace() for c in ws)
+    rng = random.Random(0)
+    ids = ["a", "bé", "c c", "中", "e e", "　x"]
+    for trial in range(300):
+        pad = lambda n: "".join(rng.choice(ws) for _ in range(rng.randint(0, n)))      # noqa: E731
+        (tmp_path / "V").write_text(pad(3) + "\n".join(ids) + pad(3), encoding="utf-8", newline="")
+        (tmp_path / "E").write_text(pad(2) + "\n".join(f"{rng.choice(ids)}\t{rng.choice(ids)}" for _ in range(6)) + pad(2),
+                                    encoding="utf-8", newline="")
+        outcome = []
+        for parse in (lambda: G._python_parse_edges(tmp_path, G.read_vertex_ids(tmp_path)),
+                      lambda: G._native_parse_edges(tmp_path)):
+            try:
+                s, d = parse()
+                outcome.append((s.tolist(), d.tolist()))
+            except Exception as e:      # noqa: BLE001 -- both must fail alike (e.g. an id lost to the strip)
+                outcome.append(type(e).__name__)
+        assert outcome[0] == outcome[1], (trial, outcome)
