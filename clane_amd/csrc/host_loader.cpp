@@ -125,6 +125,40 @@ std::string_view stripped(std::string_view s) {
     return s;
 }
 
+// Is [p, p + n) well-formed UTF-8 (Python's strict decoder: no overlong forms, no surrogates, nothing above U+10FFFF)?
+// The files are read in text mode upstream, so anything else is a UnicodeDecodeError there.
+bool valid_utf8(const char *ptr, size_t n) {
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(ptr), *end = p + n;
+    while (p < end) {
+        if (end - p >= 8) {                                     // eight ASCII bytes at a time
+            uint64_t w;
+            std::memcpy(&w, p, 8);
+            if ((w & 0x8080808080808080ull) == 0) {
+                p += 8;
+                continue;
+            }
+        }
+        const unsigned char c = *p;
+        if (c < 0x80) {
+            ++p;
+        } else if (c >= 0xc2 && c <= 0xdf) {
+            if (end - p < 2 || (p[1] & 0xc0) != 0x80) return false;
+            p += 2;
+        } else if (c >= 0xe0 && c <= 0xef) {
+            if (end - p < 3 || (p[1] & 0xc0) != 0x80 || (p[2] & 0xc0) != 0x80) return false;
+            if ((c == 0xe0 && p[1] < 0xa0) || (c == 0xed && p[1] > 0x9f)) return false;      // overlong / surrogate
+            p += 3;
+        } else if (c >= 0xf0 && c <= 0xf4) {
+            if (end - p < 4 || (p[1] & 0xc0) != 0x80 || (p[2] & 0xc0) != 0x80 || (p[3] & 0xc0) != 0x80) return false;
+            if ((c == 0xf0 && p[1] < 0x90) || (c == 0xf4 && p[1] > 0x8f)) return false;      // overlong / beyond U+10FFFF
+            p += 4;
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+
 template <typename F>
 void for_each_line(std::string_view body, F &&f) {  // Python's str.split('\n'): n separators -> n+1 fields
     size_t pos = 0;
@@ -286,12 +320,16 @@ int64_t clane_count_lines(const char *path, char *err, int errlen) {
 }
 
 // src[k], dst[k] <- vertex indices of line k of E.  Returns the number of edges, or -1 (file error),
-// -2 (malformed line), -3 (unknown vertex id); err holds the message of the FIRST offending line.
+// -2 (malformed line), -3 (unknown vertex id), -4 (a file is not valid UTF-8: text mode upstream raises UnicodeDecodeError); err holds the message of the FIRST offending line.
 // The E file is cut at line boundaries and parsed by up to 16 threads (the id -> index map is read-only by then).
 int64_t clane_parse_edges(const char *v_path, const char *e_path, int64_t *src, int64_t *dst, int64_t capacity,
                           char *err, int errlen) {
     FileText v_file, e_file;
     if (!v_file.open(v_path, err, errlen) || !e_file.open(e_path, err, errlen)) return -1;
+    if (!valid_utf8(v_file.text().data(), v_file.text().size())) {
+        std::snprintf(err, errlen, "V is not valid UTF-8");
+        return -4;
+    }
     IdTable first;
     first.build(stripped(v_file.text()));
     const std::string_view body = stripped(e_file.text());
@@ -316,6 +354,10 @@ int64_t clane_parse_edges(const char *v_path, const char *e_path, int64_t *src, 
         Fail &fail = fails[size_t(t)];
         std::string_view part = body.substr(start[t], start[t + 1] - start[t]);
         if (t < pieces - 1) part.remove_suffix(1);           // the '\n' that ends the piece's last line
+        if (!valid_utf8(part.data(), part.size())) {         // pieces end at line ends: no character straddles two
+            fail = Fail{k, -4, "E is not valid UTF-8"};
+            return;
+        }
         // lines in batches: cut + hash + prefetch the whole batch, then resolve it (the table misses overlap)
         constexpr int kBatch = 16;
         struct Pending {
@@ -366,6 +408,12 @@ int64_t clane_parse_edges(const char *v_path, const char *e_path, int64_t *src, 
         });
         resolve();
     });
+    for (const Fail &f : fails) {                              // upstream decodes the whole file before it parses a line
+        if (f.status == -4) {
+            std::snprintf(err, errlen, "%s", f.msg.c_str());
+            return -4;
+        }
+    }
     for (const Fail &f : fails) {                              // pieces are in file order: the first failure wins
         if (f.status) {
             std::snprintf(err, errlen, "%s", f.msg.c_str());

@@ -96,8 +96,10 @@ def _native_parse_edges(data_root: Path):
     src = np.empty(n, dtype=np.int64)
     dst = np.empty(n, dtype=np.int64)
     got = lib.clane_parse_edges(v_path, e_path, src.ctypes.data, dst.ctypes.data, n, err, len(err))
+    if got == -4:           # not valid UTF-8: the Python loop opens the files in text mode and raises what upstream raises
+        return None
     if got in (-2, -3):
-        raise ValueError(err.value.decode())
+        raise ValueError(err.value.decode(errors="replace"))
     if got < 0:
         raise OSError(err.value.decode())
     return src[:got], dst[:got]

@@ -62,6 +62,10 @@ int main(int argc, char **argv) {
     CHECK(parse(dir, "a", "", s, d, msg) == -2);                                               // empty E: one empty line
     CHECK(parse(dir, "\x1c\xc2\xa0 a\nb\xe3\x80\x80\xe2\x80\xa8", "\xc2\x85" "a\tb\xe2\x81\x9f\x1f", s, d, msg) == 1 && s[0] == 0 && d[0] == 1);  // Unicode spaces around the files
     CHECK(parse(dir, "a\xc2\xa0" "b\nc", "a\xc2\xa0" "b\tc", s, d, msg) == 1 && s[0] == 0 && d[0] == 1);   // ... and inside an id
+    CHECK(parse(dir, "a\nb", "a\tb\nb\t\xff", s, d, msg) == -4);                                // not UTF-8: upstream's text mode raises
+    CHECK(parse(dir, "a\n\xed\xa0\x80", "a\ta", s, d, msg) == -4);                              // a surrogate in V
+    CHECK(parse(dir, "a\nb", "zz\tb\nb\t\xc0\xaf", s, d, msg) == -4);                          // decoding fails before any line is parsed
+    CHECK(parse(dir, "\xf0\x9f\x98\x80\nb", "\xf0\x9f\x98\x80\tb", s, d, msg) == 1 && s[0] == 0);  // 4-byte characters are fine
     CHECK(parse(dir, "", "x\ty", s, d, msg) == -3);                                            // empty V file: one vertex named ""
     CHECK(parse(dir, "", "\t", s, d, msg) == -2);                                              // E strips to one empty line
     CHECK(parse(dir, "a\n\nb", "a\t\n\tb", s, d, msg) == 2 && d[0] == 1 && s[1] == 1 && d[1] == 2);   // the empty id

@@ -771,3 +771,20 @@ def test_native_loader_strips_what_python_strips(tmp_path):
             except Exception as e:      # noqa: BLE001 -- both must fail alike (e.g. an id lost to the strip)
                 outcome.append(type(e).__name__)
         assert outcome[0] == outcome[1], (trial, outcome)
+
+
+def test_files_that_are_not_utf8_raise_what_text_mode_raises(tmp_path):
+    """Upstream opens V and E in text mode (graph.py:43, :72): bytes that are not UTF-8 are a UnicodeDecodeError before
+    any line is looked at.  The native parser recognises them and leaves the raising to the Python loop."""
+    from clane_amd import graph as G
+    (tmp_path / "V").write_bytes(b"a\nb\nc")
+    (tmp_path / "E").write_bytes(b"zz\tb\nb\t\xff\n")            # line 1 has an unknown id, line 2 a bad byte
+    with pytest.raises(UnicodeDecodeError):
+        G.read_edge_indices(tmp_path, G.read_vertex_ids(tmp_path))
+    (tmp_path / "E").write_bytes(b"a\tb\nb\t\xed\xa0\x80\n")      # a UTF-16 surrogate: overlong / surrogate forms are errors too
+    with pytest.raises(UnicodeDecodeError):
+        G.read_edge_indices(tmp_path, G.read_vertex_ids(tmp_path))
+    (tmp_path / "V").write_text("é\n中\n😀\nz", encoding="utf-8")
+    (tmp_path / "E").write_text("é\t😀\n中\tz", encoding="utf-8")
+    src, dst = G.read_edge_indices(tmp_path, G.read_vertex_ids(tmp_path))
+    assert src.tolist() == [0, 1] and dst.tolist() == [2, 3]
