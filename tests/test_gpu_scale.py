@@ -410,6 +410,8 @@ def test_workgroups_are_dealt_to_the_xcds_round_robin(dev, k):
     runs on XCD (w + c) % 8, c the same for the whole launch (it carries over from the dispatches before, so it is
     not always 0) -- for small and large grids, 64 to 1024 threads per workgroup, on the default and a side stream.
     All chunks of one class then share one L2 and the eight classes use eight different ones."""
+    if torch.cuda.get_device_properties(dev).multi_processor_count != 256:
+        pytest.skip("not the 8-XCD / 256-CU partition the class pass is tuned for (results do not depend on it)")
     side = torch.cuda.Stream(dev)
     rotations = set()
     for n, threads in ((8, 64), (64, 256), (2048, 256), (100_000, 256), (20_001, 1024), (333_333, 64)):
