@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", nargs="+", default=["rmat200k", "rmat2m", "powerlaw10m"])
 ap.add_argument("--sweeps", type=int, default=60)
 ap.add_argument("--repeats", type=int, default=4)
+ap.add_argument("--cols", type=int, default=None, help="only the first COLS columns of X (a column slice: narrower-row kernels)")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
 ok = True
@@ -22,6 +23,8 @@ for w in args.workload:
     gen, V, E, d, dname, gseed, xseed = bench.WORKLOADS[w]
     csr = synth.rmat_csr(V, E, seed=gseed, device=str(dev)) if gen == "rmat" else synth.powerlaw_csr(V, E, seed=gseed, device=str(dev))
     X = synth.gaussian_X(V, d, seed=xseed).to(bench.DTYPES[dname])
+    if args.cols:
+        X = X[:, :args.cols].contiguous()
     eng = SweepEngine(csr, X, dev)
     runs = []
     t0 = time.perf_counter()
@@ -35,7 +38,7 @@ for w in args.workload:
         runs.append((p_hash, [float.hex(x) for x in deltas], z_hash))
     same = all(r == runs[0] for r in runs)
     ok = ok and same
-    print(json.dumps({"workload": w, "dtype": dname, "sweeps": args.sweeps, "repeats": args.repeats, "bit_identical": same,
+    print(json.dumps({"workload": w, "dtype": dname, "d": int(X.shape[1]), "sweeps": args.sweeps, "repeats": args.repeats, "bit_identical": same,
                       "P_sha": runs[0][0], "Z_sha": runs[0][2], "last_delta": float.fromhex(runs[0][1][-1]),
                       "seconds": round(time.perf_counter() - t0, 1)}), flush=True)
     del eng
