@@ -120,7 +120,7 @@ class SweepEngine:
                  exchange: str = "auto", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
-                 phase_threshold: int = PHASE_THRESHOLD):
+                 phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
@@ -369,6 +369,13 @@ class SweepEngine:
         if self.device.type == "cuda":
             self._delta_host = self._delta_host.pin_memory()
             self._delta_ev = [torch.cuda.Event() for _ in range(2)]
+        # delta_stream (several ranks, opt-in): the delta's all-reduce and host copy run on a stream of their own, so a
+        # sweep launched ahead does not queue behind RCCL's latency.  With ONE rank (no xGMI hop) the extra event costs
+        # what it saves (profiles/r02_delta_stream_ab.md); to be decided on a real multi-GPU box.
+        self._delta_stream = None
+        self._delta_busy = [False, False]
+        if self.device.type == "cuda" and (self.world > 1 or self._forced) and delta_stream:
+            self._delta_stream = torch.cuda.Stream(self.device)
         self.block_out = torch.zeros(len(self.blocks), dtype=torch.float64, device=dev)
         self.sq_loc = torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev)
         self.sq_full: Optional[torch.Tensor] = None
@@ -677,6 +684,9 @@ class SweepEngine:
             raise RuntimeError("sweep() before build_P()")
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
         parity = self.cur
+        if self._delta_stream is not None and self._delta_busy[parity]:
+            torch.cuda.current_stream(self.device).wait_event(self._delta_ev[parity])   # its last all-reduce has read delta_pp[parity]
+            self._delta_busy[parity] = False
         key = (parity, float(gamma), stream)
         plan = self._plans.get(key)
         if plan is None:
@@ -715,12 +725,25 @@ class SweepEngine:
                 main.wait_event(done)
         final()
         mine = self.delta_pp[parity:parity + 1]
-        self._all_reduce(mine)
         for w in works:
             w.wait()
-        self._delta_host[parity:parity + 1].copy_(mine, non_blocking=True)
-        if self._delta_ev is not None:
-            self._delta_ev[parity].record()
+        if self._delta_stream is not None:
+            # the scalar all-reduce and the copy of the delta leave the sweep's stream: the next sweep (launched ahead
+            # by the lagged check) does not queue behind RCCL's latency.  delta_pp[parity] is next written two sweeps
+            # on; sweep_launch makes that sweep wait for this event first.
+            reduced = torch.cuda.Event()
+            reduced.record()
+            with torch.cuda.stream(self._delta_stream):
+                self._delta_stream.wait_event(reduced)
+                self._all_reduce(mine)
+                self._delta_host[parity:parity + 1].copy_(mine, non_blocking=True)
+                self._delta_ev[parity].record()
+            self._delta_busy[parity] = True
+        else:
+            self._all_reduce(mine)
+            self._delta_host[parity:parity + 1].copy_(mine, non_blocking=True)
+            if self._delta_ev is not None:
+                self._delta_ev[parity].record()
         self.cur = 1 - self.cur
         self.sweeps_done += 1
         self.quiet_stale = True

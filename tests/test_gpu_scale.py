@@ -331,6 +331,21 @@ def test_rccl_single_rank_group_drives_the_engine_collectives(dev):
             assert eng.comm.calls["all_reduce"] >= 3
             if exchange != "columns":
                 assert eng.comm.calls["all_gather"] >= 9                    # 3 chunks x 3 sweeps
+        # delta_stream (opt-in): the scalar all-reduce on a stream of its own, sweeps launched one ahead -- same bits
+        runs = []
+        for own in (False, True):
+            eng = SweepEngine(csr, X, dev, comm=TorchComm(pg, force_collectives=True), exchange="columns", delta_stream=own)
+            assert (eng._delta_stream is not None) == own
+            eng.build_P()
+            ticket, deltas = eng.sweep_launch(gamma), []
+            for _ in range(11):
+                ahead = eng.sweep_launch(gamma)
+                deltas.append(eng.sweep_wait(ticket))
+                ticket = ahead
+            deltas.append(eng.sweep_wait(ticket))
+            runs.append((deltas, eng.get_Z()))
+            assert eng.comm.calls["all_reduce"] >= 12
+        assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
     finally:
         dist.destroy_process_group()
 
