@@ -34,6 +34,7 @@ SIGNATURES = {
     "clane_last_error": (C.c_char_p, []),
     "clane_build_info": (C.c_char_p, []),
     "clane_xcc_ids": (C.c_int, [_p, _i64, _i32, _p]),
+    "clane_check_csr": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "clane_spmm_partials_len": (_i64, [_i64, _i64]),
     "clane_reduce_ws_len": (_i64, []),
     "clane_reduce_partials": (C.c_int, [_p, _i64, _p, _p, _p]),
@@ -292,6 +293,20 @@ class HipKernels:
         out = torch.full((n_blocks,), -1, dtype=torch.int32, device=device if device is not None else "cuda")
         self._check(self.lib.clane_xcc_ids(out.data_ptr(), n_blocks, block_threads, self._stream(out)), "clane_xcc_ids")
         return out
+
+    def check_csr(self, rowptr: torch.Tensor, colidx: torch.Tensor, nrows: int, n_edges: int, table_rows: int) -> None:
+        """Raise ValueError unless rowptr[0..nrows] is non-decreasing within [0, n_edges] and colidx[:n_edges] holds
+        rows of a table of ``table_rows`` rows (one pass on the device; blocks until it is done)."""
+        if rowptr.dtype != torch.int64 or colidx.dtype != torch.int32 or rowptr.numel() < nrows + 1 or colidx.numel() < n_edges:
+            raise ValueError("check_csr: rowptr must be int64 [nrows + 1], colidx int32 [n_edges]")
+        status = torch.zeros(1, dtype=torch.int32, device=rowptr.device)
+        self._check(self.lib.clane_check_csr(rowptr.data_ptr(), colidx.data_ptr(), nrows, n_edges, table_rows,
+                                             status.data_ptr(), self._stream(rowptr)), "clane_check_csr")
+        bad = int(status.item())
+        if bad:
+            what = [w for bit, w in ((1, "rowptr is not a non-decreasing sequence within [0, n_edges]"),
+                                     (2, f"colidx holds entries outside [0, {table_rows})")) if bad & bit]
+            raise ValueError("the CSR handed to the kernels is not valid: " + "; ".join(what))
 
     def build_info(self) -> str:
         return self.lib.clane_build_info().decode()

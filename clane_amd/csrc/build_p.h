@@ -304,4 +304,22 @@ __global__ void xcc_ids_kernel(int32_t *__restrict__ out) {
     if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
 }
 
+// Validates what every gather kernel takes on trust: rowptr[0..nrows] non-decreasing within [0, n_edges] and every
+// colidx[e] a row of the table.  status[0] |= 1: a bad rowptr entry, |= 2: a column out of range.  (A kernel that
+// gathers through a bad index faults the GPU -- on this pool that can reset every GPU of the host.)
+__global__ void check_csr_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows,
+                                 int64_t n_edges, int64_t table_rows, int32_t *__restrict__ status) {
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    int bad = 0;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i <= nrows; i += stride) {
+        const int64_t a = rowptr[i];
+        if (a < 0 || a > n_edges || (i < nrows && rowptr[i + 1] < a)) bad |= 1;
+    }
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n_edges; e += stride) {
+        const int32_t c = colidx[e];
+        if (c < 0 || c >= table_rows) bad |= 2;
+    }
+    if (bad) atomicOr(status, bad);
+}
+
 }  // namespace clane

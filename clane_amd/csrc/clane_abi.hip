@@ -461,6 +461,17 @@ int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *s
     return check_launch("xcc_ids");
 }
 
+int clane_check_csr(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t n_edges, int64_t table_rows,
+                    int32_t *status, void *stream) {
+    if (!rowptr || !status || nrows < 0 || n_edges < 0 || table_rows < 0 || (n_edges > 0 && !colidx))
+        return fail(CLANE_ERR_INVALID_ARGUMENT, "check_csr: bad arguments");
+    const int64_t work = n_edges > nrows + 1 ? n_edges : nrows + 1;
+    const int64_t blocks = ceil_div(work, int64_t(kBlock) * 8);
+    check_csr_kernel<<<unsigned(blocks < 1 ? 1 : blocks > 65536 ? 65536 : blocks), kBlock, 0, (hipStream_t)stream>>>(
+        rowptr, colidx, nrows, n_edges, table_rows, status);
+    return check_launch("check_csr");
+}
+
 int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long) {
     return spmm_main_grid(nrows > 0 ? nrows : 1) + (n_long > 0 ? n_long : 0);
 }

@@ -135,6 +135,9 @@ class SweepEngine:
             raise ValueError(f"X must be [V, d] with V={csr.num_vertices}, got {tuple(X.shape)}")
         if cosine_mode not in ("reference", "per_edge"):
             raise ValueError(f"cosine_mode must be 'reference' or 'per_edge', got {cosine_mode!r}")
+        csr.validate()                      # before anything is uploaded or indexed on the device
+        if X.ndim != 2 or X.shape[0] != csr.num_vertices:
+            raise ValueError(f"X must be [V, d] with V = {csr.num_vertices}, got {tuple(X.shape)}")
         self.k = kernels if kernels is not None else _hip.kernels()
         self.device = torch.device(device)
         self.dtype = X.dtype
@@ -237,6 +240,9 @@ class SweepEngine:
             self.colidx = torch.zeros(1, dtype=torch.int32, device=dev)
         self.indeg = torch.from_numpy(self.local.indeg).to(dev)
         self.E_loc = int(self.local.colidx.shape[0])
+        # what every gather kernel takes on trust, checked once on the device (a bad index faults the GPU)
+        if hasattr(self.k, "check_csr"):
+            self.k.check_csr(self.rowptr, self.colidx, self.part.n_local, self.E_loc, self.part.padded_vertices)
         self.P = torch.zeros(max(self.E_loc, 1), dtype=self.acc_dtype, device=dev)
         self.P_valid = False
         deg = np.diff(self.local.rowptr)

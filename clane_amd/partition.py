@@ -46,6 +46,19 @@ class HostCSR:
     def num_edges(self) -> int:
         return int(self.colidx.shape[0])
 
+    def validate(self) -> None:
+        """ValueError unless this is a CSR the kernels can gather through: rowptr int64 [V + 1] from 0 to E,
+        non-decreasing; colidx int32 [E] within [0, V).  (Sortedness / uniqueness within a row is the loader's business:
+        ``graph.csr_from_edges``.)  On the host, before anything is uploaded: an index out of range on the device ends
+        the process at best."""
+        V, rp, ci = self.num_vertices, self.rowptr, self.colidx
+        if rp.dtype != np.int64 or ci.dtype != np.int32 or rp.shape != (V + 1,) or ci.ndim != 1:
+            raise ValueError("HostCSR: rowptr must be int64 [V + 1] and colidx int32 [E]")
+        if rp[0] != 0 or rp[-1] != ci.size or (V and bool((rp[1:] < rp[:-1]).any())):
+            raise ValueError("HostCSR: rowptr must rise from 0 to the number of edges")
+        if ci.size and (int(ci.min()) < 0 or int(ci.max()) >= V):
+            raise ValueError(f"HostCSR: colidx holds entries outside [0, {V})")
+
     def outdeg(self) -> np.ndarray:
         return np.diff(self.rowptr)
 

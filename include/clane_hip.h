@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CLANE_ABI_VERSION 2 /* 2: + clane_build_info, clane_xcc_ids, clane_spmm_update_class_*, clane_edge_score_class_* */
+#define CLANE_ABI_VERSION 2 /* 2: + clane_build_info, clane_xcc_ids, clane_check_csr, clane_spmm_update_class_*, clane_edge_score_class_* */
 
 #define CLANE_OK 0
 #define CLANE_ERR_INVALID_ARGUMENT (-1)
@@ -80,6 +80,13 @@ const char *clane_build_info(void);
  * block_threads threads ran on.  clane_spmm_update_class_* / clane_edge_score_class_* get their speed -- not their
  * results -- from workgroup w running on XCD (w + c) % 8 with c the same for the whole launch; the GPU test suite checks that with this call. */
 int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *stream);
+/* Validates on the device what every gather kernel below takes on trust -- call it once per graph before the first
+ * sweep: rowptr[0..nrows] must be non-decreasing within [0, n_edges], every colidx[e] (e < n_edges) a row of a table of
+ * table_rows rows.  *status (device int32, zeroed by the caller) gets bit 0 for a bad rowptr entry, bit 1 for a column
+ * out of range; nothing else is touched.  (The reference cannot go wrong here: torch.sparse validates its indices,
+ * graph.py:104-110.  A HIP kernel gathering through a bad index faults the GPU.) */
+int clane_check_csr(const int64_t *rowptr, const int32_t *colidx, int64_t nrows, int64_t n_edges, int64_t table_rows,
+                    int32_t *status, void *stream);
 
 /* Doubles written by clane_spmm_update_*(nrows) plus clane_spmm_update_long_*(n_long). */
 int64_t clane_spmm_partials_len(int64_t nrows, int64_t n_long);

@@ -17,6 +17,13 @@ def _np(t):
 
 
 class OracleKernels:
+    def check_csr(self, rowptr, colidx, nrows, n_edges, table_rows):
+        rp, ci = rowptr.cpu().numpy()[:nrows + 1], colidx.cpu().numpy()[:n_edges]
+        if rp[0] < 0 or rp[-1] > n_edges or (np.diff(rp) < 0).any():
+            raise ValueError("the CSR handed to the kernels is not valid: rowptr")
+        if n_edges and (ci.min() < 0 or ci.max() >= table_rows):
+            raise ValueError("the CSR handed to the kernels is not valid: colidx")
+
     def spmm_partials_len(self, nrows, n_long):
         return -(-max(nrows, 1) // 32) + n_long
 

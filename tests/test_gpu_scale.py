@@ -459,3 +459,39 @@ def test_class_items_in_pieces_on_the_card(dev, k, monkeypatch):
     pieces = xcd.class_items(*args, colidx_dev=eng.colidx, **kw)
     for name in whole:
         assert np.array_equal(whole[name], pieces[name]) and np.array_equal(whole[name], host[name]), name
+
+
+def test_check_csr_refuses_what_would_fault_the_gpu(dev, k):
+    """clane_check_csr: one pass on the device over rowptr / colidx before any kernel gathers through them.  A valid CSR
+    passes (also an empty one); a decreasing or out-of-range rowptr entry and a column outside the table are named; and
+    SweepEngine runs the check itself, so a bad CSR never reaches a gather kernel."""
+    csr = synth.rmat_csr(50_000, 1_000_000, seed=21, device=str(dev))
+    rp, ci = torch.from_numpy(csr.rowptr).to(dev), torch.from_numpy(csr.colidx).to(dev)
+    V, E = csr.num_vertices, csr.num_edges
+    k.check_csr(rp, ci, V, E, V)
+    k.check_csr(torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), 0, 0, 5)
+    with pytest.raises(ValueError, match="colidx holds entries outside"):
+        k.check_csr(rp, ci, V, E, V - 1 if int(ci.max()) == V - 1 else int(ci.max()))
+    bad = ci.clone()
+    bad[E // 2] = -1
+    with pytest.raises(ValueError, match="colidx"):
+        k.check_csr(rp, bad, V, E, V)
+    for where, value in ((V // 3, E + 7), (V // 2, -2), (V, E + 1)):
+        bad = rp.clone()
+        bad[where] = value
+        with pytest.raises(ValueError, match="rowptr"):
+            k.check_csr(bad, ci, V, E, V)
+    dec = rp.clone()
+    i = int(torch.nonzero(rp[1:] > rp[:-1])[5])
+    dec[i + 1] = dec[i] - 1 if int(dec[i]) > 0 else dec[i]
+    if int(dec[i + 1]) < int(dec[i]):
+        with pytest.raises(ValueError, match="rowptr"):
+            k.check_csr(dec, ci, V, E, V)
+    with pytest.raises(ValueError, match="int64"):
+        k.check_csr(rp.to(torch.int32), ci, V, E, V)
+    broken = HostCSR(V, csr.rowptr, csr.colidx.copy())
+    broken.colidx[123] = V + 5
+    with pytest.raises(ValueError, match="colidx holds entries outside"):     # on the host, before anything is uploaded
+        SweepEngine(broken, synth.gaussian_X(V, 16, seed=22), dev)
+    with pytest.raises(ValueError, match=r"X must be \[V, d\]"):
+        SweepEngine(csr, synth.gaussian_X(V - 1, 16, seed=22), dev)

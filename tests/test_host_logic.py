@@ -788,3 +788,21 @@ def test_files_that_are_not_utf8_raise_what_text_mode_raises(tmp_path):
     (tmp_path / "E").write_text("é\t😀\n中\tz", encoding="utf-8")
     src, dst = G.read_edge_indices(tmp_path, G.read_vertex_ids(tmp_path))
     assert src.tolist() == [0, 1] and dst.tolist() == [2, 3]
+
+
+def test_host_csr_validate():
+    """What SweepEngine checks on the host before anything is indexed on the device."""
+    from clane_amd.partition import HostCSR
+    good = HostCSR(3, np.array([0, 2, 2, 3], dtype=np.int64), np.array([1, 2, 0], dtype=np.int32))
+    good.validate()
+    HostCSR(1, np.array([0, 0], dtype=np.int64), np.empty(0, dtype=np.int32)).validate()
+    for rowptr, colidx, what in (([0, 2, 1, 3], [1, 2, 0], "rowptr"), ([1, 2, 2, 3], [1, 2, 0], "rowptr"),
+                                 ([0, 2, 2, 4], [1, 2, 0], "rowptr"), ([0, 2, 2, 3], [1, 3, 0], "colidx"),
+                                 ([0, 2, 2, 3], [1, -1, 0], "colidx")):
+        with pytest.raises(ValueError, match=what):
+            HostCSR(3, np.array(rowptr, dtype=np.int64), np.array(colidx, dtype=np.int32)).validate()
+    with pytest.raises(ValueError, match="int64"):
+        HostCSR(3, np.array([0, 2, 2, 3], dtype=np.int32), np.array([1, 2, 0], dtype=np.int32)).validate()
+    with pytest.raises(ValueError, match="colidx holds entries outside"):
+        SweepEngine(HostCSR(3, np.array([0, 2, 2, 3], dtype=np.int64), np.array([1, 7, 0], dtype=np.int32)),
+                    torch.zeros(3, 4), "cpu", kernels=object())
