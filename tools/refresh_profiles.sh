@@ -14,6 +14,7 @@ if [ "$PART" = pmc ] || [ "$PART" = all ]; then
   done
   tools/profile_bench.sh rmat200k $TAG --steps 100
   tools/profile_bench.sh powerlaw10m $TAG
+  tools/profile_bench.sh rmat16m $TAG --steps 8 --warmup 2
   cp "$P/traffic.json" "$R/profiles/traffic.json"      # the bench lines below quote it
 fi
 if [ "$PART" = bench ] || [ "$PART" = all ]; then
