@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
 """Headline benchmark: embedding-update sweeps/sec + achieved HBM GB/s of the K3 SpMM kernel.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload rmat2m|rmat200k|powerlaw10m|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--workload rmat2m|rmat200k|powerlaw10m|tiny]
 
 One "step" = one Jacobi sweep  Z <- X + gamma * P Z  over the whole graph, P frozen: the K3
 kernels, the deterministic L1-delta reduction, the host read-back of that scalar (the
 reference decides after every sweep, embedder.py:94-105) and, for N > 1, the all-reduce of that
 scalar.  Inputs are resident in HBM before the timed region.
 
+Timing protocol: W warm-up sweeps, then B blocks (default 5) of EXACTLY K sweeps, each block bracketed
+by a barrier + torch.cuda.synchronize() on both sides (host clock, MAX over ranks) and by a HIP event pair on the
+sweep's stream; `value` / `ms_per_step` are the MEDIAN block, `ms_per_step_min` / `_max` the spread.
+
 N > 1: one process per GPU over RCCL.  `python bench.py --gpus N` starts the N ranks itself (fresh child
 processes through torch.distributed.run, before this process has touched a GPU) and relays rank 0's JSON
 line; started under torchrun (WORLD_SIZE set) it is one of the ranks.  The graph is fixed and divided, so
 scaling is STRONG: by default every GPU sweeps d/N columns of all rows (no exchange per sweep);
 `--exchange allgather_all` is north_star's literal plan (rows divided, one in-place RCCL all-gather of the
-updated rows per sweep), `halo` / `halo_p2p` / `allgather` are the leaner row splits.  Rank 0 prints one JSON line.
+updated rows per sweep), `halo` / `halo_p2p` / `allgather` are the leaner row splits.  At N > 1 the record also
+carries a `comm` block (what RCCL saw, time inside the collectives) and -- `--also-exchange`, default
+allgather_all -- the same measurement of north_star's literal division in `north_star_literal`, so ONE record
+answers both "what scales" and "what north_star asked for".  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import socket
+import statistics
 import subprocess
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -38,17 +48,21 @@ WORKLOADS = {
     "rmat200k": ("rmat", 200_000, 4_000_000, 128, "f32", 1, 2),       # BASELINE config 2
     "powerlaw10m": ("powerlaw", 10_000_000, 200_000_000, 128, "bf16", 5, 6),   # BASELINE config 4 (shape)
     "tiny": ("rmat", 20_000, 200_000, 64, "f32", 7, 8),
+    "tiny16": ("rmat", 20_000, 200_000, 16, "f32", 7, 8),             # 4 packs a row: more ranks than packs leaves idle column ranks
     # 8x config 3: a 16 GiB embedding matrix (byte offsets beyond 32 bits, ~85 GB of HBM in use) -- capacity check
     "rmat16m": ("rmat", 16_000_000, 320_000_000, 256, "f32", 9, 10),
 }
 DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "f64": torch.float64}
 PARITY_TOL = {"f32": 1e-4, "f64": 1e-10, "bf16": 8e-3}       # bf16: 2^-8 rounding of every stored value
+PARITY_P_TOL = {"f32": 2e-6, "f64": 1e-12, "bf16": 1e-4}     # P itself (fp32 arithmetic on the stored values)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_NOTE = ("traffic = rocprofv3 FETCH_SIZE x calibrated factor + WRITE_SIZE per launch (separate --pmc passes, "
-                "profiles/); these counters sit on the L2's fabric side, so Infinity-Cache hits are counted as "
-                "traffic: frac = min(algorithmic, traffic) bytes / kernel time / 8 TB/s is an UPPER bound of the "
-                "HBM share, never quoted above the roof; achieved_algorithmic is the no-reuse gather model "
+TRAFFIC_NOTE = ("traffic = rocprofv3 FETCH_SIZE x calibrated factor + WRITE_SIZE per launch, taken in separate --pmc "
+                "passes of this same command (profiles/) and matched to the live run by kernel configuration: bytes "
+                "and time come from different runs; these counters sit on the L2's fabric side, so Infinity-Cache "
+                "hits are counted as traffic: frac = min(algorithmic, traffic) bytes / kernel time / 8 TB/s, capped "
+                "at 1, is an UPPER bound of the HBM share; achieved_algorithmic is the no-reuse gather model "
                 "(SURVEY 8d), which also counts L2 hits")
+LITERAL_DEADLINE_S = 600.0      # north_star_literal block: past this the main record is printed without it
 
 
 def log(msg):
@@ -70,8 +84,8 @@ def launch_ranks(n: int) -> int:
 
 
 def oracle_first_sweep(csr, X, P_host, gamma):
-    """The C oracle's first sweep from Z = X (oracle/clane_oracle.c); P from the GPU when given, else the oracle's
-    own build_P (graph.py:118-128).  Returns (Z1, seconds of the sweep, threads, the P used, X as fp32)."""
+    """The C oracle's first sweep from Z = X (oracle/clane_oracle.c); P from the oracle's own build_P
+    (graph.py:118-128) unless one is given.  Returns (Z1, seconds of the sweep, threads, the P used, X as fp32)."""
     from oracle import clane_oracle_c as OC
     Xf = X.float() if X.dtype != torch.float32 else X    # the oracle computes in fp32 on the (bf16-)rounded inputs
     if P_host is None:
@@ -82,15 +96,13 @@ def oracle_first_sweep(csr, X, P_host, gamma):
     return Z, time.perf_counter() - t0, OC.threads(), P_host.float(), Xf
 
 
-def cpu_baseline(csr, X, P_host, gamma, Z1_gpu, budget_s=15.0):
+def cpu_baseline(csr, Xf, P_host, gamma, Z1_oracle, first, budget_s=15.0):
     """The oracle's sweep timed on this box's host cores: the plain-C restatement (oracle/clane_oracle.c,
-    OpenMP over rows, same CSR / fp32) -- kind "port".  Also the parity check of the first GPU sweep."""
-    from oracle import clane_oracle as O
+    OpenMP over rows, same CSR / fp32) -- kind "port"."""
     from oracle import clane_oracle_c as OC
-    Z, first, threads, P_host, Xf = oracle_first_sweep(csr, X, P_host, gamma)     # warm-up, also the parity sweep
-    parity = O.rel_l2(Z1_gpu.float(), Z)
+    threads = OC.threads()
     n = int(max(1, min(20, budget_s // max(first, 1e-3))))
-    Za, Zb = Z.clone(), torch.empty_like(Z)
+    Za, Zb = Z1_oracle.clone(), torch.empty_like(Z1_oracle)
     t0 = time.perf_counter()
     for _ in range(n):
         Zb, _ = OC.sweep(csr.rowptr, csr.colidx, P_host, Xf, Za, gamma, out=Zb)
@@ -98,59 +110,76 @@ def cpu_baseline(csr, X, P_host, gamma, Z1_gpu, budget_s=15.0):
     per = (time.perf_counter() - t0) / n
     return {"value": 1.0 / per, "unit": "sweeps/s", "cores": threads, "kind": "port",
             "sample": f"{n} full sweeps of the same graph by oracle/clane_oracle.c (plain C, OpenMP over rows, "
-                      f"{threads} threads), P taken from the GPU build_P"}, parity, P_host, Xf
+                      f"{threads} threads), P from the oracle's own build_P (graph.py:118-128)"}
 
 
 def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=8.0):
-    """The PyTorch-CPU restatement SURVEY 8d names --  Z = X + gamma * torch.sparse.mm(P, Z)  plus the L1 delta,
-    as in oracle/clane_oracle.py:sweep -- on all host threads and on ONE thread.  A full sweep takes seconds to
-    minutes that way, so each figure is timed on a bounded SAMPLE of the workload, a seeded random 1/m of the rows
-    (same degree mix; every m-th row would not do: R-MAT's hubs sit on the ids with trailing zero bits), and scaled
-    by the share of the edges the sample holds."""
+    """The PyTorch-CPU restatement SURVEY 8d names --  Z = X + gamma * (P @ Z)  plus the L1 delta, as in
+    oracle/clane_oracle.py:sweep -- with P as a torch.sparse_csr_tensor (its CPU kernel is parallel over rows; the COO
+    form of torch.sparse.mm is not: 0.127 sweeps/s on 128 threads against 0.130 on one in round 2), on all host
+    threads and on ONE thread.  FULL sweeps (1 warm-up + up to 10 timed) when one fits the budget; else a bounded
+    SAMPLE of the workload, a seeded random 1/m of the rows (same degree mix; every m-th row would not do: R-MAT's hubs
+    sit on the ids with trailing zero bits), scaled by the share of the edges the sample holds -- `sample` says which."""
+    import warnings
     deg = np.diff(csr.rowptr)
     E, V = int(csr.rowptr[-1]), csr.num_vertices
     Z = Xf
     all_threads = torch.get_num_threads()
 
-    def timed(stride, threads, reps):
+    def timed(stride, threads, max_reps):
         rows = np.arange(V, dtype=np.int64) if stride == 1 else \
             np.sort(np.random.default_rng(stride).choice(V, size=max(1, V // stride), replace=False))
-        take = np.repeat(csr.rowptr[rows], deg[rows]) + (np.arange(int(deg[rows].sum())) -
-                                                         np.repeat(np.cumsum(deg[rows]) - deg[rows], deg[rows]))
-        idx = torch.stack([torch.from_numpy(np.repeat(np.arange(rows.size), deg[rows])),
-                           torch.from_numpy(csr.colidx[take].astype(np.int64))])
-        Ps = torch.sparse_coo_tensor(idx, P_host[torch.from_numpy(take)], size=(rows.size, V), is_coalesced=True)
+        if stride == 1:
+            crow, cols, vals = csr.rowptr, csr.colidx, P_host
+        else:
+            take = np.repeat(csr.rowptr[rows], deg[rows]) + (np.arange(int(deg[rows].sum())) -
+                                                             np.repeat(np.cumsum(deg[rows]) - deg[rows], deg[rows]))
+            crow = np.concatenate([[0], np.cumsum(deg[rows])])
+            cols, vals = csr.colidx[take], P_host[torch.from_numpy(take)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                    # "Sparse CSR tensor support is in beta state"
+            Ps = torch.sparse_csr_tensor(torch.from_numpy(np.asarray(crow, dtype=np.int64)),
+                                         torch.from_numpy(np.asarray(cols).astype(np.int64)), vals, size=(rows.size, V))
         rows_t = torch.from_numpy(rows)
-        Xs, Zs = Xf[rows_t], Z[rows_t]
+        Xs, Zs = (Xf, Z) if stride == 1 else (Xf[rows_t], Z[rows_t])
         sink = torch.from_numpy(deg[rows] == 0)
+        n_edges = int(deg[rows].sum())
         torch.set_num_threads(threads)
         try:
-            best = float("inf")
-            for _ in range(reps + 1):                          # first pass = warm-up
+            times = []
+            spent = 0.0
+            for i in range(max_reps + 1):                      # first pass = warm-up
                 t0 = time.perf_counter()
-                Zn = Xs + gamma * torch.sparse.mm(Ps, Z)
+                Zn = Xs + gamma * (Ps @ Z)
                 Zn[sink] = Zs[sink]
                 (Zn - Zs).abs().sum()
-                best = min(best, time.perf_counter() - t0)
+                dt = time.perf_counter() - t0
+                spent += dt
+                if i:
+                    times.append(dt)
+                if i >= 1 and spent + dt > budget_s:
+                    break
         finally:
             torch.set_num_threads(all_threads)
-        share = take.size / max(E, 1)
-        return best / share, share, rows.size
+        share = n_edges / max(E, 1)
+        return min(times) / share, share, rows.size, len(times)
 
-    # size the samples from one small probe so that each figure costs a few seconds at most
-    probe, share, _ = timed(max(1, V // 20_000), all_threads, 1)
-    stride_all = max(1, int(np.ceil(probe * 3 / budget_s)))     # warm-up + 2 timed passes within the budget
-    per_all, share_all, n_all = timed(stride_all, all_threads, 2)
-    probe1, _, _ = timed(max(1, V // 5_000), 1, 1)
-    stride_1 = max(1, int(np.ceil(probe1 * 2 / budget_s)))
-    per_1, share_1, n_1 = timed(stride_1, 1, 1)
+    def figure(threads, probe_rows):
+        probe, _, _, _ = timed(max(1, V // probe_rows), threads, 1)           # a small probe sizes the sample
+        stride = 1 if probe * 3 <= budget_s else max(2, int(np.ceil(probe * 3 / budget_s)))
+        per, share, n_rows, reps = timed(stride, threads, 10 if stride == 1 else 2)
+        what = (f"{reps} full sweeps (after 1 warm-up), best" if stride == 1 else
+                f"a random 1/{stride} of the rows ({n_rows} rows, {share:.1%} of the edges), best of {reps}, scaled to a "
+                f"whole sweep")
+        return per, what
+
+    per_all, what_all = figure(all_threads, 20_000)
+    per_1, what_1 = figure(1, 5_000)
     return {"value": 1.0 / per_all, "unit": "sweeps/s", "cores": all_threads, "kind": "port",
-            "sample": f"X + gamma*torch.sparse.mm(P, Z) + L1 delta (oracle/clane_oracle.py:sweep) on a random "
-                      f"1/{stride_all} of the rows ({n_all} rows, {share_all:.1%} of the edges), best of 2, scaled to a whole "
-                      f"sweep; torch {torch.__version__}, {all_threads} threads",
+            "sample": f"X + gamma*(P @ Z) + L1 delta with P a torch.sparse_csr_tensor (oracle/clane_oracle.py:sweep): "
+                      f"{what_all}; torch {torch.__version__}, {all_threads} threads",
             "one_thread": {"value": 1.0 / per_1, "unit": "sweeps/s", "cores": 1,
-                           "sample": f"the same on a random 1/{stride_1} of the rows ({n_1} rows, {share_1:.2%} of the edges), "
-                                     f"torch.set_num_threads(1)"}}
+                           "sample": f"the same with torch.set_num_threads(1): {what_1}"}}
 
 
 def traffic_entry(workload: str, world: int, eng, dom: str, slice_of=None):
@@ -178,11 +207,14 @@ def traffic_entry(workload: str, world: int, eng, dom: str, slice_of=None):
     return got, (entry.get("source") if got is not None else f"{key}: kernel {dom} not in the measurement")
 
 
-def main():
+def make_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="timed blocks of --steps sweeps each (SURVEY 8d: median of 5); the JSON line reports the median "
+                         "block and the spread")
     ap.add_argument("--workload", default="rmat2m", choices=sorted(WORKLOADS))
     ap.add_argument("--gamma", type=float, default=0.76)
     ap.add_argument("--chunks", type=int, default=None)
@@ -199,6 +231,12 @@ def main():
                          "plan: rows divided, one in-place RCCL all-gather of the updated rows per sweep; allgather = "
                          "the same for the live rows only; halo / halo_p2p = rows sent only to the ranks that read "
                          "them (clane_amd/halo.py, partition.py; DESIGN.md section 6)")
+    ap.add_argument("--also-exchange", default="allgather_all",
+                    choices=["none", "columns", "halo", "halo_p2p", "allgather", "allgather_all"],
+                    help="N > 1: after the main division's timed blocks, rebuild the engine with THIS division and report "
+                         "its sweeps/s, parity and collective time in `north_star_literal` (default allgather_all = "
+                         "north_star's row partition + one all-gather per sweep; skipped when it is the main division; "
+                         "none = off)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -222,8 +260,283 @@ def main():
                          "(what every rank of `--gpus N` does); for profiling that rank's kernels, not a headline number")
     ap.add_argument("--calibrate", action="store_true",
                     help="also launch l1_distance over two [V,d] matrices (known bytes) -- PMC calibration")
-    args = ap.parse_args()
+    return ap
 
+
+class Ranks:
+    """The process group as bench.py uses it (a no-op on one GPU)."""
+
+    def __init__(self, world, rank, dev, pg):
+        self.world, self.rank, self.dev, self.pg = world, rank, dev, pg
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        t = torch.tensor(list(values), dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def gather_objects(self, obj):
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def agree_to_fail(self, failed: bool) -> bool:
+        """True on EVERY rank when any rank says so (one scalar all-reduce): a failed check on rank 0 must not leave
+        the others inside a collective until the launcher tears them down."""
+        return self.max_over_ranks([1.0 if failed else 0.0])[0] > 0
+
+
+def generate_input(args, ranks: Ranks):
+    """The synthetic graph + content embeddings, the same on every rank."""
+    import torch.distributed as dist
+    from clane_amd import synth
+    gen, V, E, d, dname, gseed, xseed = WORKLOADS[args.workload]
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
+    if os.environ.get("CLANE_BENCH_PERTURB_RANK") == str(rank) and world > 1:
+        gseed += 1000           # test hook: this rank draws a different graph, the agreement check must repair it
+    make = (lambda: synth.rmat_csr(V, E, seed=gseed, device=str(dev))) if gen == "rmat" else \
+           (lambda: synth.powerlaw_csr(V, E, seed=gseed, device=str(dev)))
+    if world > 1 and args.share_gpu:
+        # Rehearsal with every rank on ONE card: the generator's rocPRIM sort / unique kernels (decoupled look-back:
+        # workgroups spin on their predecessors) crawl when several processes run them on a time-sliced GPU -- four
+        # ranks sat in torch.unique for minutes at config 3 (round 2, gpurun_out/final/bench_n4.err).  One rank at
+        # a time, the others wait at a barrier on the host.
+        csr = None
+        for turn in range(world):
+            if turn == rank:
+                csr = make()
+                torch.cuda.synchronize()
+            dist.barrier()
+    else:
+        csr = make()
+    X = synth.gaussian_X(V, d, seed=xseed).to(DTYPES[dname])
+    if args.column_slice_of:
+        if world != 1:
+            raise SystemExit("--column-slice-of is a one-GPU rehearsal")
+        from clane_amd.engine import column_slice
+        c0, c1 = column_slice(d, X.dtype, args.column_slice_of, 0)
+        X = X[:, c0:c1].contiguous()
+    if world > 1:       # every rank generated the graph on its own GPU from the same seed: make sure they agree
+        mine = (csr.num_edges, int(csr.colidx.astype(np.int64).sum()), int(csr.rowptr[::997].sum()),
+                float(X[::9973].double().sum()))
+        everyone = ranks.gather_objects(mine)
+        if any(e != everyone[0] for e in everyone):
+            # should not happen (counter-based RNG, same seed, same GPU model); if it does, rank 0's input wins
+            log(f"ranks disagree on the synthetic input ({everyone}): broadcasting rank 0's graph and X")
+            from clane_amd.partition import HostCSR
+            n_edges = torch.tensor([csr.num_edges], dtype=torch.int64, device=dev)
+            dist.broadcast(n_edges, 0)
+            rp = torch.from_numpy(csr.rowptr).to(dev)
+            ci = torch.from_numpy(csr.colidx).to(dev) if rank == 0 else torch.empty(int(n_edges), dtype=torch.int32,
+                                                                                    device=dev)
+            Xd = X.to(dev)
+            for t in (rp, ci, Xd):
+                dist.broadcast(t, 0)
+            csr, X = HostCSR(V, rp.cpu().numpy(), ci.cpu().numpy()), Xd.cpu()
+    return csr, X
+
+
+def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bool):
+    """Engine for `exchange`, build_P (timed on its second call), the parity sweep, warm-up, and the timed blocks.
+    Returns a dict of everything measured (every rank gets the same numbers where they are reduced)."""
+    from clane_amd.embedder import Embedder
+    from clane_amd.engine import SweepEngine
+    world, rank, dev = ranks.world, ranks.rank, ranks.dev
+    t0 = time.perf_counter()
+    eng = SweepEngine(csr, X, dev, process_group=ranks.pg, chunks=args.chunks, long_threshold=args.long_threshold,
+                      hub_threshold=args.hub_threshold, exchange=exchange,
+                      hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs,
+                      class_threshold=args.class_threshold, class_chunk=args.class_chunk)
+    torch.cuda.synchronize()
+    log(f"engine up in {time.perf_counter() - t0:.1f}s ({eng.exchange}); rank rows={eng.part.n_local} edges={eng.E_loc} "
+        f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
+        f"hub(16 waves)={sum(0 if l is None else l.numel() for l in eng.hub_rows)} "
+        f"split={sum(0 if l is None else l[0].numel() for l in eng.split_rows)} "
+        f"class={sum(0 if l is None else l[0].numel() for l in eng.class_rows)} "
+        f"thresholds {eng.long_threshold}/{eng.hub_threshold}")
+
+    # build_P once (timed separately, not part of a step), P frozen afterwards
+    eng.build_P()                      # first call loads the code objects; time the second
+    ranks.barrier()
+    t0 = time.perf_counter()
+    eng.build_P()
+    torch.cuda.synchronize()
+    build_p_ms = ranks.max_over_ranks([(time.perf_counter() - t0) * 1e3])[0]
+
+    out = {"eng": eng, "build_P_ms": build_p_ms, "calibration_bytes": None, "Z1": None}
+    if args.calibrate:      # known-size streaming read in this library's own 16 B/lane access pattern
+        eng.snapshot()
+        eng.distance_from_snapshot()
+        out["calibration_bytes"] = 2 * eng.part.n_local * eng.ld * eng.Zcur.element_size()    # l1_distance reads two matrices
+    if not args.no_parity:              # the sweep the oracle is checked against (Z = X before it); collective
+        eng.sweep(args.gamma)
+        Z1 = eng.get_Z()
+        out["Z1"] = Z1 if rank == 0 else None
+    for _ in range(args.warmup):
+        eng.sweep(args.gamma)
+
+    host_sync = "pipelined" if args.pipelined else args.host_sync
+    pipelined = host_sync == "pipelined" or (
+        host_sync == "auto" and eng.estimated_sweep_seconds() < (Embedder.LAGGED_BELOW_ESTIMATE_S if world > 1
+                                                                  else Embedder.LAGGED_BELOW_S))
+    out["pipelined"], out["host_sync"] = pipelined, host_sync
+    eng.time_kernels = time_kernels
+    eng.kernel_events = []
+    eng.time_collectives = world > 1
+    eng.collective_events = []
+    wall, local_wall, hip_ms = [], [], []
+    delta = float("nan")
+    for _ in range(max(1, args.blocks)):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        if pipelined:
+            ticket = eng.sweep_launch(args.gamma)
+            for _ in range(args.steps - 1):
+                following = eng.sweep_launch(args.gamma)
+                delta = eng.sweep_wait(ticket)
+                ticket = following
+            delta = eng.sweep_wait(ticket)
+        else:
+            for _ in range(args.steps):
+                delta = eng.sweep(args.gamma)
+        ev1.record()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        ranks.barrier()
+        elapsed = time.perf_counter() - t0
+        wall.append(ranks.max_over_ranks([elapsed])[0])
+        local_wall.append(mine)
+        hip_ms.append(ev0.elapsed_time(ev1))
+    eng.time_kernels = eng.time_collectives = False
+    med = statistics.median(wall)
+    out.update({
+        "delta": delta, "elapsed": med, "value": args.steps / med, "ms_per_step": med / args.steps * 1e3,
+        "ms_per_step_min": min(wall) / args.steps * 1e3, "ms_per_step_max": max(wall) / args.steps * 1e3,
+        "block_ms_per_step": [w / args.steps * 1e3 for w in wall],
+        "ms_per_step_hip_events": ranks.max_over_ranks([statistics.median(hip_ms) / args.steps])[0],
+        "ktimes": eng.kernel_times_ms() if time_kernels else {}, "ctimes": eng.collective_times_ms(),
+        # this rank's own clock, before the closing barrier: the spread over the ranks says who waits for whom
+        "rank_ms_per_step": ranks.gather_objects(statistics.median(local_wall) / args.steps * 1e3),
+    })
+    return out
+
+
+def comm_block(args, ranks: Ranks, m) -> dict:
+    """What a reader of an N > 1 record must be able to check: which backend, how many ranks and which devices the
+    process group really had, what a rank receives per sweep and how long the sweep's stream spends in collectives."""
+    import torch.distributed as dist
+    eng, dev = m["eng"], ranks.dev
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": ranks.rank, "device": str(dev), "name": props.name,
+            "pci_bus_id": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:"
+                          f"{getattr(props, 'pci_device_id', 0):02x}",
+            "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+            "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", "all"))}
+    devices = ranks.gather_objects(mine)
+    recv = ranks.gather_objects(int(eng.exchange_bytes_per_sweep()))
+    per_rank = m["rank_ms_per_step"]
+    c = m["ctimes"]
+    collective = ranks.max_over_ranks([c.get("exchange_exposed", 0.0) + c.get("allreduce", 0.0),
+                                       c.get("exchange_exposed", 0.0), c.get("allreduce", 0.0)])
+    return {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+            "distinct_devices": len({(d_["uuid"], d_["pci_bus_id"]) for d_ in devices}), "devices": devices,
+            "shared_gpu_rehearsal": bool(args.share_gpu), "exchange": eng.exchange,
+            "exchange_bytes_per_sweep": max(recv), "exchange_bytes_per_sweep_by_rank": recv,
+            "collective_ms_per_sweep": collective[0],
+            "collective_detail": {"exchange_exposed_ms": collective[1], "allreduce_ms": collective[2],
+                                  "sweeps_timed": c.get("sweeps_timed", 0),
+                                  "how": "HIP events on the sweep's stream, max over ranks: the wait for the row "
+                                         "exchange still outstanding once the rank's own kernels are done (what the "
+                                         "per-chunk overlap did not hide) + the all-reduce of the delta scalar"},
+            "ms_per_step_by_rank": per_rank, "ms_per_step_rank_min": min(per_rank), "ms_per_step_rank_max": max(per_rank),
+            "collectives_issued": dict(eng.comm.calls) if hasattr(eng.comm, "calls") else None}
+
+
+def describe_parallelism(args, world, eng, X, E) -> str:
+    chunks = len(eng.blocks)
+    if args.column_slice_of:
+        return (f"REHEARSAL on 1 GPU of one rank of the column split x{args.column_slice_of}: columns "
+                f"[0:{X.shape[1]}) of X and Z, whole graph; not a headline number")
+    if world == 1:
+        return f"1 GPU, {chunks} launch block(s)/sweep"
+    if eng.columns:
+        return (f"column split x{world}: every GPU holds the whole graph and columns [{eng.col0}:{eng.col1}) "
+                f"(rank 0) of X and Z; no exchange per sweep, one scalar all-reduce (RCCL); build_P all-reduces "
+                f"the {E} partial dot products")
+    how = ("stored by the producing kernels straight into the readers' tables (hipIpc peer mappings)" if eng.p2p
+           else f"exchange={eng.exchange} over RCCL per chunk")
+    return (f"row split x{world}, {chunks} launch block(s)/sweep, {how} "
+            f"({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep) + scalar all-reduce")
+
+
+def roofline_block(args, world, m) -> dict:
+    """Roofline of the DOMINANT K3 kernel (largest share of the sweep), from HIP events recorded on the launch stream
+    inside the timed region.  One launch of each kernel per chunk, so per-launch bytes = that kernel's algorithmic
+    bytes per sweep / chunks (SURVEY.md section 8d gather model).  The fraction is quoted from the SMALLER of
+    (algorithmic, measured) bytes and never above the roof, so that cache hits cannot inflate it."""
+    eng, ktimes = m["eng"], m["ktimes"]
+    chunks = len(eng.blocks)          # launches of each kernel per sweep
+    kbytes = eng.kernel_bytes()
+    per_kernel = {}
+    names = eng.kernel_names()
+    for key, ms in ktimes.items():
+        if kbytes[key] > 0 and ms > 0:       # ms = per sweep, summed over the blocks
+            per_kernel[names[key]] = {"avg_launch_ms": ms / chunks,
+                                      "algorithmic_bytes_per_launch": kbytes[key] / chunks,
+                                      "achieved_algorithmic": kbytes[key] / (ms * 1e-3) / 1e9}
+    if not per_kernel:                       # a rank without columns (d < N packs) launches nothing
+        return {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 0.0,
+                "traffic": None, "note": "rank 0 holds no columns of this matrix: no kernel to time",
+                "kernel_config": eng.kernel_config()}
+    dom = max(per_kernel, key=lambda n: per_kernel[n]["avg_launch_ms"])
+    pass_ms = sum(ktimes.values())
+    pass_bytes = sum(kbytes.values())
+    pass_traffic = 0.0
+    for name, pk in per_kernel.items():
+        tr, why = traffic_entry(args.workload, world, eng, name, args.column_slice_of)
+        alg = pk["algorithmic_bytes_per_launch"]
+        pk["traffic"] = tr
+        counted = min(alg, tr) if tr is not None else alg
+        pk["achieved"] = min(counted / (pk["avg_launch_ms"] * 1e-3) / 1e9, HBM_PEAK_GBPS)
+        pk["frac"] = pk["achieved"] / HBM_PEAK_GBPS
+        pk["traffic_over_algorithmic"] = None if tr is None else tr / alg
+        if tr is None:
+            pk["traffic_missing"] = why
+        pass_traffic = None if (tr is None or pass_traffic is None) else pass_traffic + tr * chunks
+    pass_counted = min(pass_bytes, pass_traffic) if pass_traffic is not None else pass_bytes
+    pass_rate = min(pass_counted / (pass_ms * 1e-3) / 1e9, HBM_PEAK_GBPS)
+    pd = per_kernel[dom]
+    note = TRAFFIC_NOTE if pd["traffic"] is not None else (
+        f"no valid PMC traffic for this configuration ({pd['traffic_missing']}): frac is the algorithmic rate, capped "
+        f"at the roof -- rates above 8 TB/s mean rows served from L2 / the Infinity Cache, not HBM")
+    return {"bound": "hbm", "kernel": dom, "achieved": pd["achieved"], "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": pd["frac"], "traffic": pd["traffic"],
+            "traffic_source": None if pd["traffic"] is None else
+            "separate --pmc runs of this command (profiles/traffic.json), not the timed run",
+            "achieved_algorithmic": pd["achieved_algorithmic"],
+            "traffic_over_algorithmic": pd["traffic_over_algorithmic"],
+            "algorithmic_bytes_per_launch": pd["algorithmic_bytes_per_launch"],
+            "avg_launch_ms": pd["avg_launch_ms"], "note": note, "kernels": per_kernel,
+            "k3_pass": {"algorithmic_bytes": pass_bytes, "traffic": pass_traffic, "ms": pass_ms,
+                        "achieved": pass_rate, "frac": pass_rate / HBM_PEAK_GBPS,
+                        "achieved_algorithmic": pass_bytes / (pass_ms * 1e-3) / 1e9},
+            "kernel_config": eng.kernel_config()}
+
+
+def main():
+    args = make_parser().parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher: be the launcher
         raise SystemExit(launch_ranks(args.gpus))
     if os.environ.get("CLANE_BENCH_WATCHDOG_S"):                # debugging aid: every rank dumps its stack every S seconds
@@ -231,8 +544,7 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["CLANE_BENCH_WATCHDOG_S"]), repeat=True, file=sys.stderr)
 
     import torch.distributed as dist
-    from clane_amd import _hip, synth
-    from clane_amd.engine import SweepEngine
+    from clane_amd import _hip
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -251,222 +563,86 @@ def main():
     torch.cuda.set_device(dev)
     pg = None
     if world > 1:
+        # rank 0 spends seconds in the CPU oracle while the others wait inside a collective: well within this
+        patience = datetime.timedelta(minutes=30)
         if args.backend == "nccl":
             try:
-                dist.init_process_group("nccl", device_id=dev)
+                dist.init_process_group("nccl", device_id=dev, timeout=patience)
             except dist.DistBackendError:
                 if masked:      # RCCL refuses two ranks on one device: most likely a one-GPU box, not a masking launcher
                     print(f"[bench] rank {rank}: RCCL could not start with {world} ranks and ONE visible GPU; to rehearse "
                           f"the N > 1 flow on a one-GPU box use --backend gloo --share-gpu", file=sys.stderr)
                 raise
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=patience)
         pg = dist.group.WORLD
+    ranks = Ranks(world, rank, dev, pg)
 
-    gen, V, E, d, dname, gseed, xseed = WORKLOADS[args.workload]
-    if os.environ.get("CLANE_BENCH_PERTURB_RANK") == str(rank) and world > 1:
-        gseed += 1000           # test hook: this rank draws a different graph, the agreement check must repair it
+    gen, V, _, d, dname, gseed, xseed = WORKLOADS[args.workload]
     t0 = time.perf_counter()
-    if gen == "rmat":
-        csr = synth.rmat_csr(V, E, seed=gseed, device=str(dev))
-    else:
-        csr = synth.powerlaw_csr(V, E, seed=gseed, device=str(dev))
+    csr, X = generate_input(args, ranks)
     E = csr.num_edges
-    X = synth.gaussian_X(V, d, seed=xseed).to(DTYPES[dname])
-    if args.column_slice_of:
-        if world != 1:
-            raise SystemExit("--column-slice-of is a one-GPU rehearsal")
-        from clane_amd.engine import column_slice
-        c0, c1 = column_slice(d, X.dtype, args.column_slice_of, 0)
-        X = X[:, c0:c1].contiguous()
-    if world > 1:       # every rank generated the graph on its own GPU from the same seed: make sure they agree
-        mine = (E, int(csr.colidx.astype(np.int64).sum()), int(csr.rowptr[::997].sum()), float(X[::9973].double().sum()))
-        everyone = [None] * world
-        dist.all_gather_object(everyone, mine)
-        if any(e != everyone[0] for e in everyone):
-            # should not happen (counter-based RNG, same seed, same GPU model); if it does, rank 0's input wins
-            log(f"ranks disagree on the synthetic input ({everyone}): broadcasting rank 0's graph and X")
-            from clane_amd.partition import HostCSR
-            n_edges = torch.tensor([csr.num_edges], dtype=torch.int64, device=dev)
-            dist.broadcast(n_edges, 0)
-            rp = torch.from_numpy(csr.rowptr).to(dev)
-            ci = torch.from_numpy(csr.colidx).to(dev) if rank == 0 else torch.empty(int(n_edges), dtype=torch.int32,
-                                                                                    device=dev)
-            Xd = X.to(dev)
-            for t in (rp, ci, Xd):
-                dist.broadcast(t, 0)
-            csr, X = HostCSR(V, rp.cpu().numpy(), ci.cpu().numpy()), Xd.cpu()
-            E = csr.num_edges
-    log(f"{args.workload}: |V|={V} |E|={csr.num_edges} d={d} max outdeg={int(np.diff(csr.rowptr).max())} "
+    log(f"{args.workload}: |V|={V} |E|={E} d={d} max outdeg={int(np.diff(csr.rowptr).max())} "
         f"generated in {time.perf_counter() - t0:.1f}s")
 
-    t0 = time.perf_counter()
-    eng = SweepEngine(csr, X, dev, process_group=pg, chunks=args.chunks, long_threshold=args.long_threshold,
-                      hub_threshold=args.hub_threshold, exchange=args.exchange,
-                      hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs,
-                      class_threshold=args.class_threshold, class_chunk=args.class_chunk)
-    torch.cuda.synchronize()
-    log(f"engine up in {time.perf_counter() - t0:.1f}s; rank rows={eng.part.n_local} edges={eng.E_loc} "
-        f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
-        f"hub(16 waves)={sum(0 if l is None else l.numel() for l in eng.hub_rows)} "
-        f"split={sum(0 if l is None else l[0].numel() for l in eng.split_rows)} "
-        f"class={sum(0 if l is None else l[0].numel() for l in eng.class_rows)} "
-        f"thresholds {eng.long_threshold}/{eng.hub_threshold}")
-
-    # build_P once (timed separately, not part of a step), P frozen afterwards
-    eng.build_P()                      # first call loads the code objects; time the second
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.build_P()
-    torch.cuda.synchronize()
-    build_p_ms = (time.perf_counter() - t0) * 1e3
-
-    calibration_bytes = None
-    if args.calibrate:      # known-size streaming read in this library's own 16 B/lane access pattern
-        eng.snapshot()
-        eng.distance_from_snapshot()
-        calibration_bytes = 2 * eng.part.n_local * eng.ld * eng.Zcur.element_size()    # l1_distance reads two matrices
-    Z1 = None
-    if not args.no_parity:              # the sweep the oracle is checked against (Z = X before it); collective
-        eng.sweep(args.gamma)
-        Z1 = eng.get_Z()
-        if rank != 0:
-            Z1 = None
-    for _ in range(args.warmup):
-        eng.sweep(args.gamma)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if args.pipelined:
-        args.host_sync = "pipelined"
-    from clane_amd.embedder import Embedder
-    pipelined = args.host_sync == "pipelined" or (
-        args.host_sync == "auto" and eng.estimated_sweep_seconds() < (Embedder.LAGGED_BELOW_ESTIMATE_S if world > 1
-                                                                       else Embedder.LAGGED_BELOW_S))
-    eng.time_kernels = True
-    eng.kernel_events = []
-    barrier()
-    t0 = time.perf_counter()
-    if pipelined:
-        ticket = eng.sweep_launch(args.gamma)
-        for _ in range(args.steps - 1):
-            following = eng.sweep_launch(args.gamma)
-            delta = eng.sweep_wait(ticket)
-            ticket = following
-        delta = eng.sweep_wait(ticket)
-    else:
-        for _ in range(args.steps):
-            delta = eng.sweep(args.gamma)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    eng.time_kernels = False
-    ktimes = eng.kernel_times_ms()
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-
-    # Roofline of the DOMINANT K3 kernel (largest share of the sweep), from HIP events recorded on the
-    # launch stream inside the timed region.  One launch of each kernel per chunk, so per-launch
-    # bytes = that kernel's algorithmic bytes per sweep / chunks (SURVEY.md section 8d gather model).
-    # the fraction is quoted from the SMALLER of (algorithmic, measured) bytes, so that cache hits
-    # cannot inflate it.
-    chunks = len(eng.blocks)          # launches of each kernel per sweep
-    kbytes = eng.kernel_bytes()
-    per_kernel = {}
-    KERNEL_NAMES = eng.kernel_names()
-    for key, ms in ktimes.items():
-        if kbytes[key] > 0 and ms > 0:       # ms = per sweep, summed over the blocks
-            gbps = kbytes[key] / (ms * 1e-3) / 1e9
-            per_kernel[KERNEL_NAMES[key]] = {"avg_launch_ms": ms / chunks,
-                                             "algorithmic_bytes_per_launch": kbytes[key] / chunks,
-                                             "achieved_algorithmic": gbps}
-    dom = max(per_kernel, key=lambda n: per_kernel[n]["avg_launch_ms"])
-    pass_ms = sum(ktimes.values())
-    pass_bytes = sum(kbytes.values())
-    pass_traffic = 0.0
-    for name, pk in per_kernel.items():
-        tr, why = traffic_entry(args.workload, world, eng, name, args.column_slice_of)
-        alg = pk["algorithmic_bytes_per_launch"]
-        pk["traffic"] = tr
-        counted = min(alg, tr) if tr is not None else alg
-        rate = counted / (pk["avg_launch_ms"] * 1e-3) / 1e9
-        pk["achieved"] = min(rate, HBM_PEAK_GBPS) if tr is None else rate
-        pk["frac"] = pk["achieved"] / HBM_PEAK_GBPS
-        pk["traffic_over_algorithmic"] = None if tr is None else tr / alg
-        if tr is None:
-            pk["traffic_missing"] = why
-        pass_traffic = None if (tr is None or pass_traffic is None) else pass_traffic + tr * chunks
-    pass_counted = min(pass_bytes, pass_traffic) if pass_traffic is not None else pass_bytes
-    pass_rate = pass_counted / (pass_ms * 1e-3) / 1e9
-    if pass_traffic is None:
-        pass_rate = min(pass_rate, HBM_PEAK_GBPS)
-    pd = per_kernel[dom]
-    note = TRAFFIC_NOTE if pd["traffic"] is not None else (
-        f"no valid PMC traffic for this configuration ({pd['traffic_missing']}): frac is the algorithmic rate, capped "
-        f"at the roof -- rates above 8 TB/s mean rows served from L2 / the Infinity Cache, not HBM")
-
-    if args.column_slice_of:
-        parallelism = (f"REHEARSAL on 1 GPU of one rank of the column split x{args.column_slice_of}: columns "
-                       f"[0:{X.shape[1]}) of X and Z, whole graph; not a headline number")
-    elif world == 1:
-        parallelism = f"1 GPU, {chunks} launch block(s)/sweep"
-    elif eng.columns:
-        parallelism = (f"column split x{world}: every GPU holds the whole graph and columns [{eng.col0}:{eng.col1}) "
-                       f"(rank 0) of X and Z; no exchange per sweep, one scalar all-reduce (RCCL); build_P all-reduces "
-                       f"the {E} partial dot products")
-    else:
-        how = ("stored by the producing kernels straight into the readers' tables (hipIpc peer mappings)" if eng.p2p
-               else f"exchange={eng.exchange} over RCCL per chunk")
-        parallelism = (f"row split x{world}, {chunks} launch block(s)/sweep, {how} "
-                       f"({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep) + scalar all-reduce")
+    m = measure_division(args, ranks, csr, X, args.exchange, time_kernels=True)
+    eng = m["eng"]
     result = {
         "metric": "embedding-update iters/sec (Jacobi sweeps of Z <- X + gamma*P*Z, P frozen)",
-        "value": args.steps / elapsed, "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "value": m["value"], "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": dname, "data": "synthetic",
+        "blocks": max(1, args.blocks), "ms_per_step_min": m["ms_per_step_min"], "ms_per_step_max": m["ms_per_step_max"],
+        "block_ms_per_step": m["block_ms_per_step"], "ms_per_step_hip_events": m["ms_per_step_hip_events"],
+        "timing": f"{args.warmup} warm-up sweeps, then {max(1, args.blocks)} blocks of exactly {args.steps} sweeps, each "
+                  f"bracketed by barrier + torch.cuda.synchronize() (host clock, max over ranks) and by a HIP event pair on "
+                  f"the sweep's stream (ms_per_step_hip_events); value / ms_per_step = the median block",
         "config": {"workload": f"{'R-MAT' if gen == 'rmat' else 'power-law'} |V|={V} |E|={E} d={d} {dname}, "
                                f"gamma={args.gamma}, CosineSimilarity "
                                f"(reference mode), seeds {gseed}/{xseed}",
-                   "parallelism": parallelism,
-                   "host_sync": (f"pipelined ({args.host_sync}): the delta of sweep t is read while sweep t+1 runs"
-                                 if pipelined else f"after every sweep ({args.host_sync}; the reference's order)")},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": pd["achieved"], "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": pd["frac"], "traffic": pd["traffic"],
-                     "achieved_algorithmic": pd["achieved_algorithmic"],
-                     "traffic_over_algorithmic": pd["traffic_over_algorithmic"],
-                     "algorithmic_bytes_per_launch": pd["algorithmic_bytes_per_launch"],
-                     "avg_launch_ms": pd["avg_launch_ms"], "note": note, "kernels": per_kernel,
-                     "k3_pass": {"algorithmic_bytes": pass_bytes, "traffic": pass_traffic, "ms": pass_ms,
-                                 "achieved": pass_rate, "frac": pass_rate / HBM_PEAK_GBPS,
-                                 "achieved_algorithmic": pass_bytes / (pass_ms * 1e-3) / 1e9},
-                     "kernel_config": eng.kernel_config()},
-        "build_P_ms": build_p_ms, "last_delta": delta,
+                   "parallelism": describe_parallelism(args, world, eng, X, E),
+                   "host_sync": (f"pipelined ({m['host_sync']}): the delta of sweep t is read while sweep t+1 runs"
+                                 if m["pipelined"] else f"after every sweep ({m['host_sync']}; the reference's order)")},
+        "roofline": roofline_block(args, world, m),
+        "build_P_ms": m["build_P_ms"], "last_delta": m["delta"],
     }
-    if calibration_bytes is not None:
-        result["calibration"] = {"kernel": "l1_distance_kernel", "bytes_read": calibration_bytes}
-    if Z1 is not None:              # rank 0: the first sweep against the C oracle -- at any N
-        from oracle import clane_oracle as O
-        if world == 1 and not args.no_cpu_baseline:
-            base, parity, P_host, Xf = cpu_baseline(csr, X, eng.P_global(), args.gamma, Z1)
-            result["cpu_baseline"] = base
-            result["cpu_baseline_torch"] = cpu_baseline_torch(csr, Xf, P_host, args.gamma)
-        else:                       # P from the oracle's own build_P when the ranks hold only their rows of it
-            if world > 1:           # torchrun gives every rank OMP_NUM_THREADS=1; the others are idle at the barrier now
-                from oracle import clane_oracle_c as OC
+    if m["calibration_bytes"] is not None:
+        result["calibration"] = {"kernel": "l1_distance_kernel", "bytes_read": m["calibration_bytes"]}
+    if world > 1:
+        result["comm"] = comm_block(args, ranks, m)
+
+    # ---- parity: the first GPU sweep (and P itself) against the C oracle, which builds its OWN P -------------
+    Z1_oracle = None
+    failed = False
+    if not args.no_parity:
+        P_gpu = eng.P_global() if (world == 1 or eng.columns) else None     # row splits: each rank holds its rows of P
+        if rank == 0:
+            from oracle import clane_oracle as O
+            from oracle import clane_oracle_c as OC
+            if world > 1:           # torchrun gives every rank OMP_NUM_THREADS=1; the others are idle in the collective below
                 OC.set_threads(os.cpu_count() or 1)
-            P_host = eng.P_global() if (world == 1 or eng.columns) else None
-            Zo, _, _, _, _ = oracle_first_sweep(csr, X, P_host, args.gamma)
-            parity = O.rel_l2(Z1.float(), Zo)
-        result["parity_rel_l2_vs_oracle_after_1_sweep"] = parity
-        if not parity < PARITY_TOL[dname]:
-            print(json.dumps(result), flush=True)
-            raise SystemExit(f"parity check failed: rel-L2 {parity}")
+            Z1_oracle, first, _, P_oracle, Xf = oracle_first_sweep(csr, X, None, args.gamma)
+            parity = O.rel_l2(m["Z1"].float(), Z1_oracle)
+            result["parity_rel_l2_vs_oracle_after_1_sweep"] = parity
+            result["parity_note"] = ("first sweep from Z = X on the GPU(s), P from the GPU build_P, against "
+                                     "oracle/clane_oracle.c running its own build_P and sweep")
+            failed = not parity < PARITY_TOL[dname]
+            if P_gpu is not None:
+                parity_p = O.rel_l2(P_gpu.float(), P_oracle)
+                result["parity_P_rel_l2_vs_oracle"] = parity_p
+                failed = failed or not parity_p < PARITY_P_TOL[dname]
+            if world == 1 and not args.no_cpu_baseline and not failed:
+                result["cpu_baseline"] = cpu_baseline(csr, Xf, P_oracle, args.gamma, Z1_oracle, first)
+                result["cpu_baseline_torch"] = cpu_baseline_torch(csr, Xf, P_oracle, args.gamma)
+        failed = ranks.agree_to_fail(failed)
+        if failed:                  # every rank leaves, non-zero, together
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(f"parity check failed: {result.get('parity_rel_l2_vs_oracle_after_1_sweep')} "
+                             f"(P: {result.get('parity_P_rel_l2_vs_oracle')})")
+
     if args.iterate:
         from clane_amd.embedder import Embedder
         from clane_amd.graph import Graph
@@ -476,10 +652,10 @@ def main():
         g._attach_engine(eng)
         emb = Embedder(g, CosineSimilarity(), dev, gamma=args.gamma, tolerence=args.tolerence, verbose=False,
                        max_sweeps=2000)
-        barrier()
+        ranks.barrier()
         t0 = time.perf_counter()
         emb.iterate()
-        barrier()
+        ranks.barrier()
         wall = time.perf_counter() - t0
         result["iterate"] = {"wall_s": wall, "outer_rounds": len(emb.sweep_counts), "sweeps": sum(emb.sweep_counts),
                              "sweeps_launched": emb.sweeps_launched,
@@ -489,11 +665,64 @@ def main():
                                      "stopping rule (embedder.py:56-108); sweeps whose delta is provably 0 (after an "
                                      "exactly-zero delta with P frozen) are counted, not launched; not part of the "
                                      "headline value"}
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+
+    # ---- north_star's literal division beside the default one, in the same record -----------------------------
+    printed = threading.Event()
+    lock = threading.Lock()
+
+    def emit():
+        with lock:
+            if not printed.is_set():
+                printed.set()
+                if rank == 0:
+                    print(json.dumps(result), flush=True)
+
+    if world > 1 and args.also_exchange not in ("none", eng.exchange):
+        # Whatever happens in here, the main record above must come out: past the deadline every rank prints /
+        # leaves on its own (a rank stuck in a collective cannot be talked to).
+        def give_up():
+            result["north_star_literal"] = {"exchange": args.also_exchange, "error": f"no result within "
+                                            f"{LITERAL_DEADLINE_S:.0f} s: printed without it"}
+            emit()
+            os._exit(0)
+        timer = threading.Timer(LITERAL_DEADLINE_S, give_up)
+        timer.daemon = True
+        timer.start()
+        block = {"exchange": args.also_exchange}
+        try:
+            del m["eng"]
+            m2 = measure_division(args, ranks, csr, X, args.also_exchange, time_kernels=False)
+            e2 = m2["eng"]
+            block.update({
+                "what": ("north_star's division: node rows of Z partitioned across the GPUs, every GPU holds the full Z, "
+                         "ONE in-place RCCL all-gather of the updated rows per sweep (per launch chunk, overlapped with "
+                         "the next chunk's kernels)" if args.also_exchange == "allgather_all" else
+                         f"the same graph divided with exchange={args.also_exchange}"),
+                "value": m2["value"], "unit": "sweeps/s", "ms_per_step": m2["ms_per_step"],
+                "ms_per_step_min": m2["ms_per_step_min"], "ms_per_step_max": m2["ms_per_step_max"],
+                "ms_per_step_hip_events": m2["ms_per_step_hip_events"], "steps": args.steps, "blocks": max(1, args.blocks),
+                "build_P_ms": m2["build_P_ms"], "last_delta": m2["delta"],
+                "parallelism": describe_parallelism(args, world, e2, X, E),
+                "host_sync": "pipelined" if m2["pipelined"] else "after every sweep",
+                "vs_main_division": m2["value"] / m["value"], "comm": comm_block(args, ranks, m2)})
+            bad = False
+            if rank == 0 and Z1_oracle is not None and m2["Z1"] is not None:
+                from oracle import clane_oracle as O
+                block["parity_rel_l2_vs_oracle_after_1_sweep"] = O.rel_l2(m2["Z1"].float(), Z1_oracle)
+                bad = not block["parity_rel_l2_vs_oracle_after_1_sweep"] < PARITY_TOL[dname]
+            if ranks.agree_to_fail(bad):
+                block["error"] = "parity check failed"
+                failed = True
+        except Exception as exc:            # noqa: BLE001 -- reported in the record; the main measurement stands
+            block["error"] = f"{type(exc).__name__}: {exc}"
+        timer.cancel()
+        result["north_star_literal"] = block
+    emit()
     if world > 1:
         dist.barrier()              # leave together
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("north_star_literal: parity check failed")
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@ from the tensor dtype.  Work is enqueued on torch's current HIP stream.
 """
 from __future__ import annotations
 
+import abc
 import ctypes as C
 import os
 import threading
@@ -239,7 +240,81 @@ def _vec(t: torch.Tensor, dtype: torch.dtype, name: str):
     return t.data_ptr()
 
 
-class HipKernels:
+class KernelBackend(abc.ABC):
+    """Every call ``SweepEngine`` / ``Graph`` / ``CosineSimilarity`` make on their kernel object -- the contract
+    between the host logic and whatever executes the kernels.  ``HipKernels`` (the C ABI) is the product's only
+    implementation; the CPU suite's test double (tests/oracle_kernels.py) implements the same list.  An
+    implementation that lacks one of these cannot be instantiated, so nothing the engine relies on (the CSR check
+    that keeps a bad index from faulting the GPU, say) can be skipped silently: the engine calls them
+    unconditionally."""
+
+    # sizes
+    @abc.abstractmethod
+    def spmm_partials_len(self, nrows: int, n_long: int) -> int: ...
+    @abc.abstractmethod
+    def reduce_ws_len(self) -> int: ...
+    @abc.abstractmethod
+    def spmm_split_slab_len(self, n_segments: int, d: int) -> int: ...
+    @abc.abstractmethod
+    def spmm_class_slab_len(self, n_slots: int, d: int) -> int: ...
+    # input check, build description
+    @abc.abstractmethod
+    def check_csr(self, rowptr, colidx, nrows: int, n_edges: int, table_rows: int) -> None: ...
+    @abc.abstractmethod
+    def build_info(self) -> str: ...
+    # K0 / K1 / K2
+    @abc.abstractmethod
+    def row_sqnorm(self, Z, d: int, sq): ...
+    @abc.abstractmethod
+    def degree_weighted_sums(self, sq, rowptr, indeg, nrows: int, ws, out2): ...
+    @abc.abstractmethod
+    def edge_score(self, rowptr, colidx, nrows, row0, Z, d, mode, sums2, sq, scores, long_threshold=0, long_rows=None,
+                   fuse_softmax=False): ...
+    @abc.abstractmethod
+    def edge_score_class(self, rowptr, colidx, item_e0, item_len, item_slot, item_row, items_per_block, class_rows,
+                         slot_ptr, row0, Z, d, mode, sums2, sq, scores, stats=None, fuse_softmax=False,
+                         n_slots=None): ...
+    @abc.abstractmethod
+    def edge_score_finalize(self, rowptr, colidx, nrows, row0, mode, sums2, sq, scores): ...
+    @abc.abstractmethod
+    def segment_softmax(self, rowptr, nrows, vals, min_degree=0, max_degree=0, long_rows=None): ...
+    @abc.abstractmethod
+    def pair_cosine(self, A, B, d, out, ws): ...
+    # K3
+    @abc.abstractmethod
+    def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials,
+                    sinks_untouched=False, mirror=None): ...
+    @abc.abstractmethod
+    def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row, row0, Z_old, X, gamma, Z_new, d, partials,
+                         mirror=None): ...
+    @abc.abstractmethod
+    def spmm_update_split(self, rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, row0, Z_old, X,
+                          gamma, Z_new, d, slab, partials, mirror=None): ...
+    @abc.abstractmethod
+    def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
+                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None): ...
+    @abc.abstractmethod
+    def reduce_partials(self, partials, n, ws, out): ...
+    @abc.abstractmethod
+    def l1_distance(self, A, B, d, ws, out): ...
+    @abc.abstractmethod
+    def gather_rows(self, src, idx, d, dst): ...
+    # further destinations of finished rows, tables other processes map
+    @abc.abstractmethod
+    def make_mirror(self, row_ptr, slot, bufs): ...
+    @abc.abstractmethod
+    def shareable_matrix(self, shape, dtype, device): ...
+    @abc.abstractmethod
+    def open_shared_matrix(self, handle, shape, dtype, device): ...
+
+    def bind(self, method: str, *args, **kwargs):
+        """A zero-argument callable that makes the call ``method(*args, **kwargs)``; an implementation may
+        pre-marshal it (HipKernels does)."""
+        fn = getattr(self, method)
+        return lambda: fn(*args, **kwargs)
+
+
+class HipKernels(KernelBackend):
     """Tensor-level view of the C ABI.  One instance per process is enough (stateless)."""
 
     def __init__(self, lib: Optional[C.CDLL] = None):
@@ -311,6 +386,9 @@ class HipKernels:
     def build_info(self) -> str:
         return self.lib.clane_build_info().decode()
 
+    def make_mirror(self, row_ptr, slot, bufs) -> Mirror:
+        return Mirror(row_ptr, slot, bufs)
+
     def reduce_ws_len(self) -> int:
         return int(self.lib.clane_reduce_ws_len())
 
@@ -347,14 +425,16 @@ class HipKernels:
 
     def edge_score_class(self, rowptr, colidx, item_e0, item_len, item_slot, item_row, items_per_block: int, class_rows,
                          slot_ptr, row0: int, Z, d: int, mode: int, sums2, sq, scores, stats=None,
-                         fuse_softmax: bool = False):
+                         fuse_softmax: bool = False, n_slots: Optional[int] = None):
         """K1 over the class rows' work items (XCD-affine gathers); with `fuse_softmax` every listed row leaves
-        soft-maxed (stats: 2 accumulate-type elements per slot)."""
+        soft-maxed (stats: 2 accumulate-type elements per slot).  ``n_slots`` = slot_ptr[-1] when the caller knows it
+        on the host (the engine does): without it the size check of `stats` reads it back from the device, which
+        blocks the host on everything queued before this call."""
         zp, ldz = _mat(Z, "Z")
         n_items = item_e0.numel()
         if n_items % items_per_block or any(t.numel() != n_items for t in (item_len, item_slot, item_row)):
             raise ValueError("edge_score_class: the item arrays must hold whole blocks of items_per_block items")
-        if fuse_softmax and (stats is None or stats.numel() < 2 * int(slot_ptr[-1])):
+        if fuse_softmax and (stats is None or stats.numel() < 2 * (int(slot_ptr[-1]) if n_slots is None else n_slots)):
             raise ValueError("edge_score_class: stats needs 2 elements per slot")
         acc = acc_dtype(Z.dtype)
         self._check(self._fn("clane_edge_score_class", Z.dtype)(

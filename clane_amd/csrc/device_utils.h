@@ -11,6 +11,7 @@ namespace clane {
 constexpr int kWave = 64;          // gfx950 wavefront
 constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxRowsPerBlock = 256;   // rows a workgroup of the row kernels stages in LDS (rowptr slice, per-row deltas)
 constexpr int kMaxGrid = 256 * 8;  // 256 CUs x 8 resident 256-thread workgroups
 constexpr int kMaxItemsPerBlock = 64;  // class-affine passes: chunk descriptors a workgroup stages in LDS
 

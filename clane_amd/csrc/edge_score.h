@@ -195,9 +195,21 @@ __global__ __launch_bounds__(kBlock) void edge_score_kernel(
 }
 
 // Narrow rows (LPR < 64): one SUB-WAVE per source row, 64/LPR rows per wave in flight -- the K1 counterpart
-// of spmm_update_subrow_kernel.  Each sub-wave keeps its source pack in registers, walks its row LPR edges
-// per refill and 8 neighbour rows per group (branch-free gathers), reduces the 8 partial dots with the
-// transposed butterfly over its LPR lanes, and soft-maxes its row (running max / sum, second pass).
+// of spmm_update_subrow_kernel, with the same row claiming: every sub-wave takes its rows from the workgroup's
+// LDS counter on its own and the wave advances all of them by one group of 8 edges per iteration, so a wave's
+// time is the SUM of its rows' groups / (64/LPR) instead of the maximum over a fixed group of rows (r03: the
+// statically grouped version ran at 4.0 TB/s on the 10M-vertex power-law graph where K3 reaches 6.1 over the
+// same rows).  A sub-wave is in one of four states, uniform over its LPR lanes:
+//   claim   -- take the next row of <= long_threshold edges, load its source pack;
+//   score   -- LPR buffered edges (one column per lane), consumed 8 at a time: 8 branch-free neighbour-row
+//              loads, 8 partial dots, the transposed butterfly over the LPR lanes, the finished scores handed
+//              to lane = edge; after a chunk the running max / sum of the row and one coalesced store;
+//   rescale -- a row of more than LPR edges is soft-maxed by a second pass over the sub-wave's own stores,
+//              one LPR-edge chunk per iteration (each lane re-reads what it wrote) while the other sub-waves
+//              of the wave keep gathering;
+//   done    -- no rows left in the block: the lanes carry on with zero-weight reads of table row 0 (an L1 hit).
+// Every edge goes through the same fma chain and the same exchange tree as in score_edge_range: the scores are
+// bit-identical to the one-wave and the long-row kernels'.
 template <typename T, int VEC, int LPR, int U>
 __global__ __launch_bounds__(kBlock) void edge_score_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows, int64_t row0,
@@ -205,78 +217,118 @@ __global__ __launch_bounds__(kBlock) void edge_score_subrow_kernel(
     const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores,
     int64_t long_threshold, bool fuse_softmax, int rows_per_block) {
     using A = typename Elem<T>::acc_t;
-    static_assert(LPR < kWave && LPR >= 8 && U == 8, "sub-wave layout");
-    constexpr int RPW = kWave / LPR;
+    static_assert(LPR < kWave && LPR >= 8 && U == 8 && LPR % U == 0, "sub-wave layout");
+    constexpr int kClaim = 0, kScore = 1, kRescale = 2, kDone = 3;
+    __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
+    __shared__ int s_next;
     const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sub = lane / LPR, sl = lane % LPR, sub_base = sub * LPR;
     const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
-    const int64_t row_end = row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows;
+    const int nb = int((row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows) - row_begin);
     const A D = global_denominator<A>(mode, sums2);
     const int c0 = sl * VEC;
     const bool col_ok = c0 < d;
     const int c0s = col_ok ? c0 : 0;
 
-    for (int64_t base = row_begin + wave * RPW; base < row_end; base += kWavesPerBlock * RPW) {
-        const int64_t r = base + sub;
-        int64_t e0 = 0;
-        int deg = 0;
-        if (r < row_end) {
-            e0 = rowptr[r];
-            const int64_t dg = rowptr[r + 1] - e0;
-            deg = (long_threshold > 0 && dg > long_threshold) ? 0 : int(dg);
-        }
-        const int64_t gsrc = row0 + (r < row_end ? r : row_begin);
-        Pack<T, VEC> s0 = load_pack<T, VEC>(Z + gsrc * ldz + c0s);
-        if (!col_ok) s0 = Pack<T, VEC>{};
-        const A nsrc = mode == kScorePerEdge ? sqrt(sq[gsrc]) : A(0);
-        A run_m = -A(INFINITY), run_s = A(0);
-        for (int eb = 0; __any(eb < deg); eb += LPR) {
-            const int n = deg - eb < LPR ? (deg - eb > 0 ? deg - eb : 0) : LPR;
-            int c = sl < n ? colidx[e0 + eb + sl] : 0;
-            c = sl < n ? c : lane_get(c, sub_base);      // lanes past the row: the chunk's first column (row 0 if none)
-            A mine = A(0);
-            for (int j = 0; __any(j < n); j += U) {
-                A part[U];
-                Pack<T, VEC> z[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int idx = j + u;
-                    const int cj = lane_get(c, sub_base + (idx < LPR ? idx : LPR - 1));
-                    z[u] = load_pack<T, VEC>(Z + int64_t(cj) * ldz + c0s);
+    for (int i = threadIdx.x; i <= nb; i += kBlock) s_rowptr[i] = rowptr[row_begin + i];
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+
+    int phase = kClaim;
+    int64_t e0 = 0;            // first edge of the open row
+    int deg = 0, eb = 0;       // its edge count; edges before the buffered chunk
+    int n = 0, j = 0;          // buffered edges (c: one column per lane) and how many of them are scored
+    int rpos = 0;              // rescale: edges of the row already normalised
+    int c = 0;
+    A mine = A(0);             // score of edge eb + sl
+    A run_m = -A(INFINITY), run_s = A(0), nsrc = A(0);
+    Pack<T, VEC> s0{};
+
+    for (;;) {
+        if (phase != kDone && (phase != kScore || j >= n)) {      // divergent between sub-waves, uniform inside one
+            if (phase == kScore) {               // the buffered chunk is scored: running max / sum, store
+                const bool in = sl < n;
+                if (fuse_softmax) {              // graph.py:122-123, online over the row's chunks
+                    const A v = in ? mine : -A(INFINITY);
+                    const A new_m = fmax(run_m, group_max<LPR>(v));
+                    const A ex = in ? exp_acc<A>(v - new_m) : A(0);
+                    const A cs = group_sum<LPR>(ex);
+                    run_s = run_s * exp_acc<A>(run_m - new_m) + cs;
+                    run_m = new_m;
+                    if (deg <= LPR) mine = ex / cs;              // the whole row is this chunk: finished in registers
                 }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    part[u] = A(0);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k)
-                        part[u] = fma(Elem<T>::to_acc(s0.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
+                if (in) scores[e0 + eb + sl] = mine;
+                eb += n;
+                if (eb >= deg) {
+                    phase = (fuse_softmax && deg > LPR) ? kRescale : kClaim;
+                    rpos = 0;
                 }
-                A serve = transpose_reduce8<LPR>(part, sl);
-                const int idx_serve = j + sl / (LPR / 8);
-                int col_serve = 0;
-                if (mode == kScorePerEdge) col_serve = lane_get(c, sub_base + (idx_serve < LPR ? idx_serve : LPR - 1));
-                serve = finalize_score<A>(serve, mode, D, nsrc, sq, col_serve);
-                const int rel = sl - j;                      // lane sl of the sub-wave takes edge eb + sl
-                const bool take = rel >= 0 && rel < U;
-                const A got = lane_get(serve, take ? sub_base + rel * (LPR / 8) : lane);
-                if (take) mine = got;
             }
-            const bool in = sl < n;
-            if (fuse_softmax) {
-                const A v = in ? mine : -A(INFINITY);
-                const A new_m = fmax(run_m, group_max<LPR>(v));
-                const A ex = in ? exp_acc<A>(v - new_m) : A(0);
-                const A cs = group_sum<LPR>(ex);
-                run_s = run_s * exp_acc<A>(run_m - new_m) + cs;
-                run_m = new_m;
-                if (deg <= LPR) mine = ex / cs;
+            if (phase == kRescale) {
+                const int e = rpos + sl;
+                if (e < deg) scores[e0 + e] = exp_acc<A>(scores[e0 + e] - run_m) / run_s;
+                rpos += LPR;
+                if (rpos >= deg) phase = kClaim;
             }
-            if (in) scores[e0 + eb + sl] = mine;
+            if (phase == kClaim) {
+                for (;;) {
+                    int v = 0;
+                    if (sl == 0) v = atomicAdd(&s_next, 1);
+                    const int row = lane_get(v, sub_base);
+                    if (row >= nb) {
+                        phase = kDone;
+                        break;
+                    }
+                    const int64_t dg = s_rowptr[row + 1] - s_rowptr[row];
+                    if (dg == 0 || (long_threshold > 0 && dg > long_threshold)) continue;
+                    e0 = s_rowptr[row];
+                    deg = int(dg);
+                    eb = 0;
+                    const int64_t gsrc = row0 + row_begin + row;
+                    s0 = load_pack<T, VEC>(Z + gsrc * ldz + c0s);
+                    if (!col_ok) s0 = Pack<T, VEC>{};
+                    nsrc = mode == kScorePerEdge ? sqrt(sq[gsrc]) : A(0);
+                    run_m = -A(INFINITY);
+                    run_s = A(0);
+                    phase = kScore;
+                    break;
+                }
+            }
+            n = 0;
+            j = 0;
+            c = 0;
+            mine = A(0);
+            if (phase == kScore) {               // refill: the next LPR edges of the row, one per lane
+                n = deg - eb < LPR ? deg - eb : LPR;
+                if (sl < n) c = colidx[e0 + eb + sl];
+                c = sl < n ? c : lane_get(c, sub_base);           // lanes past the row: the chunk's first column
+            }
         }
-        if (fuse_softmax && deg > LPR) {
-            for (int e = sl; e < deg; e += LPR) scores[e0 + e] = exp_acc<A>(scores[e0 + e] - run_m) / run_s;
+        if (__all(phase == kDone)) break;
+        // one group of U edges per sub-wave
+        A part[U];
+        Pack<T, VEC> z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cj = lane_get(c, sub_base + ((j + u) & (LPR - 1)));
+            z[u] = load_pack<T, VEC>(Z + int64_t(cj) * ldz + c0s);
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            part[u] = A(0);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) part[u] = fma(Elem<T>::to_acc(s0.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
+        }
+        A serve = transpose_reduce8<LPR>(part, sl);
+        const int idx_serve = (j + sl / (LPR / 8)) & (LPR - 1);
+        int col_serve = 0;
+        if (mode == kScorePerEdge) col_serve = lane_get(c, sub_base + idx_serve);
+        serve = finalize_score<A>(serve, mode, D, nsrc, sq, col_serve);
+        const int rel = sl - j;                      // lane sl of the sub-wave takes edge eb + sl
+        const bool take = rel >= 0 && rel < U;
+        const A got = lane_get(serve, take ? sub_base + rel * (LPR / 8) : lane);
+        if (take) mine = got;
+        j += U;
     }
 }
 

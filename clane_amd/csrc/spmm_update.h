@@ -50,8 +50,6 @@
 
 namespace clane {
 
-constexpr int kMaxRowsPerBlock = 256;
-
 // First (<= 64-edge) chunk of a row's colidx / P, one edge per lane.
 template <typename A>
 struct EdgeChunk {

@@ -33,8 +33,8 @@ from . import _hip
 from .comm import TorchComm
 from .halo import build_halo_layout
 from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
-from .xcd import (CLASS_CHUNK, CLASS_ITEMS_PER_BLOCK, CLASS_THRESHOLD_BY_ROWS_PER_WAVE, PHASE_THRESHOLD,
-                  PHASES_BY_ROWS_PER_WAVE, class_items, items_per_block_for)
+from .xcd import (CLASS_CHUNK, CLASS_THRESHOLD_BY_ROWS_PER_WAVE, PHASE_THRESHOLD, PHASES_BY_ROWS_PER_WAVE,
+                  class_items)
 
 # Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md, r02_class_threshold_sweep.md):
 #   deg <= T                 one (sub-)wave per row, rows claimed dynamically inside a workgroup
@@ -136,8 +136,6 @@ class SweepEngine:
         if cosine_mode not in ("reference", "per_edge"):
             raise ValueError(f"cosine_mode must be 'reference' or 'per_edge', got {cosine_mode!r}")
         csr.validate()                      # before anything is uploaded or indexed on the device
-        if X.ndim != 2 or X.shape[0] != csr.num_vertices:
-            raise ValueError(f"X must be [V, d] with V = {csr.num_vertices}, got {tuple(X.shape)}")
         self.k = kernels if kernels is not None else _hip.kernels()
         self.device = torch.device(device)
         self.dtype = X.dtype
@@ -152,7 +150,7 @@ class SweepEngine:
                              f"got {exchange!r}")
         # a one-rank group whose comm insists on its collectives keeps the division it is given (RCCL rehearsal on a
         # one-GPU box, comm.TorchComm(force_collectives=True)); "auto" is then the plain one-GPU plan
-        self._forced = self.world == 1 and bool(getattr(self.comm, "force", False)) and exchange in (
+        self._forced = self.world == 1 and self.comm is not None and bool(self.comm.force) and exchange in (
             "columns", "allgather", "allgather_all")
         divided = self.world > 1 or self._forced
         if exchange == "auto":
@@ -241,8 +239,7 @@ class SweepEngine:
         self.indeg = torch.from_numpy(self.local.indeg).to(dev)
         self.E_loc = int(self.local.colidx.shape[0])
         # what every gather kernel takes on trust, checked once on the device (a bad index faults the GPU)
-        if hasattr(self.k, "check_csr"):
-            self.k.check_csr(self.rowptr, self.colidx, self.part.n_local, self.E_loc, self.part.padded_vertices)
+        self.k.check_csr(self.rowptr, self.colidx, self.part.n_local, self.E_loc, self.part.padded_vertices)
         self.P = torch.zeros(max(self.E_loc, 1), dtype=self.acc_dtype, device=dev)
         self.P_valid = False
         deg = np.diff(self.local.rowptr)
@@ -253,6 +250,7 @@ class SweepEngine:
         self.hub_rows: List[Optional[torch.Tensor]] = []      # hub_threshold < deg <= SPLIT_EDGES: 16 waves/row
         self.split_rows: List[Optional[tuple]] = []           # deg > SPLIT_EDGES: (rows, seg_ptr, seg_row) on device
         self.class_rows: List[Optional[tuple]] = []           # deg > class_threshold: (rows, slot_ptr, e0, len, slot, row)
+        self.class_slots: List[int] = []                      # slot_ptr[-1] of each block's class rows, known on the host
         self.k1_long_rows: List[Optional[torch.Tensor]] = []  # K1's workgroup-per-row list: above k1_threshold, not class
         self.split_edges = SPLIT_EDGES if split_hubs else 0
         hub_edges = int(deg[deg > SPLIT_EDGES].sum()) // max(1, len(self.blocks))
@@ -274,19 +272,20 @@ class SweepEngine:
             if rows_c.size:
                 rows_abs = rows_c + b.local_start
                 phased = dict(phase_threshold=self.phase_threshold, phases=self.class_phases)
-                items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk,
-                                    CLASS_ITEMS_PER_BLOCK, row_ids=rows_c, colidx_dev=self.colidx, **phased)
-                ipb = items_per_block_for(int(items["slot_ptr"][-1]))
-                if ipb != CLASS_ITEMS_PER_BLOCK:    # few chunks in this launch (a chunk of a rank's rows): smaller workgroups
-                    items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk, ipb,
-                                        row_ids=rows_c, colidx_dev=self.colidx, **phased)
+                # items per workgroup follow the item count (few chunks in a launch -- a chunk of a rank's rows --
+                # get smaller workgroups): class_items picks it after its one counting pass over the edges
+                items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk, None,
+                                    row_ids=rows_c, colidx_dev=self.colidx, **phased)
+                ipb = items["items_per_block"]
                 self.class_rows.append((to_dev(rows_c), torch.from_numpy(items["slot_ptr"]).to(dev),
                                         torch.from_numpy(items["e0"]).to(dev), torch.from_numpy(items["len"]).to(dev),
                                         torch.from_numpy(items["slot"]).to(dev), torch.from_numpy(items["row"]).to(dev),
                                         ipb))
-                max_slots = max(max_slots, int(items["slot_ptr"][-1]))
+                self.class_slots.append(int(items["slot_ptr"][-1]))
+                max_slots = max(max_slots, self.class_slots[-1])
             else:
                 self.class_rows.append(None)
+                self.class_slots.append(0)
             k1_long = (db > self.k1_threshold) & ~(is_class if self.class_k1 else np.zeros_like(is_class)) \
                 if self.k1_threshold > 0 else np.zeros_like(is_class)
             self.k1_long_rows.append(to_dev(np.nonzero(k1_long)[0]))
@@ -318,7 +317,7 @@ class SweepEngine:
         self.send_rows: List[Optional[torch.Tensor]] = []
         self.send_buf: List[Optional[torch.Tensor]] = []
         self.mirrors: List[Optional[object]] = []
-        self.fused_pack = bool(fused_pack) and hasattr(_hip, "Mirror")
+        self.fused_pack = bool(fused_pack)
         for b in self.blocks:
             ex = b.exchange
             has = ex is not None and ex.send_rows.size > 0 and not self.p2p
@@ -392,9 +391,13 @@ class SweepEngine:
         # Alternate chunks go to two side streams, so the tail of one chunk's kernels overlaps the head of the
         # next chunk's (a chunk at 8 GPUs is only ~0.25 ms of kernels: ramp-up and tail are a third of it).
         self.side_streams = None
-        if overlap_chunks and len(self.blocks) > 1 and self.device.type == "cuda" and hasattr(self.k, "bind"):
+        if overlap_chunks and len(self.blocks) > 1 and self.device.type == "cuda":
             self.side_streams = [torch.cuda.Stream(self.device) for _ in range(2)]
         self.time_kernels = False
+        # bench.py, N > 1: HIP events on the sweep's stream around what it spends waiting for the other ranks -- the
+        # row exchange still outstanding after its own kernels (what the overlap did not hide) and the scalar all-reduce
+        self.time_collectives = False
+        self.collective_events = []      # [(after kernels, after exchange waits, after all-reduce)]
         self._stage_cv, self._stage_free = threading.Condition(), None      # stage_Z: slots made on first use
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
 
@@ -440,8 +443,7 @@ class SweepEngine:
         flag.item()
 
     def _make_mirror(self, row_ptr, slot, buf):
-        make = getattr(self.k, "make_mirror", None)          # substitute kernels (tests) bring their own
-        return make(row_ptr, slot, buf) if make is not None else _hip.Mirror(row_ptr, slot, buf)
+        return self.k.make_mirror(row_ptr, slot, buf)
 
     # ---- views of one block -------------------------------------------------------------
     def _rows(self, b: Block):
@@ -578,7 +580,8 @@ class SweepEngine:
                     rows_c, slot_ptr, it_e0, it_len, it_slot, it_row, ipb = self.class_rows[i]
                     k.edge_score_class(rp, self.colidx, it_e0, it_len, it_slot, it_row, ipb, rows_c,
                                        slot_ptr, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
-                                       self.slabs[i % len(self.slabs)], fuse_softmax=True)
+                                       self.slabs[i % len(self.slabs)], fuse_softmax=True,
+                                       n_slots=self.class_slots[i])
         elif self.E_loc > 0:
             # column split: dot products of the owned columns, summed over the GPUs, then denominators + softmax
             if busy:
@@ -609,9 +612,7 @@ class SweepEngine:
 
     # ---- one sweep (embedder.py:84-94) --------------------------------------------------
     def _bind(self, method: str, *args, **kwargs):
-        if hasattr(self.k, "bind"):
-            return self.k.bind(method, *args, **kwargs)          # pre-marshalled ABI call
-        return lambda: getattr(self.k, method)(*args, **kwargs)  # substitute kernels (tests)
+        return self.k.bind(method, *args, **kwargs)              # HipKernels: the pre-marshalled ABI call
 
     def _build_plan(self, cur: int, gamma: float):
         """Launch lists of one sweep reading Zbuf[cur]: per block, bound kernel calls, event marks and the
@@ -731,8 +732,15 @@ class SweepEngine:
                 main.wait_event(done)
         final()
         mine = self.delta_pp[parity:parity + 1]
+        cev = None
+        if self.time_collectives and self._delta_stream is None and len(self.collective_events) < self.MAX_TIMED_SWEEPS:
+            cev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            self.collective_events.append(cev)
+            cev[0].record()
         for w in works:
             w.wait()
+        if cev is not None:
+            cev[1].record()
         if self._delta_stream is not None:
             # the scalar all-reduce and the copy of the delta leave the sweep's stream: the next sweep (launched ahead
             # by the lagged check) does not queue behind RCCL's latency.  delta_pp[parity] is next written two sweeps
@@ -747,6 +755,8 @@ class SweepEngine:
             self._delta_busy[parity] = True
         else:
             self._all_reduce(mine)
+            if cev is not None:
+                cev[2].record()
             self._delta_host[parity:parity + 1].copy_(mine, non_blocking=True)
             if self._delta_ev is not None:
                 self._delta_ev[parity].record()
@@ -779,6 +789,16 @@ class SweepEngine:
             return {}
         per_sweep = t.reshape(-1, len(self.blocks), 4).sum(1).mean(0)
         return dict(zip(("split", "hub", "mid", "main"), per_sweep.tolist()))
+
+    def collective_times_ms(self):
+        """{'exchange_exposed', 'allreduce'} -> ms per sweep seen from the sweep's stream (averaged over the recorded
+        sweeps; call after a synchronize): how long it waited for the row exchange after its own kernels were done, and
+        for the all-reduce of the delta.  Empty when nothing was recorded (one GPU, or time_collectives off)."""
+        ev, self.collective_events = self.collective_events, []
+        if not ev:
+            return {}
+        t = np.array([(a.elapsed_time(b), b.elapsed_time(c)) for a, b, c in ev])
+        return {"exchange_exposed": float(t[:, 0].mean()), "allreduce": float(t[:, 1].mean()), "sweeps_timed": len(ev)}
 
     def kernel_bytes(self):
         """Algorithmic bytes per SWEEP of each K3 kernel (SURVEY.md section 8d gather model, split by the
@@ -816,8 +836,7 @@ class SweepEngine:
         """Everything that decides which K3 kernels a sweep launches over which rows, and with which compile-time
         tuning: measurements of a kernel (profiles/traffic.json) are only valid for the configuration they were
         taken with, and bench.py refuses to quote them for another."""
-        build = self.k.build_info() if hasattr(self.k, "build_info") else "substitute kernels"
-        return {"build": build, "dtype": str(self.dtype).replace("torch.", ""), "d": self.d,
+        return {"build": self.k.build_info(), "dtype": str(self.dtype).replace("torch.", ""), "d": self.d,
                 "lanes_per_row": lanes_per_row(self.d, self.dtype) if self.d > 0 else 0,
                 "rows": int(self.part.n_local), "edges": int(self.E_loc), "launch_blocks": len(self.blocks),
                 "long_threshold": self.long_threshold, "score_threshold": self.score_threshold,

@@ -80,7 +80,7 @@ def row_pieces(rowptr: np.ndarray, max_edges: int):
         a = b
 
 
-def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: int,
+def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: Optional[int],
                 row_ids: Optional[np.ndarray] = None, colidx_dev: Optional[torch.Tensor] = None,
                 phase_threshold: int = 0, phases: int = 1) -> dict:
     """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
@@ -91,7 +91,8 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     (len 0, slot -1).  With `phases` > 1 the rows above `phase_threshold` edges are cut by (phase, class) -- their
     edges sorted by xcd_subclass -- and their blocks come first, phase by phase (each phase a whole number of
     8-block rounds, so block index % 8 stays the class), then the blocks of the other rows.  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
-    item's row, default `rows` itself) and int64 slot_ptr [rows + 1]."""
+    item's row, default `rows` itself), int64 slot_ptr [rows + 1] and the items_per_block used (None on entry: chosen
+    by `items_per_block_for` from the item count, once the O(E) counting pass has it -- the layout itself is cheap)."""
     n = rows.size
     NS = XCD_CLASSES * max(1, phases)                       # sub-classes per row (phase-major)
     sizes = (rowptr[rows + 1] - rowptr[rows]).astype(np.int64)
@@ -124,6 +125,8 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     seg_e0 = np.repeat(rowptr[rows], NS) + (np.cumsum(seg_len) - seg_len - np.repeat(start, NS))
     nchunk = -(-seg_len // chunk)
     tot = int(nchunk.sum())
+    if items_per_block is None:
+        items_per_block = items_per_block_for(tot)
     seg_of = np.repeat(np.arange(n * NS), nchunk)
     within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
     e0 = seg_e0[seg_of] + within * chunk
@@ -158,7 +161,8 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
         pieces.append((np.zeros(flat, dtype=np.int64), np.zeros(flat, dtype=np.int32),
                        np.full(flat, -1, dtype=np.int32), np.zeros(flat, dtype=np.int32)))
     out_e0, out_len, out_slot, out_row = (np.concatenate([p[i] for p in pieces]) for i in range(4))
-    return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "slot_ptr": slot_ptr}
+    return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "slot_ptr": slot_ptr,
+            "items_per_block": int(items_per_block)}
 
 
 def items_per_block_for(n_items: int) -> int:

@@ -8,6 +8,7 @@ substitutes it: ``SweepEngine`` only gets it when a test passes it in explicitly
 import numpy as np
 import torch
 
+from clane_amd._hip import KernelBackend
 from clane_amd.xcd import xcd_class
 from oracle import clane_oracle as O
 
@@ -16,7 +17,16 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-class OracleKernels:
+class OracleKernels(KernelBackend):
+    """Implements the whole ``KernelBackend`` contract (the abstract base refuses to instantiate otherwise), so the
+    engine never has to ask whether a call exists."""
+
+    def build_info(self):
+        return "substitute kernels (tests/oracle_kernels.py)"
+
+    def open_shared_matrix(self, handle, shape, dtype, device):
+        raise NotImplementedError("one process: ThreadComm.share_matrices hands the tensors over directly")
+
     def check_csr(self, rowptr, colidx, nrows, n_edges, table_rows):
         rp, ci = rowptr.cpu().numpy()[:nrows + 1], colidx.cpu().numpy()[:n_edges]
         if rp[0] < 0 or rp[-1] > n_edges or (np.diff(rp) < 0).any():
@@ -58,8 +68,9 @@ class OracleKernels:
                     scores[rp[r]:rp[r + 1]] = torch.softmax(scores[rp[r]:rp[r + 1]], 0)
 
     def edge_score_class(self, rowptr, colidx, item_e0, item_len, item_slot, item_row, items_per_block, class_rows,
-                         slot_ptr, row0, Z, d, mode, sums2, sq, scores, stats=None, fuse_softmax=False):
+                         slot_ptr, row0, Z, d, mode, sums2, sq, scores, stats=None, fuse_softmax=False, n_slots=None):
         """K1 over the class rows' items; checks the same layout contract as spmm_update_class."""
+        assert n_slots is None or n_slots == int(slot_ptr[-1])
         e0, ln, rw = _np(item_e0), _np(item_len), _np(item_row)
         assert 4 <= items_per_block <= 64 and e0.size % items_per_block == 0 and e0.size // items_per_block % 8 == 0
         Zf = Z[:, :d].to(scores.dtype)

@@ -7,6 +7,7 @@ import sys
 from pathlib import Path
 from types import SimpleNamespace
 
+import pytest
 import torch
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -63,20 +64,41 @@ def test_traffic_is_only_quoted_for_the_configuration_it_was_measured_with(tmp_p
     assert "kernel_config" in real["rmat2m_n1"] and real["rmat2m_n1"]["kernel_config"]["d"] == 256
 
 
-def test_sampled_torch_baseline_matches_a_full_sweep_in_order_of_magnitude():
+def test_torch_baseline_sampled_and_full(monkeypatch):
+    """The PyTorch-CPU baseline (P as a sparse CSR tensor, whose CPU kernel threads over rows): with a tiny budget it
+    times a random row sample and scales it; with room it times FULL sweeps; either way it is the same quantity as a
+    plain full sweep, and the all-thread figure is not below the one-thread figure (round 2's COO form did not scale)."""
     import time
+    import warnings
+    import numpy as np
     from clane_amd import synth
     from oracle import clane_oracle as O
-    csr = synth.rmat_csr(30_000, 400_000, seed=1, device="cpu")
-    X = synth.gaussian_X(30_000, 64, seed=2)
+    csr = synth.rmat_csr(60_000, 1_500_000, seed=1, device="cpu")
+    X = synth.gaussian_X(60_000, 64, seed=2)
     P = O.build_P_values(csr.rowptr, csr.colidx, X)
     out = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=0.02)      # tiny budget: forces row sampling
     assert out["kind"] == "port" and out["cores"] == torch.get_num_threads() and out["one_thread"]["cores"] == 1
-    assert "torch.sparse.mm" in out["sample"] and "random 1/" in out["sample"]
-    Ps = O.as_sparse(csr.rowptr, csr.colidx, P)
-    O.sweep(csr.rowptr, csr.colidx, P, X, X, 0.76, Ps)
+    assert "sparse_csr_tensor" in out["sample"] and "random 1/" in out["sample"]
+    full_run = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=20.0)
+    assert "full sweeps" in full_run["sample"] and "full sweeps" in full_run["one_thread"]["sample"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Ps = torch.sparse_csr_tensor(torch.from_numpy(csr.rowptr), torch.from_numpy(csr.colidx.astype(np.int64)), P,
+                                     size=(60_000, 60_000))
+    sink = torch.from_numpy(np.diff(csr.rowptr) == 0)
+
+    def sweep():
+        Zn = X + 0.76 * (Ps @ X)
+        Zn[sink] = X[sink]
+        return (Zn - X).abs().sum()
+    sweep()
     t0 = time.perf_counter()
-    O.sweep(csr.rowptr, csr.colidx, P, X, X, 0.76, Ps)
+    ref = sweep()
     full = time.perf_counter() - t0
-    assert 0.1 < (1.0 / out["value"]) / full < 10                       # a scaled sample, not a different quantity
+    Zo, d_or = O.sweep(csr.rowptr, csr.colidx, P, X, X, 0.76)            # the CSR form is the oracle's sweep
+    assert float(ref) == pytest.approx(float(d_or), rel=1e-5)
+    for fig in (out, full_run):
+        assert 0.1 < (1.0 / fig["value"]) / full < 10                   # a scaled sample, not a different quantity
+    if torch.get_num_threads() >= 4:
+        assert full_run["value"] > 1.5 * full_run["one_thread"]["value"]
     assert torch.get_num_threads() == out["cores"]                      # thread count restored

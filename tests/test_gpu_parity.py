@@ -263,7 +263,7 @@ def test_k3_and_k1_random_shapes(dev, k):
             k.edge_score(rowptr, colidx, V, 0, Zo, d, _hip.SCORE_REFERENCE, sums2, None, P, T,
                          long_rows if n_long else None, fuse_softmax=True)
             P_ref = O.build_P_values(csr.rowptr, csr.colidx, Zold.to(acc).double())
-            assert rel(P[:csr.num_edges], P_ref) < max(TOL[dtype], 1e-6) if dtype != torch.bfloat16 else 1e-4, tag
+            assert rel(P[:csr.num_edges], P_ref) < (max(TOL[dtype], 1e-6) if dtype != torch.bfloat16 else 1e-4), tag
         else:
             P.zero_()
         # K3
@@ -869,8 +869,8 @@ def test_edge_score_class_affine_rows(dev, k, dtype, d, pad):
             assert rel(fused[listed_d], ref[listed_d]) < (1e-14 if dtype == torch.float64 else 3e-7)
             P_or = O.build_P_values(csr0.rowptr, colidx, Zc.to(acc).double(),
                                     mode="per_edge" if mode == _hip.SCORE_PER_EDGE else "reference")
-            assert rel(fused[listed_d], P_or[torch.from_numpy(listed)]) < max(TOL[dtype], 1e-6) \
-                if dtype != torch.bfloat16 else 1e-4
+            assert rel(fused[listed_d], P_or[torch.from_numpy(listed)]) < (
+                max(TOL[dtype], 1e-6) if dtype != torch.bfloat16 else 1e-4)
             for r in rows:
                 assert float(fused[csr0.rowptr[r]:csr0.rowptr[r + 1]].double().sum()) == pytest.approx(1.0, abs=1e-5)
     with pytest.raises(ValueError, match="stats"):

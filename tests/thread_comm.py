@@ -26,6 +26,7 @@ class ThreadWorld:
 class ThreadComm:
     def __init__(self, shared: ThreadWorld, rank: int):
         self.s, self.rank, self.world = shared, rank, shared.world
+        self.force = False          # clane_amd.comm's interface: a one-rank group that insists on its collectives
 
     def _exchange(self, value):
         """Everyone deposits `value`; returns the list of all ranks' values (valid until the next collective)."""
