@@ -677,7 +677,7 @@ def main():
                 if rank == 0:
                     print(json.dumps(result), flush=True)
 
-    if world > 1 and args.also_exchange not in ("none", eng.exchange):
+    if world > 1 and args.also_exchange not in ("none", eng.exchange) and not args.column_slice_of:
         # Whatever happens in here, the main record above must come out: past the deadline every rank prints /
         # leaves on its own (a rank stuck in a collective cannot be talked to).
         def give_up():
@@ -690,7 +690,10 @@ def main():
         timer.start()
         block = {"exchange": args.also_exchange}
         try:
+            main_division = eng.exchange
             del m["eng"]
+            eng = None                      # the first engine's tables go back to the allocator before the second is built
+            torch.cuda.empty_cache()
             m2 = measure_division(args, ranks, csr, X, args.also_exchange, time_kernels=False)
             e2 = m2["eng"]
             block.update({
@@ -704,7 +707,8 @@ def main():
                 "build_P_ms": m2["build_P_ms"], "last_delta": m2["delta"],
                 "parallelism": describe_parallelism(args, world, e2, X, E),
                 "host_sync": "pipelined" if m2["pipelined"] else "after every sweep",
-                "vs_main_division": m2["value"] / m["value"], "comm": comm_block(args, ranks, m2)})
+                "vs_main_division": m2["value"] / m["value"], "main_division": main_division,
+                "comm": comm_block(args, ranks, m2)})
             bad = False
             if rank == 0 and Z1_oracle is not None and m2["Z1"] is not None:
                 from oracle import clane_oracle as O

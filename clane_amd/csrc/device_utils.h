@@ -112,20 +112,76 @@ __device__ __forceinline__ double lane_get_uniform(double v, int src) {
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-// Butterfly sum over aligned groups of WIDTH lanes; every lane of the group gets the total.
+// Value of lane (lane ^ M), M a compile-time power of two -- WITHOUT the LDS crossbar: DPP moves inside a row of 16
+// lanes (quad_perm for 1 and 2; row_half_mirror + quad reversal for 4; row_ror:8 for 8), gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows (16, 32).  A ds_bpermute (what __shfl_xor compiles to) is an
+// LDS-pipe round trip of ~100 cycles; the butterflies below are chains of 3..6 of them, sitting between a group's
+// gathers and the next group's in K1 and inside the sub-wave service blocks.  Pure data movement: results are
+// bit-identical to the __shfl_xor form.  Partner lanes must be active (they are: every caller reduces over groups
+// of lanes that execute together).  All six verified on the card against lane ^ M (tools/lane_xor_check.hip).
+#ifndef CLANE_XOR_DPP
+#define CLANE_XOR_DPP 1
+#endif
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+template <int M>
+__device__ __forceinline__ int lane_xor(int v) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "lane_xor: M must be a power of two below 64");
+#if CLANE_XOR_DPP
+    if constexpr (M == 1) return dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // row_half_mirror (i -> 7 - i), then quad_perm [3,2,1,0]
+    else if constexpr (M == 8) return dpp_mov<0x128>(v);                 // row_ror:8
+    else if constexpr (M == 16) {   // {rows 0 and 2 of a with rows 0 and 2 of b, ...}: r[0] = (a0, b0, a2, b2), r[1] = (a1, b1, a3, b3)
+        const auto r = __builtin_amdgcn_permlane16_swap(unsigned(v), unsigned(v), false, false);
+        return int((threadIdx.x & 16) ? r[0] : r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(unsigned(v), unsigned(v), false, false);
+        return int((threadIdx.x & 32) ? r[0] : r[1]);
+    }
+#else
+    return __shfl_xor(v, M, kWave);
+#endif
+}
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) {
+    return __int_as_float(lane_xor<M>(__float_as_int(v)));
+}
+template <int M>
+__device__ __forceinline__ double lane_xor(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = lane_xor<M>(int(b));
+    const int hi = lane_xor<M>(int(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// Butterfly sum over aligned groups of WIDTH lanes (partners lane ^ WIDTH/2, ..., lane ^ 1, in that order); every
+// lane of the group gets the total, bit for bit the same one.
 template <int WIDTH, typename A>
 __device__ __forceinline__ A group_sum(A v) {
-#pragma unroll
-    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    if constexpr (WIDTH >= 64) v += lane_xor<32>(v);
+    if constexpr (WIDTH >= 32) v += lane_xor<16>(v);
+    if constexpr (WIDTH >= 16) v += lane_xor<8>(v);
+    if constexpr (WIDTH >= 8) v += lane_xor<4>(v);
+    if constexpr (WIDTH >= 4) v += lane_xor<2>(v);
+    if constexpr (WIDTH >= 2) v += lane_xor<1>(v);
     return v;
+}
+template <int M, typename A>
+__device__ __forceinline__ A max_step(A v) {
+    const A o = lane_xor<M>(v);
+    return o > v ? o : v;
 }
 template <int WIDTH, typename A>
 __device__ __forceinline__ A group_max(A v) {
-#pragma unroll
-    for (int m = WIDTH / 2; m >= 1; m >>= 1) {
-        const A o = __shfl_xor(v, m, kWave);
-        v = o > v ? o : v;
-    }
+    if constexpr (WIDTH >= 64) v = max_step<32>(v);
+    if constexpr (WIDTH >= 32) v = max_step<16>(v);
+    if constexpr (WIDTH >= 16) v = max_step<8>(v);
+    if constexpr (WIDTH >= 8) v = max_step<4>(v);
+    if constexpr (WIDTH >= 4) v = max_step<2>(v);
+    if constexpr (WIDTH >= 2) v = max_step<1>(v);
     return v;
 }
 

@@ -24,6 +24,10 @@
 
 namespace clane {
 
+#ifndef CLANE_K1_HALF_GROUP
+#define CLANE_K1_HALF_GROUP 0     // edge_score_subrow_kernel: skip a group's second half when no sub-wave needs it
+#endif
+
 constexpr int kScoreReference = 0;
 constexpr int kScorePerEdge = 1;
 constexpr int kScoreRawDot = 2;
@@ -38,13 +42,11 @@ __device__ __forceinline__ A transpose_reduce8(const A (&v)[8], int sl) {
     const bool h0 = (sl & m0) != 0, h1 = (sl & m1) != 0, h2 = (sl & m2) != 0;
     A r[4], q[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (h0 ? v[i + 4] : v[i]) + __shfl_xor(h0 ? v[i] : v[i + 4], m0, kWave);
+    for (int i = 0; i < 4; ++i) r[i] = (h0 ? v[i + 4] : v[i]) + lane_xor<m0>(h0 ? v[i] : v[i + 4]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) q[i] = (h1 ? r[i + 2] : r[i]) + __shfl_xor(h1 ? r[i] : r[i + 2], m1, kWave);
-    A t = (h2 ? q[1] : q[0]) + __shfl_xor(h2 ? q[0] : q[1], m2, kWave);
-#pragma unroll
-    for (int m = m2 / 2; m >= 1; m >>= 1) t += __shfl_xor(t, m, kWave);
-    return t;
+    for (int i = 0; i < 2; ++i) q[i] = (h1 ? r[i + 2] : r[i]) + lane_xor<m1>(h1 ? r[i] : r[i + 2]);
+    const A t = (h2 ? q[1] : q[0]) + lane_xor<m2>(h2 ? q[0] : q[1]);
+    return group_sum<m2>(t);             // the remaining partners lane ^ m2/2 ... lane ^ 1
 }
 
 template <typename A>
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(kBlock) void edge_score_subrow_kernel(
                     const A new_m = fmax(run_m, group_max<LPR>(v));
                     const A ex = in ? exp_acc<A>(v - new_m) : A(0);
                     const A cs = group_sum<LPR>(ex);
-                    run_s = run_s * exp_acc<A>(run_m - new_m) + cs;
+                    if (eb == 0) run_s = cs;                     // first chunk: 0 * exp(-inf) + cs without the exp
+                    else run_s = run_s * exp_acc<A>(run_m - new_m) + cs;
                     run_m = new_m;
                     if (deg <= LPR) mine = ex / cs;              // the whole row is this chunk: finished in registers
                 }
@@ -308,16 +311,28 @@ __global__ __launch_bounds__(kBlock) void edge_score_subrow_kernel(
         // one group of U edges per sub-wave
         A part[U];
         Pack<T, VEC> z[U];
+#if CLANE_K1_HALF_GROUP
+        // no sub-wave of this wave has more than U/2 edges left in its chunk (most rows of a power-law graph have
+        // 2..4 edges): the second half of the group would only re-read rows with nobody to take the score
+        const bool second_half = __any(n - j > U / 2);
+#else
+        constexpr bool second_half = true;
+#endif
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int cj = lane_get(c, sub_base + ((j + u) & (LPR - 1)));
-            z[u] = load_pack<T, VEC>(Z + int64_t(cj) * ldz + c0s);
+            if (u < U / 2 || second_half) {
+                const int cj = lane_get(c, sub_base + ((j + u) & (LPR - 1)));
+                z[u] = load_pack<T, VEC>(Z + int64_t(cj) * ldz + c0s);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             part[u] = A(0);
+            if (u < U / 2 || second_half) {
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) part[u] = fma(Elem<T>::to_acc(s0.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
+                for (int k = 0; k < VEC; ++k)
+                    part[u] = fma(Elem<T>::to_acc(s0.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
+            }
         }
         A serve = transpose_reduce8<LPR>(part, sl);
         const int idx_serve = (j + sl / (LPR / 8)) & (LPR - 1);
@@ -409,9 +424,11 @@ __global__ __launch_bounds__(kBlock) void edge_score_class_kernel(
     }
 }
 
-// One workgroup per class row: the chunks' {max, sum} combined in slot order (every thread walks the same list: the
-// result does not depend on the thread count), then the row's scores become  exp(score - max) / total
-// (graph.py:122-123).
+// One workgroup per class row: the chunks' {max, sum} combined, then the row's scores become  exp(score - max) / total
+// (graph.py:122-123).  Every wave forms the row's {max, total} on its own and all of them alike: lane l folds the slots
+// l, l + 64, ... in slot order, then a fixed butterfly -- the association depends on the slot count alone (not on the
+// thread count, not on which wave), and a 4 000-slot hub is a chain of 64 dependent steps instead of 4 000 (r03; every
+// thread used to walk the whole list: 0.38 ms of config 4's build_P).
 template <typename A>
 __global__ __launch_bounds__(kBlock) void edge_softmax_class_kernel(const int64_t *__restrict__ rowptr,
                                                                     const int32_t *__restrict__ class_rows,
@@ -419,12 +436,15 @@ __global__ __launch_bounds__(kBlock) void edge_softmax_class_kernel(const int64_
                                                                     const A *__restrict__ stats,
                                                                     A *__restrict__ scores) {
     const int i = blockIdx.x;
+    const int lane = lane_id();
     const int64_t r = class_rows[i];
     const int64_t s0 = slot_ptr[i], s1 = slot_ptr[i + 1];
     A m = -A(INFINITY);
-    for (int64_t s = s0; s < s1; ++s) m = fmax(m, stats[2 * s]);
+    for (int64_t s = s0 + lane; s < s1; s += kWave) m = fmax(m, stats[2 * s]);
+    m = group_max<kWave>(m);
     A total = A(0);
-    for (int64_t s = s0; s < s1; ++s) total += stats[2 * s + 1] * exp_acc<A>(stats[2 * s] - m);
+    for (int64_t s = s0 + lane; s < s1; s += kWave) total += stats[2 * s + 1] * exp_acc<A>(stats[2 * s] - m);
+    total = group_sum<kWave>(total);
     const int64_t e1 = rowptr[r + 1];
     for (int64_t e = rowptr[r] + threadIdx.x; e < e1; e += kBlock) scores[e] = exp_acc<A>(scores[e] - m) / total;
 }

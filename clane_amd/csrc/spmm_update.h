@@ -142,9 +142,11 @@ __device__ __forceinline__ void gather_accumulate(const int32_t *__restrict__ co
 template <int LPR, typename A, int VEC>
 __device__ __forceinline__ void fold_subwaves(A (&acc)[VEC]) {
 #pragma unroll
-    for (int m = LPR; m < kWave; m <<= 1) {
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] += __shfl_xor(acc[k], m, kWave);
+    for (int k = 0; k < VEC; ++k) {
+        if constexpr (LPR <= 4) acc[k] += lane_xor<4>(acc[k]);
+        if constexpr (LPR <= 8) acc[k] += lane_xor<8>(acc[k]);
+        if constexpr (LPR <= 16) acc[k] += lane_xor<16>(acc[k]);
+        if constexpr (LPR <= 32) acc[k] += lane_xor<32>(acc[k]);
     }
 }
 

@@ -93,12 +93,14 @@ def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
 
 class StagedZ:
     """The embeddings of one moment on their way to the host (``SweepEngine.stage_Z``): the sweeps go on while
-    the copy drains over PCIe; ``result()`` waits for it and returns a fresh ``[V, d]`` CPU tensor in vertex order."""
+    the copy drains over PCIe; ``result()`` waits for it and returns a fresh ``[V, d]`` CPU tensor in vertex order.
+    On several GPUs (``stage_Z(pieces=True)``) every rank stages only what it holds -- its columns of all rows, or its
+    own rows -- and ``piece()`` returns that part with where it belongs (``place_piece`` puts parts together)."""
 
-    def __init__(self, engine=None, slot=None, ready: Optional[torch.Tensor] = None):
-        self._engine, self._slot, self._ready = engine, slot, ready
+    def __init__(self, engine=None, slot=None, ready: Optional[torch.Tensor] = None, where: Optional[dict] = None):
+        self._engine, self._slot, self._ready, self._where = engine, slot, ready, where
 
-    def result(self) -> torch.Tensor:
+    def _resolve(self) -> torch.Tensor:
         if self._ready is None:
             eng, slot = self._engine, self._slot
             slot["done"].synchronize()
@@ -106,6 +108,25 @@ class StagedZ:
             eng._release_stage_slot(slot)
             self._engine = self._slot = None
         return self._ready
+
+    def result(self) -> torch.Tensor:
+        if self._where is not None:
+            raise RuntimeError("this copy holds one rank's part of the matrix: use piece() / place_piece()")
+        return self._resolve()
+
+    def piece(self) -> dict:
+        """{'kind': 'columns', 'c0', 'c1', 'Z': [V, c1 - c0]} or {'kind': 'rows', 'vertex': int64 [n], 'Z': [n, d]}."""
+        if self._where is None:
+            raise RuntimeError("this copy holds the whole matrix: use result()")
+        return dict(self._where, Z=self._resolve())
+
+
+def place_piece(out: torch.Tensor, piece: dict) -> None:
+    """Write one rank's part (``StagedZ.piece()``) into the full ``[V, d]`` matrix ``out``."""
+    if piece["kind"] == "columns":
+        out[:, piece["c0"]:piece["c1"]] = piece["Z"]
+    else:
+        out[piece["vertex"]] = piece["Z"]
 
 
 class SweepEngine:
@@ -136,6 +157,7 @@ class SweepEngine:
         if cosine_mode not in ("reference", "per_edge"):
             raise ValueError(f"cosine_mode must be 'reference' or 'per_edge', got {cosine_mode!r}")
         csr.validate()                      # before anything is uploaded or indexed on the device
+        csr.indeg(device)                   # counted once, on THIS engine's card (partition / halo layouts reuse it)
         self.k = kernels if kernels is not None else _hip.kernels()
         self.device = torch.device(device)
         self.dtype = X.dtype
@@ -399,6 +421,7 @@ class SweepEngine:
         self.time_collectives = False
         self.collective_events = []      # [(after kernels, after exchange waits, after all-reduce)]
         self._stage_cv, self._stage_free = threading.Condition(), None      # stage_Z: slots made on first use
+        self._own_vertex = None          # stage_Z(pieces=True) on a row split: vertex id of every own row
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
 
     def _build_p2p_mirrors(self, deg) -> None:
@@ -502,14 +525,21 @@ class SweepEngine:
         self._sync_quiet_rows()
         return self.Zcur[self.pos, :self.d].cpu()
 
-    def stage_Z(self) -> StagedZ:
+    def stage_Z(self, pieces: bool = False) -> StagedZ:
         """Start copying the current embeddings to the host WITHOUT stalling the sweeps (``--save_history`` at
         scale): a device-to-device copy (into vertex order) on the sweep stream (the ping-pong buffer is overwritten two
         sweeps later, long before 2 GB have crossed PCIe), then an asynchronous D2H into pinned memory on a copy
         stream.  At most STAGE_SLOTS copies are in flight; with none free this call waits for ``result()`` of an
-        earlier one (possibly on another thread).  Multi-GPU runs gather synchronously (collective)."""
-        if self.world > 1 or self.device.type != "cuda":
+        earlier one (possibly on another thread).
+        Several GPUs: ``pieces=True`` stages only what THIS rank holds -- its column slice of every row (column
+        split) or its own rows (row splits) -- the same way and with no collective: N PCIe links drain in parallel and
+        whoever wants the whole matrix puts the ranks' pieces together on the host (``StagedZ.piece``,
+        ``place_piece``; ``Embedder`` does, through files).  Without ``pieces`` a multi-GPU run gathers synchronously
+        (``get_Z``: collective), as a host-memory engine does."""
+        if self.device.type != "cuda" or (self.world > 1 and not pieces):
             return StagedZ(ready=self.get_Z())
+        by_rows = self.world > 1 and not self.columns          # this rank's own rows; else all rows (of its columns)
+        n_rows = self.part.n_local if by_rows else self.V
         with self._stage_cv:
             if self._stage_free is None:
                 self._stage_free, self._stage_made = [], 0
@@ -520,18 +550,28 @@ class SweepEngine:
                 slot = self._stage_free.pop()
             else:
                 self._stage_made += 1
-                slot = {"dev": torch.empty(self.V, self.ld, dtype=self.dtype, device=self.device),
-                        "host": torch.empty(self.V, self.ld, dtype=self.dtype, pin_memory=True),
+                slot = {"dev": torch.empty(n_rows, self.ld, dtype=self.dtype, device=self.device),
+                        "host": torch.empty(n_rows, self.ld, dtype=self.dtype, pin_memory=True),
                         "done": torch.cuda.Event()}
         main = torch.cuda.current_stream(self.device)
-        torch.index_select(self.Zcur, 0, self.pos, out=slot["dev"])         # vertex order, on the sweep stream
+        where = None
+        if by_rows:                                             # own rows, block by block (local row order)
+            for b in self.blocks:
+                slot["dev"][self._rows(b)].copy_(self._zrows(self.Zcur, b))
+            if self._own_vertex is None:
+                self._own_vertex = torch.from_numpy(self.local.vertex.astype(np.int64))
+            where = {"kind": "rows", "vertex": self._own_vertex}
+        else:
+            torch.index_select(self.Zcur, 0, self.pos, out=slot["dev"])     # vertex order, on the sweep stream
+            if self.world > 1:
+                where = {"kind": "columns", "c0": self.col0, "c1": self.col1}
         copied = torch.cuda.Event()
         copied.record(main)
         self._copy_stream.wait_event(copied)
         with torch.cuda.stream(self._copy_stream):
             slot["host"].copy_(slot["dev"], non_blocking=True)
             slot["done"].record(self._copy_stream)
-        return StagedZ(self, slot)
+        return StagedZ(self, slot, where=where)
 
     def _release_stage_slot(self, slot) -> None:
         with self._stage_cv:

@@ -125,17 +125,28 @@ def _cached_edge_indices(data_root: Path, vertex_ids: Sequence[str]):
     return src, dst
 
 
-def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray) -> HostCSR:
+def csr_from_edges(num_vertices: int, src: np.ndarray, dst: np.ndarray, device="auto") -> HostCSR:
     """Coalesced adjacency (graph.py:104-110): sorted by (src, dst), duplicates merged, self-loops kept.
-    One sort of the (src, dst) keys.  Large edge lists are sorted on the GPU when there is one (40M edges: 5.4 s with
-    numpy, 2.4 s with torch on 8 host cores, 0.2 s on the card including both copies); a host utility either way."""
+    One sort of the (src, dst) keys.  Large edge lists are sorted on a GPU (40M edges: 5.4 s with numpy, 2.4 s with
+    torch on 8 host cores, 0.2 s on the card including both copies); a host utility either way.  ``device``: the card
+    to borrow -- "auto" (the current one, when there is one: the embedding loop needs it anyway), a device, or None /
+    "cpu" for the host.  A card without room for the keys and the sort's scratch (several times 8 bytes per edge)
+    is not an error: the host sorts instead."""
     n = int(num_vertices)
     key = (torch.from_numpy(np.ascontiguousarray(src, dtype=np.int64)) * n
            + torch.from_numpy(np.ascontiguousarray(dst, dtype=np.int64)))
-    on_card = key.numel() >= GPU_SORT_MIN_EDGES and torch.cuda.is_available()
+    if device == "auto":
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    on_card = (device is not None and torch.device(device).type == "cuda" and key.numel() >= GPU_SORT_MIN_EDGES)
     if on_card:
-        key = key.cuda()
-    key = _sorted_unique(key, 0, n * n)
+        try:
+            return _csr_from_keys(n, _sorted_unique(key.to(device), 0, n * n))
+        except torch.cuda.OutOfMemoryError:
+            torch.cuda.empty_cache()
+    return _csr_from_keys(n, _sorted_unique(key, 0, n * n))
+
+
+def _csr_from_keys(n: int, key: torch.Tensor) -> HostCSR:
     rows = torch.div(key, n, rounding_mode="floor")
     counts = torch.bincount(rows, minlength=n).cpu().numpy()
     rowptr = np.zeros(n + 1, dtype=np.int64)

@@ -62,18 +62,24 @@ class HostCSR:
     def outdeg(self) -> np.ndarray:
         return np.diff(self.rowptr)
 
-    def indeg(self) -> np.ndarray:
-        """In-degree of every vertex (int32 [V]), counted once (on the card when there is one: 40M edges take 0.1 s on
-        the host) and kept; the CSR is not meant to be edited afterwards."""
+    def indeg(self, device=None) -> np.ndarray:
+        """In-degree of every vertex (int32 [V]), counted once and kept; the CSR is not meant to be edited afterwards.
+        Counted on the host unless the caller names a GPU (``SweepEngine`` passes its own: 40M edges take 0.1 s on the
+        host): a host utility never opens a HIP context on a device nobody asked for, and a card without room for the
+        scratch falls back to the host."""
         if self._indeg is None:
             import torch
-            if self.colidx.size >= (1 << 22) and torch.cuda.is_available():
-                total = torch.zeros(self.num_vertices, dtype=torch.int64, device="cuda")
-                for a in range(0, self.colidx.size, 1 << 28):            # pieces: bounded scratch on the card
-                    total += torch.bincount(torch.from_numpy(self.colidx[a:a + (1 << 28)]).cuda(),
-                                            minlength=self.num_vertices)
-                self._indeg = total.to(torch.int32).cpu().numpy()
-            else:
+            on_card = (device is not None and torch.device(device).type == "cuda" and self.colidx.size >= (1 << 22))
+            if on_card:
+                try:
+                    total = torch.zeros(self.num_vertices, dtype=torch.int64, device=device)
+                    for a in range(0, self.colidx.size, 1 << 28):            # pieces: bounded scratch on the card
+                        total += torch.bincount(torch.from_numpy(self.colidx[a:a + (1 << 28)]).to(device),
+                                                minlength=self.num_vertices)
+                    self._indeg = total.to(torch.int32).cpu().numpy()
+                except torch.cuda.OutOfMemoryError:
+                    on_card = False
+            if not on_card:
                 self._indeg = np.bincount(self.colidx, minlength=self.num_vertices).astype(np.int32)
         return self._indeg
 

@@ -78,6 +78,50 @@ def powerlaw_csr(num_vertices: int, num_edges: int, alpha: float = 2.1, max_degr
     return _csr_from_keys(num_vertices, keys)
 
 
+def _unique_keys_csr(num_vertices: int, rows: torch.Tensor, cols: torch.Tensor) -> HostCSR:
+    """CSR of the distinct (row, col) pairs, sorted."""
+    return _csr_from_keys(num_vertices, torch.unique(rows.long() * num_vertices + cols.long()))
+
+
+def regular_csr(num_vertices: int, lo: int, hi: int, seed: int = 11, device: Optional[str] = None) -> HostCSR:
+    """Near-regular graph: every row draws lo..hi (uniform) destinations uniformly at random (the few collisions
+    inside a row are merged) -- no hubs, no skew in either direction: the opposite of R-MAT."""
+    dev = torch.device(device) if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    deg = torch.randint(lo, hi + 1, (num_vertices,), generator=gen, device=dev)
+    rows = torch.repeat_interleave(torch.arange(num_vertices, device=dev), deg)
+    cols = torch.randint(0, num_vertices, (rows.numel(),), generator=gen, device=dev)
+    return _unique_keys_csr(num_vertices, rows, cols)
+
+
+def uniform_random_csr(num_vertices: int, num_edges: int, seed: int = 12, device: Optional[str] = None) -> HostCSR:
+    """``num_edges`` (src, dst) pairs drawn uniformly, duplicates merged (Erdos-Renyi like: Poisson degrees, a quarter
+    of a percent of the pairs collide at 2M / 40M)."""
+    dev = torch.device(device) if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    rows = torch.randint(0, num_vertices, (num_edges,), generator=gen, device=dev)
+    cols = torch.randint(0, num_vertices, (num_edges,), generator=gen, device=dev)
+    return _unique_keys_csr(num_vertices, rows, cols)
+
+
+def star_csr(num_vertices: int, num_stars: int, star_degree: int, background_max_degree: int = 3, seed: int = 13,
+             device: Optional[str] = None) -> HostCSR:
+    """``num_stars`` rows of ``star_degree`` distinct destinations each (star_degree = num_vertices: a row that reads
+    every vertex) over a sparse background of 0..background_max_degree random edges per row: almost all of the
+    edges sit in a handful of mega-hub rows."""
+    dev = torch.device(device) if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    deg = torch.randint(0, background_max_degree + 1, (num_vertices,), generator=gen, device=dev)
+    rows = torch.repeat_interleave(torch.arange(num_vertices, device=dev), deg)
+    cols = torch.randint(0, num_vertices, (rows.numel(),), generator=gen, device=dev)
+    stars = torch.randperm(num_vertices, generator=gen, device=dev)[:num_stars]
+    keys = [rows.long() * num_vertices + cols.long()]
+    for s_ in stars.tolist():
+        dst = torch.randperm(num_vertices, generator=gen, device=dev)[:star_degree]
+        keys.append(s_ * num_vertices + dst.long())
+    return _csr_from_keys(num_vertices, torch.unique(torch.cat(keys)))
+
+
 def uniform_csr(num_vertices: int, num_edges: int, seed: int = 0) -> HostCSR:
     """``num_edges`` distinct directed edges drawn uniformly (Cora-shaped synthetic, config 1)."""
     rng = np.random.default_rng(seed)

@@ -24,6 +24,7 @@ from clane_amd.partition import HostCSR
 from clane_amd.similarity import CosineSimilarity
 from clane_amd import synth
 from oracle import clane_oracle as O
+from oracle import clane_oracle_c as OC
 
 from .conftest import load_golden, write_data_root
 from .test_host_logic import KARATE_LIKE, graph_from_golden
@@ -1067,6 +1068,25 @@ def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
     assert "cpu_baseline" not in r2                                       # N = 1 only, by the bench contract
     assert r2["n_gpus"] == 2 and "column split x2" in r2["config"]["parallelism"] and r2["scaling"] == "strong"
     assert r2["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
+    # what a reader of an N > 1 record has to be able to check: the group the collectives really ran in ...
+    comm = r2["comm"]
+    assert comm["backend"] == "gloo" and comm["ranks_seen"] == 2 and len(comm["devices"]) == 2
+    assert comm["shared_gpu_rehearsal"] and comm["distinct_devices"] == 1 and comm["exchange"] == "columns"
+    assert {dv["rank"] for dv in comm["devices"]} == {0, 1} and len({dv["pid"] for dv in comm["devices"]}) == 2
+    assert comm["exchange_bytes_per_sweep"] == 0 and comm["collective_ms_per_sweep"] > 0      # the scalar all-reduce
+    assert comm["collective_detail"]["sweeps_timed"] > 0 and len(comm["ms_per_step_by_rank"]) == 2
+    assert comm["ms_per_step_rank_min"] <= comm["ms_per_step_rank_max"] <= r2["ms_per_step_max"] * 1.5
+    # ... and north_star's literal division (rows + one all-gather per sweep) measured beside the default one
+    lit = r2["north_star_literal"]
+    assert lit["exchange"] == "allgather_all" and "error" not in lit and lit["value"] > 0
+    assert lit["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and "row split x2" in lit["parallelism"]
+    assert lit["comm"]["exchange"] == "allgather_all" and lit["comm"]["exchange_bytes_per_sweep"] > 0
+    assert lit["comm"]["collectives_issued"]["all_gather"] > 0 and lit["vs_main_division"] == pytest.approx(
+        lit["value"] / r2["value"])
+    assert lit["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
+    assert "north_star_literal" not in r1 and "comm" not in r1
+    # P itself is checked against the oracle's own build_P wherever rank 0 can see all of it
+    assert r1["parity_P_rel_l2_vs_oracle"] < 2e-6 and r2["parity_P_rel_l2_vs_oracle"] < 2e-6
     # a rank that drew a different graph (test hook) is overruled by rank 0's input, not trusted and not fatal
     fixed = subprocess.run(two.args, capture_output=True, text=True, timeout=600, cwd=root,
                            env=dict(env, CLANE_BENCH_PERTURB_RANK="1"))
@@ -1075,6 +1095,11 @@ def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
     assert r3["last_delta"] == pytest.approx(r1["last_delta"], rel=1e-5)
     for r in (r1, r2):
         assert r["steps"] == 4 and r["warmup"] == 2 and r["value"] > 0 and r["roofline"]["bound"] == "hbm"
+        # SURVEY 8d's protocol: 5 blocks of `steps` sweeps, the median reported with its spread
+        assert r["blocks"] == 5 and len(r["block_ms_per_step"]) == 5
+        assert r["ms_per_step_min"] <= r["ms_per_step"] <= r["ms_per_step_max"]
+        assert r["ms_per_step"] == pytest.approx(sorted(r["block_ms_per_step"])[2])
+        assert r["value"] == pytest.approx(1e3 / r["ms_per_step"]) and 0 < r["ms_per_step_hip_events"] <= r["ms_per_step_max"]
         roof = r["roofline"]
         assert 0 < roof["frac"] <= 1.0 and roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"])
         assert roof["achieved"] <= roof["achieved_algorithmic"] + 1e-9 and roof["kernel_config"]["d"] in (64, 32)
@@ -1172,7 +1197,8 @@ def test_cli_two_processes_on_one_gpu_match_one_process(tmp_path):
 
 
 def test_config3_full_size_properties(dev):
-    """BASELINE config 3 at full size (R-MAT 2M / 40M / d=256 fp32), checked through what does not need the whole
+    """BASELINE config 3 at full size (R-MAT 2M / 40M / d=256 fp32): (0) all of P and the whole first sweep against the
+    C oracle running its own build_P and sweep (seconds on the box's host cores); and what does not need the
     oracle: (1) every row of P with edges sums to 1 (graph.py:122-123); (2) 2 000 sampled rows of the first sweep
     against a float64 restatement of embedder.py:88-92 on those rows; (3) rows without out-edges keep z;
     (4) the reported delta is sum|Z_new - Z_old|; (5) two engines give bit-identical results; (6) with P frozen
@@ -1187,8 +1213,21 @@ def test_config3_full_size_properties(dev):
     cs = torch.cat([torch.zeros(1, dtype=torch.float64), P.double().cumsum(0)])
     sums = (cs[torch.from_numpy(csr.rowptr[1:])] - cs[torch.from_numpy(csr.rowptr[:-1])]).numpy()
     assert np.abs(sums[deg > 0] - 1).max() < 1e-4 and np.abs(sums[deg == 0]).max() == 0
+    # (0) reference-mode P itself, all 40M values, against the C oracle's OWN build_P (graph.py:118-128 +
+    # similarity.py:35-37 restated in oracle/clane_oracle.c) -- nothing of the GPU's goes into the expected side
+    P_or, D_or = OC.build_P(csr.rowptr, csr.colidx, X)
+    assert P_or.numel() == P.numel() == E
+    assert O.rel_l2(P, P_or) < 2e-6 and float((P - P_or).abs().max()) < 1e-6
+    hubs = np.argsort(deg)[-3:]
+    for r in hubs:                                             # the heaviest rows on their own (class pass + combine)
+        a, b = csr.rowptr[r], csr.rowptr[r + 1]
+        assert O.rel_l2(P[a:b], P_or[a:b]) < 2e-6, r
     delta = eng.sweep(gamma)
     Z1 = eng.get_Z()
+    # the whole first sweep against the oracle's sweep run with the ORACLE's P
+    Z1_or, delta_or = OC.sweep(csr.rowptr, csr.colidx, P_or, X, X, gamma)
+    assert O.rel_l2(Z1, Z1_or) < 1e-6 and delta == pytest.approx(delta_or, rel=1e-6)
+    del Z1_or
     rows = np.random.default_rng(0).choice(V, size=2000, replace=False)
     rows = np.concatenate([rows, np.argsort(deg)[-3:]])        # and the three heaviest hubs
     Pn, Xn = P.numpy().astype(np.float64), X.numpy()

@@ -495,3 +495,173 @@ def test_check_csr_refuses_what_would_fault_the_gpu(dev, k):
         SweepEngine(broken, synth.gaussian_X(V, 16, seed=22), dev)
     with pytest.raises(ValueError, match=r"X must be \[V, d\]"):
         SweepEngine(csr, synth.gaussian_X(V - 1, 16, seed=22), dev)
+
+
+# ---- BASELINE config 1 at "|E| ~ 10k": the symmetrised Cora-shape graph (cyclic: many sweeps per propagate) ---------
+def test_corashape_symmetrised_to_convergence(tmp_path):
+    """BASELINE configs[1] / SURVEY 8d name the symmetrised variant of the Cora-shape draw (2 708 vertices, 5 429
+    directed edges + their reverses = 10 856 distinct edges, d = 1 433 binary BoW: 6 column tiles of a wave).  Unlike
+    the DAG-like directed draw it has cycles, so a propagate runs ~100 sweeps before the stopping rule
+    (embedder.py:98-108) fires -- the case that exercises that rule on the GPU at this width.  Embedder.iterate()
+    through Graph / the C ABI against the oracle's Embedder, final embeddings within 1e-5 (the bar is 1e-4)."""
+    g = load_golden("g8_corashape.npz")
+    V, d = int(g["V"]), int(g["d"])
+    X = torch.zeros(V, d)
+    X[torch.from_numpy(g["X_nz_row"].astype(np.int64)), torch.from_numpy(g["X_nz_col"].astype(np.int64))] = 1.0
+    src, dst = np.concatenate([g["src"], g["dst"]]), np.concatenate([g["dst"], g["src"]])
+    root = write_data_root(tmp_path / "cora_sym", range(V), src, dst, X.numpy())
+    graph = Graph(root)
+    assert len(graph.E) == 10_858 and graph.csr.num_edges == 10_856        # two pairs were reciprocal already
+    assert np.array_equal(graph.csr.indeg(), np.diff(graph.csr.rowptr))    # symmetric
+    emb = Embedder(graph, CosineSimilarity(), torch.device("cuda"), gamma=0.76, tolerence=10, verbose=False)
+    emb.iterate()
+    orc = O.OracleEmbedder(graph.csr.rowptr, graph.csr.colidx, X, gamma=0.76, tolerence=10)
+    Z_or = orc.iterate()
+    assert O.rel_l2(graph.Z, Z_or) < 1e-5
+    # far from the fixed point the first propagate is well defined (later counts sit on last-ulp noise, SURVEY H4)
+    assert orc.sweep_counts[0] > 60 and abs(emb.sweep_counts[0] - orc.sweep_counts[0]) <= 8
+    assert emb.outer_deltas[0] == pytest.approx(orc.outer_deltas[0], rel=1e-5)
+    # and the fixed point itself: z = x + gamma P z with P rebuilt from z (embedder.py:92, graph.py:118-128)
+    Zf = graph.Z
+    P_f = O.build_P_values(graph.csr.rowptr, graph.csr.colidx, Zf)
+    Z_next, _ = O.sweep(graph.csr.rowptr, graph.csr.colidx, P_f, X, Zf, 0.76)
+    assert O.rel_l2(Z_next, Zf) < 1e-5
+
+
+# ---- a mega-hub row in the default suite: 1M+ edges through the class pass and its many-slot combine ----------------
+def test_mega_hub_row_through_class_pass(dev):
+    """One row of 1 050 000 edges (and one of 300 000) at d = 256 fp32 over a sparse background of 1.1M vertices:
+    the hub takes the XCD-affine pass as ~4 100 chunks whose partial sums spmm_class_combine_kernel adds in slot order,
+    and edge_softmax_class_kernel combines as many {max, sum} pairs (embedder.py:90-92 and graph.py:122-123 have no
+    degree limit).  build_P and two sweeps against the C oracle, which builds its own P; the hub rows on their own;
+    and in per-edge mode (where the softmax moves with every score) the hub's P against float64."""
+    from oracle import clane_oracle_c as OC
+    V, d, gamma = 1_100_000, 256, 0.76
+    rng = np.random.default_rng(77)
+    deg = rng.integers(0, 4, size=V)                      # background: 0..3 edges, a quarter of the rows are sinks
+    hubs = {12_345: 1_050_000, 777_777: 300_000}
+    for r, n in hubs.items():
+        deg[r] = n
+    rowptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    cols = rng.integers(0, V, size=int(rowptr[-1])).astype(np.int32)
+    for r, n in hubs.items():
+        cols[rowptr[r]:rowptr[r + 1]] = rng.choice(V, size=n, replace=False)
+    # rows sorted by column, duplicates inside a short row made distinct (a CSR row holds a column once)
+    order = np.lexsort((cols, np.repeat(np.arange(V), deg)))
+    cols = cols[order]
+    dup = np.nonzero((cols[1:] == cols[:-1]) & (np.repeat(np.arange(V), deg)[1:] == np.repeat(np.arange(V), deg)[:-1]))[0]
+    keep = np.ones(cols.size, dtype=bool)
+    keep[dup + 1] = False
+    row_of = np.repeat(np.arange(V), deg)[keep]
+    cols = cols[keep]
+    rowptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(np.bincount(row_of, minlength=V), out=rowptr[1:])
+    csr = HostCSR(V, rowptr, cols)
+    E = csr.num_edges
+    X = synth.gaussian_X(V, d, seed=78)
+    eng = SweepEngine(csr, X, dev)
+    assert eng.class_threshold == 64 and eng.class_rows[0] is not None and eng.class_rows[0][0].numel() == 2
+    assert eng.class_slots[0] >= (1_050_000 + 300_000) // eng.class_chunk       # thousands of slots behind two rows
+    eng.build_P()
+    P = eng.P_global()
+    P_or, _ = OC.build_P(csr.rowptr, csr.colidx, X)
+    assert P.numel() == E and O.rel_l2(P, P_or) < 2e-6
+    for r in hubs:
+        a, b = rowptr[r], rowptr[r + 1]
+        assert O.rel_l2(P[a:b], P_or[a:b]) < 2e-6 and float(P[a:b].double().sum()) == pytest.approx(1.0, abs=1e-5)
+    Z_or = X
+    for _ in range(2):
+        delta = eng.sweep(gamma)
+        Z_or, delta_or = OC.sweep(csr.rowptr, csr.colidx, P_or, X, Z_or, gamma)
+        assert delta == pytest.approx(delta_or, rel=1e-6)
+    Z = eng.get_Z()
+    assert O.rel_l2(Z, Z_or) < 1e-6
+    for r in hubs:
+        assert O.rel_l2(Z[r], Z_or[r]) < 2e-6
+    sink = torch.from_numpy(np.diff(rowptr) == 0)
+    assert torch.equal(Z[sink], X[sink])
+    # bitwise repeatable: the slot order alone fixes the association of the 4 000 partial sums
+    eng_b = SweepEngine(csr, X, dev)
+    eng_b.build_P()
+    assert torch.equal(eng_b.P, eng.P)
+    for _ in range(2):
+        eng_b.sweep(gamma)
+    assert torch.equal(eng_b.Zcur, eng.Zcur)
+    del eng_b, eng
+    # per-edge cosine: the hub's scores differ edge by edge, its softmax is no longer 1/deg
+    eng_p = SweepEngine(csr, X, dev, cosine_mode="per_edge")
+    eng_p.build_P()
+    P_pe = eng_p.P_global()
+    want = per_edge_rows_f64(csr, X, list(hubs) + [5, 6, 7, 8])
+    for r, w in want.items():
+        a, b = rowptr[r], rowptr[r + 1]
+        if b > a:
+            assert np.linalg.norm(P_pe[a:b].numpy() - w) <= 2e-6 * np.linalg.norm(w), r
+    hub = P_pe[rowptr[12_345]:rowptr[12_346]]
+    assert float(hub.max() / hub.min()) > 1.2                    # the softmax did move
+
+
+# ---- the driver's N = 8 shape, rehearsed with as many ranks as one card may hold ------------------------------------
+def test_bench_five_ranks_share_one_gpu_with_an_idle_column_rank():
+    """`python bench.py --gpus N` as the driver starts it (no launcher), with more ranks than a row has 16-byte packs:
+    `tiny16` (d = 16 fp32 = 4 packs) over 5 ranks leaves rank 4 without columns -- the shape of karate-sized inputs on
+    an 8-GPU node.  5 ranks, not 8: a GPU box admits 6 processes on its card and this test process is one of them.
+    The record must describe the group the collectives ran in (`comm`), carry north_star's literal division beside
+    the default one (`north_star_literal`), and both must match the C oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    run = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "5", "--backend", "gloo", "--share-gpu",
+                          "--workload", "tiny16", "--exchange", "columns", "--steps", "3", "--warmup", "1", "--blocks",
+                          "3"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 5 and r["blocks"] == 3 and "column split x5" in r["config"]["parallelism"]
+    assert r["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and r["parity_P_rel_l2_vs_oracle"] < 2e-6
+    comm = r["comm"]
+    assert comm["ranks_seen"] == 5 and len(comm["devices"]) == 5 and len(comm["ms_per_step_by_rank"]) == 5
+    assert comm["backend"] == "gloo" and comm["exchange"] == "columns" and comm["exchange_bytes_per_sweep"] == 0
+    assert all(dv["name"] == comm["devices"][0]["name"] for dv in comm["devices"])
+    lit = r["north_star_literal"]
+    assert "error" not in lit and lit["exchange"] == "allgather_all" and lit["comm"]["ranks_seen"] == 5
+    assert lit["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and lit["comm"]["exchange_bytes_per_sweep"] > 0
+    assert len(lit["comm"]["exchange_bytes_per_sweep_by_rank"]) == 5
+    assert lit["last_delta"] == pytest.approx(r["last_delta"], rel=1e-5)
+
+
+# ---- the row-binning heuristics on graphs off their tuning set (results must not depend on them) --------------------
+@pytest.mark.parametrize("family", ["regular", "uniform", "stars"])
+@pytest.mark.parametrize("dtype,d", [(torch.float32, 256), (torch.bfloat16, 128)])
+def test_thresholds_off_the_tuning_set(dev, family, dtype, d):
+    """The thresholds that deal rows to kernels were swept on R-MAT and one power-law draw (engine.py, xcd.py).  Here:
+    a near-regular graph (every row 48..80 edges: at 1-KiB rows ALL rows sit around the class threshold of 64), a
+    uniform random one, and a star-heavy one (rows that read every vertex).  With the default thresholds, with the
+    class pass off and with the class threshold moved, build_P and two sweeps match the C oracle -- speed is
+    tools/threshold_robustness.py's business (profiles/r03_threshold_robustness.md), results are this test's."""
+    from oracle import clane_oracle_c as OC
+    V = 60_000
+    csr = {"regular": lambda: synth.regular_csr(V, 48, 80, device=str(dev)),
+           "uniform": lambda: synth.uniform_random_csr(V, 1_200_000, device=str(dev)),
+           "stars": lambda: synth.star_csr(V, 4, V, device=str(dev))}[family]()
+    X = synth.gaussian_X(V, d, seed=31).to(dtype)
+    Xf = X.float()
+    P_or, _ = OC.build_P(csr.rowptr, csr.colidx, Xf)
+    Z_or = Xf
+    for _ in range(2):
+        Z_or, _ = OC.sweep(csr.rowptr, csr.colidx, P_or, Xf, Z_or, 0.76)
+    tol_p, tol_z = (1e-4, 8e-3) if dtype == torch.bfloat16 else (2e-6, 1e-6)
+    seen = set()
+    for kw in ({}, {"class_threshold": 0}, {"class_threshold": 32}, {"class_threshold": 512}, {"long_threshold": 16}):
+        eng = SweepEngine(csr, X, dev, **kw)
+        seen.add((eng.class_threshold, eng.long_threshold, eng.class_rows[0] is not None))
+        eng.build_P()
+        assert O.rel_l2(eng.P_global().float(), P_or) < tol_p, (family, kw)
+        for _ in range(2):
+            eng.sweep(0.76)
+        assert O.rel_l2(eng.get_Z().float(), Z_or) < tol_z, (family, kw)
+    assert len(seen) >= 4                       # the variants really took different kernels

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""The row-binning heuristics (engine.py: LONG_THRESHOLD_BY_ROWS_PER_WAVE, the size rule; xcd.py: CLASS_THRESHOLD_*,
+PHASES_*) were tuned on R-MAT and one power-law draw.  This runs them on graphs OFF that tuning set -- a near-regular
+graph (every row 48..80 edges), a uniform random one (Poisson degrees), a star-heavy one (10 rows that read every
+vertex) -- at d = 256 fp32 (1-KiB rows) and d = 128 bf16 (256-byte rows), against the obvious alternatives: class pass
+off, class threshold halved / doubled / x4, phases off.  Results never depend on the variant (asserted: first sweep
+against the C oracle for the default, every variant against the default to 1e-5); the table shows whether the defaults
+are within ~10 % of the best variant.
+Usage: tools/threshold_robustness.py [--scale 1.0] [--out profiles/r03_threshold_robustness.md]"""
+import argparse, json, sys, time
+from pathlib import Path
+import numpy as np
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from clane_amd import _hip, synth
+from clane_amd.engine import SweepEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scale", type=float, default=1.0, help="1.0: 2M vertices (the sizes VERDICT r02 names)")
+ap.add_argument("--steps", type=int, default=15)
+ap.add_argument("--out", default=None)
+ap.add_argument("--no-oracle", action="store_true")
+args = ap.parse_args()
+dev = _hip.require_gpu("cuda:0")
+V = int(2_000_000 * args.scale)
+GRAPHS = {
+    "near-regular (rows of 48..80 edges)": lambda: synth.regular_csr(V, 48, 80, device=str(dev)),
+    "uniform random (40M pairs, Poisson degrees)": lambda: synth.uniform_random_csr(V, int(40_000_000 * args.scale), device=str(dev)),
+    "star-heavy (10 rows that read every vertex)": lambda: synth.star_csr(V, 10, V, device=str(dev)),
+}
+SHAPES = [(256, torch.float32, "d=256 fp32 (1-KiB rows)"), (128, torch.bfloat16, "d=128 bf16 (256-B rows)")]
+
+
+def variants(eng0):
+    ct = eng0.class_threshold
+    out = {"default": {}, "class pass off": {"class_threshold": 0}}
+    for f, name in ((0.5, "class threshold / 2"), (2, "class threshold x 2"), (4, "class threshold x 4")):
+        out[name] = {"class_threshold": max(8, int(ct * f))}
+    if eng0.class_phases > 1:
+        out["phases off"] = {"class_phases": 1}
+    return out
+
+
+def timed(eng, steps):
+    eng.build_P()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.build_P()
+    torch.cuda.synchronize()
+    bp = (time.perf_counter() - t0) * 1e3
+    for _ in range(3):
+        eng.sweep(0.76)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.sweep(0.76)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, bp
+
+
+lines = ["# Row-binning heuristics off their tuning set (r03, `tools/threshold_robustness.py`)", "",
+         f"|V| = {V}; sweep ms / build_P ms per variant; `behind` = default's sweep time over the best variant's.", ""]
+records = []
+for gname, make in GRAPHS.items():
+    csr = make()
+    deg = np.diff(csr.rowptr)
+    for d, dtype, sname in SHAPES:
+        X = synth.gaussian_X(V, d, seed=5).to(dtype)
+        eng = SweepEngine(csr, X, dev)
+        var = variants(eng)
+        ref = None
+        row = {}
+        for vname, kw in var.items():
+            if vname != "default":
+                eng = SweepEngine(csr, X, dev, **kw)
+            eng.build_P()
+            eng.sweep(0.76)
+            Z1 = eng.get_Z()
+            if ref is None:
+                ref = Z1
+                if not args.no_oracle:
+                    from oracle import clane_oracle as O
+                    from oracle import clane_oracle_c as OC
+                    Xf = X.float()
+                    P_or, _ = OC.build_P(csr.rowptr, csr.colidx, Xf)
+                    Z_or, _ = OC.sweep(csr.rowptr, csr.colidx, P_or, Xf, Xf, 0.76)
+                    err = O.rel_l2(Z1.float(), Z_or)
+                    assert err < (8e-3 if dtype == torch.bfloat16 else 1e-5), (gname, sname, err)
+                    row["parity_vs_oracle"] = err
+                    del P_or, Z_or
+            else:
+                diff = float((Z1.double() - ref.double()).norm() / ref.double().norm())
+                assert diff < (8e-3 if dtype == torch.bfloat16 else 1e-5), (gname, sname, vname, diff)
+            eng.set_Z(X)
+            ms, bp = timed(eng, args.steps)
+            row[vname] = {"sweep_ms": round(ms, 3), "build_P_ms": round(bp, 3), "class_threshold": eng.class_threshold,
+                          "long_threshold": eng.long_threshold, "phases": eng.class_phases,
+                          "class_rows": int(sum(0 if c is None else c[0].numel() for c in eng.class_rows))}
+            del eng
+            torch.cuda.empty_cache()
+        best = min(v["sweep_ms"] for k_, v in row.items() if isinstance(v, dict))
+        behind = row["default"]["sweep_ms"] / best
+        rec = {"graph": gname, "shape": sname, "edges": int(csr.num_edges), "max_degree": int(deg.max()),
+               "behind_best": round(behind, 3), **row}
+        records.append(rec)
+        print(json.dumps(rec), flush=True)
+        lines += [f"## {gname}, {sname} -- {csr.num_edges} edges, max degree {int(deg.max())}", "",
+                  "| variant | class threshold | T | phases | class rows | sweep ms | build_P ms |", "|---|---|---|---|---|---|---|"]
+        for vname in var:
+            v = row[vname]
+            lines.append(f"| {vname} | {v['class_threshold']} | {v['long_threshold']} | {v['phases']} | {v['class_rows']} | "
+                         f"{v['sweep_ms']:.3f} | {v['build_P_ms']:.3f} |")
+        lines += ["", f"default behind the best variant by **{(behind - 1) * 100:.1f} %**"
+                      + (f"; first sweep vs the C oracle {row['parity_vs_oracle']:.1e}" if "parity_vs_oracle" in row else ""), ""]
+if args.out:
+    Path(args.out).write_text("\n".join(lines) + "\n")
