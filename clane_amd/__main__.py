@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import shutil
 from pathlib import Path
 
 import numpy as np
@@ -93,12 +94,16 @@ def embedding(args):
                 folder.mkdir(parents=True, exist_ok=True)
                 np.save(folder.joinpath(f'Z_{sweep}.npy'), _to_numpy(Z))
         extra["history_sink"] = write_sweep
+        if world > 1:       # every rank stages its own part of Z; rank 0's writer thread assembles them (one box: same disk)
+            extra["history_parts_dir"] = args.output_root.joinpath(".clane_history_parts")
     embedder = embedder_cls(graph=g, similarity_measure=similarity_measure, device=device,
                             save_history=args.save_history, **extra, **hparams["embedder"])
     if rank != 0:
         embedder.verbose = False
     embedder.iterate()
     final_Z = g.Z                                   # collective when world > 1: every rank takes part
+    if "history_parts_dir" in extra and rank == 0:
+        shutil.rmtree(extra["history_parts_dir"], ignore_errors=True)      # iterate() flushed: every part was consumed
     if world > 1:                                   # leave together: nobody tears the group down while others talk
         import torch.distributed as dist
         dist.barrier()

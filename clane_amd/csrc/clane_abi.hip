@@ -451,8 +451,7 @@ const char *clane_build_info(void) {
     return "arch=gfx950;SPMM_U=" CLANE_STR(CLANE_SPMM_U) ";LONG_U=" CLANE_STR(CLANE_LONG_U) ";LONG_WAVES=" CLANE_STR(
         CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM)
         ";TARGET_GRID=" CLANE_STR(CLANE_TARGET_GRID) ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH)
-        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";K1_HALF_GROUP=" CLANE_STR(
-            CLANE_K1_HALF_GROUP);
+        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP);
 }
 
 int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *stream) {

@@ -24,10 +24,6 @@
 
 namespace clane {
 
-#ifndef CLANE_K1_HALF_GROUP
-#define CLANE_K1_HALF_GROUP 0     // edge_score_subrow_kernel: skip a group's second half when no sub-wave needs it
-#endif
-
 constexpr int kScoreReference = 0;
 constexpr int kScorePerEdge = 1;
 constexpr int kScoreRawDot = 2;
@@ -311,28 +307,19 @@ __global__ __launch_bounds__(kBlock) void edge_score_subrow_kernel(
         // one group of U edges per sub-wave
         A part[U];
         Pack<T, VEC> z[U];
-#if CLANE_K1_HALF_GROUP
-        // no sub-wave of this wave has more than U/2 edges left in its chunk (most rows of a power-law graph have
-        // 2..4 edges): the second half of the group would only re-read rows with nobody to take the score
-        const bool second_half = __any(n - j > U / 2);
-#else
-        constexpr bool second_half = true;
-#endif
+        // (Skipping the second half of a group when no sub-wave has more than 4 edges left -- most rows of a power-law
+        // graph have 2..4 -- was tried and lost: the wave-uniform branch breaks the run of 8 loads, 4.67 -> 7.99 ms at
+        // config 4's shape, profiles/r03_k1_subrow.md.)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (u < U / 2 || second_half) {
-                const int cj = lane_get(c, sub_base + ((j + u) & (LPR - 1)));
-                z[u] = load_pack<T, VEC>(Z + int64_t(cj) * ldz + c0s);
-            }
+            const int cj = lane_get(c, sub_base + ((j + u) & (LPR - 1)));
+            z[u] = load_pack<T, VEC>(Z + int64_t(cj) * ldz + c0s);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             part[u] = A(0);
-            if (u < U / 2 || second_half) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k)
-                    part[u] = fma(Elem<T>::to_acc(s0.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
-            }
+            for (int k = 0; k < VEC; ++k) part[u] = fma(Elem<T>::to_acc(s0.v[k]), Elem<T>::to_acc(z[u].v[k]), part[u]);
         }
         A serve = transpose_reduce8<LPR>(part, sl);
         const int idx_serve = (j + sl / (LPR / 8)) & (LPR - 1);

@@ -13,6 +13,7 @@ import math
 import time
 import queue
 import threading
+from pathlib import Path
 from typing import Callable, Optional
 
 import torch
@@ -42,6 +43,7 @@ class Embedder(object):
         verbose:            bool = True,
         max_sweeps:         Optional[int] = None,
         history_sink:       Optional[Callable[[int, int, torch.Tensor], None]] = None,
+        history_parts_dir=None,
         skip_idle_sweeps:   bool = True,
         lagged_check:       Optional[bool] = None,
     ) -> None:
@@ -87,6 +89,11 @@ class Embedder(object):
         # history_sink(outer, sweep, Z): with save_history, every sweep's embeddings are handed to it from a
         # writer thread, in order, instead of being kept in `history["Z"]` -- the copy to the host overlaps the
         # following sweeps (SweepEngine.stage_Z).  Call flush_history() (iterate() does) before relying on it.
+        # history_parts_dir (several GPUs): a directory every rank of the box can write.  Each rank then stages only
+        # the part of Z it holds (SweepEngine.stage_Z(pieces=True): no collective, N PCIe links in parallel), its
+        # writer thread drops the part there, and rank 0's writer thread puts the parts together for the sink -- the
+        # sweeps do not wait for any of it.  Without it a multi-GPU run gathers Z synchronously for every sweep.
+        self._parts_dir = Path(history_parts_dir) if history_parts_dir is not None else None
         self._writer = _HistoryWriter(history_sink) if (save_history and history_sink is not None) else None
 
     class Tolerence:
@@ -146,6 +153,17 @@ class Embedder(object):
         if self._writer is not None:
             self._writer.flush()
 
+    def _stage(self, engine, world: int):
+        """This sweep's embeddings on their way to the host (None: the engine cannot stage -- take them now)."""
+        if not hasattr(engine, "stage_Z"):
+            return None
+        pieces = (world > 1 and self._writer is not None and self._parts_dir is not None
+                  and getattr(engine, "device", torch.device("cpu")).type == "cuda")
+        if pieces and self._writer.assembler is None:
+            self._writer.assembler = _PartsAssembler(self._parts_dir, engine.comm.rank, world,
+                                                     (engine.V, engine.d_full), engine.dtype)
+        return engine.stage_Z(pieces=True) if pieces else engine.stage_Z()
+
     @torch.no_grad()
     def propagate(self, _replay: bool = False):
         """Jacobi sweeps with P frozen until `tolerence` consecutive sweeps bring no new
@@ -192,7 +210,7 @@ class Embedder(object):
             n_sweeps += 1
             if self.save_history:
                 if not idle or staged is None:      # an idle sweep leaves the embeddings as they are: same copy
-                    staged = engine.stage_Z() if hasattr(engine, "stage_Z") else None
+                    staged = self._stage(engine, world)
                 if staged is None:
                     history_Z.append(engine.get_Z())
                 elif self._writer is not None:
@@ -237,11 +255,47 @@ class Embedder(object):
                 return
 
 
+class _PartsAssembler:
+    """Several GPUs, one box: every rank's writer thread saves the part of Z it staged as a file in a directory
+    they all see; rank 0's writer thread waits for the N parts of a sweep, puts them together (``place_piece``) and
+    removes them.  No collective runs on a side thread, nothing runs on the sweep's stream."""
+    PATIENCE_S = 600.0
+
+    def __init__(self, parts_dir: Path, rank: int, world: int, shape, dtype: torch.dtype):
+        self.dir, self.rank, self.world, self.shape, self.dtype = Path(parts_dir), rank, world, tuple(shape), dtype
+        self.dir.mkdir(parents=True, exist_ok=True)
+
+    def _path(self, outer: int, sweep: int, rank: int) -> Path:
+        return self.dir / f"o{outer}_s{sweep}.r{rank}.pt"
+
+    def collect(self, outer: int, sweep: int, staged):
+        """Save this rank's part; rank 0: the whole [V, d] matrix of that sweep, the other ranks: None."""
+        mine = self._path(outer, sweep, self.rank)
+        tmp = mine.with_suffix(".tmp")
+        torch.save(staged.piece(), tmp)
+        tmp.rename(mine)                        # a part is either absent or complete
+        if self.rank != 0:
+            return None
+        from .engine import place_piece
+        Z = torch.empty(self.shape, dtype=self.dtype)
+        deadline = time.monotonic() + self.PATIENCE_S
+        for q in range(self.world):
+            path = self._path(outer, sweep, q)
+            while not path.exists():
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"history: rank {q}'s part of round {outer} sweep {sweep} never arrived in {self.dir}")
+                time.sleep(0.002)
+            place_piece(Z, torch.load(path))
+            path.unlink()
+        return Z
+
+
 class _HistoryWriter:
     """One thread that resolves staged copies in order and hands them to the sink."""
 
     def __init__(self, sink):
         self.sink, self.q, self.error = sink, queue.Queue(), None
+        self.assembler: Optional[_PartsAssembler] = None
         self.thread = threading.Thread(target=self._run, name="clane-history", daemon=True)
         self.thread.start()
 
@@ -249,8 +303,9 @@ class _HistoryWriter:
         while True:
             outer, sweep, staged = self.q.get()
             try:
-                Z = staged.result()             # always resolve: frees the staging slot even after an error
-                if self.error is None:
+                # always resolve: frees the staging slot even after an error
+                Z = staged.result() if getattr(staged, "_where", None) is None else self.assembler.collect(outer, sweep, staged)
+                if self.error is None and Z is not None:
                     self.sink(outer, sweep, Z)
             except BaseException as exc:        # surfaced by flush()
                 self.error = self.error or exc

@@ -126,7 +126,8 @@ def place_piece(out: torch.Tensor, piece: dict) -> None:
     if piece["kind"] == "columns":
         out[:, piece["c0"]:piece["c1"]] = piece["Z"]
     else:
-        out[piece["vertex"]] = piece["Z"]
+        real = piece["vertex"] >= 0                     # padding rows of an equal-size row division hold no vertex
+        out[piece["vertex"][real]] = piece["Z"][real]
 
 
 class SweepEngine:

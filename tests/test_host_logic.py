@@ -436,6 +436,86 @@ def test_history_sink_receives_every_sweep_in_order(tmp_path):
         emb.iterate()
 
 
+def test_history_parts_of_several_ranks_are_put_together(tmp_path):
+    """--save_history on several GPUs: every rank's writer thread saves the part of Z it staged, rank 0's writer puts
+    the parts of a sweep together for the sink, in order, and leaves no part behind.  Three "ranks" as writer threads
+    of one process: two column slices and... a row split with padding rows; parts arrive late and out of order."""
+    import threading
+    import time
+    from clane_amd.embedder import _HistoryWriter, _PartsAssembler
+    from clane_amd.engine import StagedZ, place_piece
+    V, d, W = 11, 6, 3
+    gen = torch.Generator().manual_seed(0)
+    sweeps = [torch.randn(V, d, generator=gen) for _ in range(5)]
+
+    def pieces_of(Z, kind):
+        if kind == "columns":
+            cuts = [(0, 2), (2, 4), (4, 6)]
+            return [{"kind": "columns", "c0": a, "c1": b} | {"Z": Z[:, a:b].clone()} for a, b in cuts]
+        owner = [torch.tensor([0, 3, 6, 9]), torch.tensor([1, 4, 7, 10]), torch.tensor([2, 5, 8, -1])]   # -1: padding
+        return [{"kind": "rows", "vertex": v, "Z": torch.where(v[:, None] >= 0, Z[v.clamp_min(0)], torch.full((1, d), 9.0))}
+                for v in owner]
+
+    for kind in ("columns", "rows"):
+        got = []
+        writers = []
+        for r in range(W):
+            w = _HistoryWriter((lambda o, s, Z: got.append((o, s, Z))) if r == 0 else (lambda o, s, Z: 1 / 0))
+            w.assembler = _PartsAssembler(tmp_path / kind, r, W, (V, d), torch.float32)
+            writers.append(w)
+
+        def feed(r, delay):
+            for i, Z in enumerate(sweeps):
+                time.sleep(delay)
+                piece = pieces_of(Z, kind)[r]
+                st = StagedZ(ready=piece.pop("Z"), where=piece)
+                writers[r].submit(i // 3, i % 3, st)
+        threads = [threading.Thread(target=feed, args=(r, 0.01 * (W - r))) for r in range(W)]   # rank 0 is the slowest
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for w in writers:
+            w.flush()                       # the other ranks' sinks (1 / 0) were never called: only rank 0 gets matrices
+        assert [(o, s) for o, s, _ in got] == [(i // 3, i % 3) for i in range(5)]
+        for (_, _, Z), want in zip(got, sweeps):
+            assert torch.equal(Z, want)
+        assert list((tmp_path / kind).iterdir()) == []
+    full = torch.zeros(V, d)
+    for piece in pieces_of(sweeps[0], "rows"):
+        place_piece(full, piece)
+    assert torch.equal(full, sweeps[0])
+    with pytest.raises(RuntimeError, match="piece"):
+        StagedZ(ready=sweeps[0], where={"kind": "columns", "c0": 0, "c1": d}).result()
+    with pytest.raises(RuntimeError, match="result"):
+        StagedZ(ready=sweeps[0]).piece()
+
+
+def test_kernel_backend_contract_is_enforced():
+    """Every call the engine makes on its kernel object is an abstract method of ``KernelBackend``: an implementation
+    that lacks one cannot be instantiated (so nothing -- the CSR check, say -- is skipped silently), the engine does
+    not probe its kernel object for optional methods, and the binding and the test double implement the same list."""
+    import inspect
+    from clane_amd._hip import HipKernels, KernelBackend
+    from .oracle_kernels import OracleKernels
+    need = KernelBackend.__abstractmethods__
+    assert {"check_csr", "spmm_update", "edge_score", "edge_score_class", "make_mirror", "build_info"} <= need
+    assert not HipKernels.__abstractmethods__ and not OracleKernels.__abstractmethods__
+
+    class Lacking(OracleKernels):
+        check_csr = KernelBackend.check_csr         # abstract again
+    Lacking.__abstractmethods__ = frozenset({"check_csr"})
+    with pytest.raises(TypeError, match="abstract"):
+        Lacking()
+    import clane_amd.engine as E
+    src = inspect.getsource(E)
+    assert "hasattr(self.k" not in src and "getattr(self.k" not in src
+    # what the engine calls on self.k is all in the contract
+    import re
+    called = set(re.findall(r"(?:self\.k|\bk)\.([a-z_0-9]+)\(", src)) | set(re.findall(r'_bind\("([a-z_]+)"', src))
+    assert called and called <= need | {"bind"}, called - need
+
+
 def test_embedder_prints_delta_and_tolerance_per_sweep(tmp_path):
     gold, g = graph_from_golden(tmp_path, "g7_readme5.npz")
     attach_cpu_engine(g)
