@@ -208,8 +208,16 @@ __global__ __launch_bounds__(kBlock) void edge_score_kernel(
 //   done    -- no rows left in the block: the lanes carry on with zero-weight reads of table row 0 (an L1 hit).
 // Every edge goes through the same fma chain and the same exchange tree as in score_edge_range: the scores are
 // bit-identical to the one-wave and the long-row kernels'.
+#ifndef CLANE_K1_MIN_WAVES
+#define CLANE_K1_MIN_WAVES 0      // edge_score_subrow_kernel: __launch_bounds__ 2nd argument (waves per SIMD), 0 = unconstrained
+#endif
+#if CLANE_K1_MIN_WAVES > 0
+#define CLANE_K1_BOUNDS __launch_bounds__(kBlock, CLANE_K1_MIN_WAVES)
+#else
+#define CLANE_K1_BOUNDS __launch_bounds__(kBlock)
+#endif
 template <typename T, int VEC, int LPR, int U>
-__global__ __launch_bounds__(kBlock) void edge_score_subrow_kernel(
+__global__ CLANE_K1_BOUNDS void edge_score_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows, int64_t row0,
     const T *__restrict__ Z, int64_t ldz, int d, int mode, const double *__restrict__ sums2,
     const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores,
