@@ -48,7 +48,7 @@ WORKLOADS = {
     "rmat200k": ("rmat", 200_000, 4_000_000, 128, "f32", 1, 2),       # BASELINE config 2
     "powerlaw10m": ("powerlaw", 10_000_000, 200_000_000, 128, "bf16", 5, 6),   # BASELINE config 4 (shape)
     "tiny": ("rmat", 20_000, 200_000, 64, "f32", 7, 8),
-    "tiny16": ("rmat", 20_000, 200_000, 16, "f32", 7, 8),             # 4 packs a row: more ranks than packs leaves idle column ranks
+    "tiny12": ("rmat", 20_000, 200_000, 12, "f32", 7, 8),             # 3 packs a row: more ranks than packs leaves idle column ranks
     # 8x config 3: a 16 GiB embedding matrix (byte offsets beyond 32 bits, ~85 GB of HBM in use) -- capacity check
     "rmat16m": ("rmat", 16_000_000, 320_000_000, 256, "f32", 9, 10),
 }
