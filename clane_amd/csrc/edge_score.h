@@ -202,17 +202,19 @@ __global__ __launch_bounds__(kBlock) void edge_score_kernel(
 //   score   -- LPR buffered edges (one column per lane), consumed 8 at a time: 8 branch-free neighbour-row
 //              loads, 8 partial dots, the transposed butterfly over the LPR lanes, the finished scores handed
 //              to lane = edge; after a chunk the running max / sum of the row and one coalesced store;
-//   rescale -- a row of more than LPR edges is soft-maxed by a second pass over the sub-wave's own stores,
-//              one LPR-edge chunk per iteration (each lane re-reads what it wrote) while the other sub-waves
-//              of the wave keep gathering;
+//   rescale -- a row of more than LPR edges is soft-maxed by a second pass over the sub-wave's own stores (each
+//              lane re-reads what it wrote), except for its last chunk, which leaves normalised from the registers;
+//              four chunks per visit (independent loads: one round trip), so a row of up to 5 chunks is done in
+//              the visit that finished its last chunk, a longer one while the other sub-waves keep gathering;
 //   done    -- no rows left in the block: the lanes carry on with zero-weight reads of table row 0 (an L1 hit).
 // Every edge goes through the same fma chain and the same exchange tree as in score_edge_range: the scores are
 // bit-identical to the one-wave and the long-row kernels'.
 #ifndef CLANE_K1_MIN_WAVES
-#define CLANE_K1_MIN_WAVES 0      // edge_score_subrow_kernel: __launch_bounds__ 2nd argument (waves per SIMD), 0 = unconstrained
+#define CLANE_K1_MIN_WAVES 7      // edge_score_subrow_kernel: __launch_bounds__ 2nd argument (waves per SIMD), 0 = unconstrained;
+                                  // 7 = 72 VGPRs, no spills (config 4's shape: 4.61 -> 4.41 ms; 8 spills: 6.41, profiles/r03_k1_subrow.md)
 #endif
-#if CLANE_K1_MIN_WAVES > 0
-#define CLANE_K1_BOUNDS __launch_bounds__(kBlock, CLANE_K1_MIN_WAVES)
+#if CLANE_K1_MIN_WAVES > 0      // fp64 accumulators need the registers: unconstrained there (the bound made them spill 64 bytes a lane)
+#define CLANE_K1_BOUNDS __launch_bounds__(kBlock, (sizeof(typename Elem<T>::acc_t) == 8 ? 1 : CLANE_K1_MIN_WAVES))
 #else
 #define CLANE_K1_BOUNDS __launch_bounds__(kBlock)
 #endif
@@ -225,6 +227,10 @@ __global__ CLANE_K1_BOUNDS void edge_score_subrow_kernel(
     using A = typename Elem<T>::acc_t;
     static_assert(LPR < kWave && LPR >= 8 && U == 8 && LPR % U == 0, "sub-wave layout");
     constexpr int kClaim = 0, kScore = 1, kRescale = 2, kDone = 3;
+#ifndef CLANE_K1_RESCALE_CHUNKS
+#define CLANE_K1_RESCALE_CHUNKS 4
+#endif
+    constexpr int kRescaleChunks = CLANE_K1_RESCALE_CHUNKS;
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
     __shared__ int s_next;
     const int lane = lane_id();
@@ -244,7 +250,7 @@ __global__ CLANE_K1_BOUNDS void edge_score_subrow_kernel(
     int64_t e0 = 0;            // first edge of the open row
     int deg = 0, eb = 0;       // its edge count; edges before the buffered chunk
     int n = 0, j = 0;          // buffered edges (c: one column per lane) and how many of them are scored
-    int rpos = 0;              // rescale: edges of the row already normalised
+    int rpos = 0, rend = 0;    // rescale: edges of the row already normalised, of those stored raw
     int c = 0;
     A mine = A(0);             // score of edge eb + sl
     A run_m = -A(INFINITY), run_s = A(0), nsrc = A(0);
@@ -262,20 +268,32 @@ __global__ CLANE_K1_BOUNDS void edge_score_subrow_kernel(
                     if (eb == 0) run_s = cs;                     // first chunk: 0 * exp(-inf) + cs without the exp
                     else run_s = run_s * exp_acc<A>(run_m - new_m) + cs;
                     run_m = new_m;
-                    if (deg <= LPR) mine = ex / cs;              // the whole row is this chunk: finished in registers
+                    // the row's LAST chunk leaves normalised straight from the registers (run_m, run_s are final:
+                    // exp(v - run_m) / run_s); only the chunks before it take the second pass
+                    if (eb + n >= deg) mine = ex / run_s;
                 }
                 if (in) scores[e0 + eb + sl] = mine;
                 eb += n;
                 if (eb >= deg) {
-                    phase = (fuse_softmax && deg > LPR) ? kRescale : kClaim;
+                    rend = deg - n;                              // edges stored raw, ahead of the last chunk
+                    phase = (fuse_softmax && rend > 0) ? kRescale : kClaim;
                     rpos = 0;
                 }
             }
-            if (phase == kRescale) {
-                const int e = rpos + sl;
-                if (e < deg) scores[e0 + e] = exp_acc<A>(scores[e0 + e] - run_m) / run_s;
-                rpos += LPR;
-                if (rpos >= deg) phase = kClaim;
+            if (phase == kRescale) {             // up to kRescaleChunks chunks per visit: independent loads, one round trip
+                A raw[kRescaleChunks];
+#pragma unroll
+                for (int r = 0; r < kRescaleChunks; ++r) {
+                    const int e = rpos + r * LPR + sl;
+                    raw[r] = e < rend ? scores[e0 + e] : A(0);
+                }
+#pragma unroll
+                for (int r = 0; r < kRescaleChunks; ++r) {
+                    const int e = rpos + r * LPR + sl;
+                    if (e < rend) scores[e0 + e] = exp_acc<A>(raw[r] - run_m) / run_s;
+                }
+                rpos += kRescaleChunks * LPR;
+                if (rpos >= rend) phase = kClaim;
             }
             if (phase == kClaim) {
                 for (;;) {

@@ -306,8 +306,16 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
 // instead of the maximum over a fixed group of rows (out-degrees are skewed: the maximum of 8 power-law rows
 // is several times their mean).  Gathers are branch-free (see accumulate_chunk): a sub-wave with fewer than U
 // edges left re-reads its last neighbour row (an L1 hit) with weight zero.
+#ifndef CLANE_SUBROW_MIN_WAVES
+#define CLANE_SUBROW_MIN_WAVES 0  // spmm_update_subrow_kernel: __launch_bounds__ 2nd argument (waves per SIMD), 0 = unconstrained
+#endif
+#if CLANE_SUBROW_MIN_WAVES > 0
+#define CLANE_SUBROW_BOUNDS __launch_bounds__(kBlock, (sizeof(typename Elem<T>::acc_t) == 8 ? 1 : CLANE_SUBROW_MIN_WAVES))
+#else
+#define CLANE_SUBROW_BOUNDS __launch_bounds__(kBlock)
+#endif
 template <typename T, typename PT, int VEC, int LPR, int U>
-__global__ __launch_bounds__(kBlock) void spmm_update_subrow_kernel(
+__global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
