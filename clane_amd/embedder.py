@@ -154,11 +154,9 @@ class Embedder(object):
             self._writer.flush()
 
     def _stage(self, engine, world: int):
-        """This sweep's embeddings on their way to the host (None: the engine cannot stage -- take them now)."""
-        if not hasattr(engine, "stage_Z"):
-            return None
+        """This sweep's embeddings on their way to the host."""
         pieces = (world > 1 and self._writer is not None and self._parts_dir is not None
-                  and getattr(engine, "device", torch.device("cpu")).type == "cuda")
+                  and engine.device.type == "cuda")
         if pieces and self._writer.assembler is None:
             self._writer.assembler = _PartsAssembler(self._parts_dir, engine.comm.rank, world,
                                                      (engine.V, engine.d_full), engine.dtype)
@@ -182,11 +180,11 @@ class Embedder(object):
         idle = _replay
         staged = None
         self._round_was_idle = False
-        can_lag = not self.save_history and hasattr(engine, "sweep_launch")
+        can_lag = not self.save_history
         ahead = bool(self.lagged_check) and can_lag
-        world = getattr(engine, "world", 1)
+        world = engine.world
         auto = self.lagged_check is None and can_lag and world == 1
-        if self.lagged_check is None and can_lag and world > 1 and hasattr(engine, "estimated_sweep_seconds"):
+        if self.lagged_check is None and can_lag and world > 1:
             # several ranks must decide alike, so not by a stopwatch: by the same estimate on every rank.  Lagging also
             # hides the latency of the per-sweep scalar all-reduce.
             ahead = engine.estimated_sweep_seconds() < self.LAGGED_BELOW_ESTIMATE_S
@@ -211,9 +209,7 @@ class Embedder(object):
             if self.save_history:
                 if not idle or staged is None:      # an idle sweep leaves the embeddings as they are: same copy
                     staged = self._stage(engine, world)
-                if staged is None:
-                    history_Z.append(engine.get_Z())
-                elif self._writer is not None:
+                if self._writer is not None:
                     self._writer.submit(outer, n_sweeps - 1, staged)
                 else:                           # reference behaviour: keep every Z; resolve copies as slots run out
                     in_flight.append((len(history_Z), staged))
