@@ -669,3 +669,25 @@ def test_thresholds_off_the_tuning_set(dev, family, dtype, d):
             eng.sweep(0.76)
         assert O.rel_l2(eng.get_Z().float(), Z_or) < tol_z, (family, kw)
     assert len(seen) >= 4                       # the variants really took different kernels
+
+
+def test_bench_main_record_survives_a_stuck_literal_block():
+    """The `north_star_literal` block runs after the main measurement and must never cost it: past its deadline every
+    rank prints / leaves on its own (a rank stuck in a collective cannot be talked to).  A deadline of a millisecond
+    stands in for a hung all-gather: ONE JSON line still comes out, with the main division's numbers, its parity and
+    `comm` block, and an `error` in place of the literal block; the launcher sees a clean exit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CLANE_BENCH_LITERAL_DEADLINE_S"] = "0.001"
+    run = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                          "--workload", "tiny", "--steps", "3", "--warmup", "1", "--blocks", "2"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
+    assert r["comm"]["ranks_seen"] == 2 and "no result within" in r["north_star_literal"]["error"]
