@@ -59,6 +59,29 @@ HUB_FACTOR = 1
 SPLIT_EDGES = 4096
 MIN_SEGMENT_EDGES = 1024
 TARGET_SEGMENTS = 512                   # two workgroups per CU
+# The XCD-affine pass buys L2 hits; it has something to buy only when the gathers are SKEWED -- when the rows the
+# eight 4-MiB L2s can hold between them take a real share of all edge reads (config 3: 61 %, config 4's shape: ~65 %).
+# On a graph whose destinations are spread evenly (a near-regular or uniform random graph: that share is the rows'
+# share of the table, 1.6 % at 2M x 1 KiB) cutting a 70-edge row into 8 class pieces is pure overhead: measured 25.7 ms
+# against 20.7 on a near-regular 2M / 128M graph (profiles/r03_threshold_robustness.md).  Below MIN_HOT_READ_SHARE only
+# rows that need their work spread anyway (above HEAVY_ROW_EDGES: the class pass doubles as the hub splitter, a
+# 2M-edge row scored by ONE workgroup took build_P from 6.6 to 29 ms) take the pass.
+L2_BYTES_ALL_XCDS = 8 * 4 * 1024 * 1024
+MIN_HOT_READ_SHARE = 0.2
+HEAVY_ROW_EDGES = 4096
+
+
+def hot_read_share(csr: HostCSR, row_bytes: int) -> float:
+    """Share of all edge reads that go to the rows the eight L2s can hold between them (the most-read rows first) --
+    what XCD affinity can turn into L2 hits at best.  The same number on every rank (global in-degrees)."""
+    V, E = csr.num_vertices, csr.num_edges
+    k = L2_BYTES_ALL_XCDS // max(int(row_bytes), 1)
+    if E == 0 or k >= V:
+        return 1.0
+    indeg = csr.indeg()
+    return float(np.partition(indeg, V - k)[V - k:].sum(dtype=np.int64)) / E
+
+
 def lanes_per_row(d: int, dtype: torch.dtype) -> int:
     """Lanes that cover one row with 16-byte packs (mirrors pick_layout in csrc/clane_abi.hip)."""
     packs = -(-d // _hip.VEC_ELEMS[dtype])
@@ -196,8 +219,14 @@ class SweepEngine:
         self.hot_rows_first = bool(hot_rows_first)
         self.halo = row_world > 1 and exchange in ("halo", "halo_p2p")
         rows_per_wave = 64 // lanes_per_row(self.d, X.dtype) if self.d > 0 else 1
+        # how much of the gather traffic XCD affinity could serve from the L2s at all (same number on every rank)
+        self.hot_read_share = hot_read_share(csr, self.ld * X.element_size()) if self.d > 0 else 1.0
+        self.class_affinity = True
         if class_threshold is None:         # XCD-affine long rows, whatever the division
             class_threshold = CLASS_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
+            if self.hot_read_share < MIN_HOT_READ_SHARE:    # evenly spread reads: only rows that need splitting anyway
+                class_threshold = max(class_threshold, HEAVY_ROW_EDGES)
+                self.class_affinity = False
         self.class_threshold = int(class_threshold)
         self.class_chunk = int(class_chunk)
         self.class_k1 = bool(class_k1) and self.class_threshold > 0    # build_P scores the class rows XCD-affine too
@@ -233,7 +262,7 @@ class SweepEngine:
                              "rows over more GPUs (exchange='halo') or wait for 64-bit indices")
         if long_threshold is None:
             long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
-            if rows_per_wave == 1 and self.class_threshold:
+            if rows_per_wave == 1 and self.class_threshold and self.class_affinity:
                 # with the class pass taking the rows above class_threshold, the 33..64-edge rows are better off with
                 # one wave each than with a 16-wave workgroup of which 15 waves leave at once (4.34 -> 4.30 ms)
                 long_threshold = max(long_threshold, self.class_threshold)
@@ -886,6 +915,7 @@ class SweepEngine:
                 "class_threshold": self.class_threshold, "class_chunk": self.class_chunk, "class_k1": self.class_k1,
                 "class_phases": self.class_phases, "phase_threshold": self.phase_threshold,
                 "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
+                "class_affinity": self.class_affinity,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 
     def exchange_bytes_per_sweep(self) -> int:

@@ -491,6 +491,37 @@ def test_history_parts_of_several_ranks_are_put_together(tmp_path):
         StagedZ(ready=sweeps[0]).piece()
 
 
+def test_class_pass_follows_the_read_skew():
+    """XCD affinity can only turn SKEWED gathers into L2 hits: `hot_read_share` = the share of all edge reads going to
+    the rows the eight 4-MiB L2s hold between them.  A skewed graph keeps the tuned class threshold; one whose
+    destinations are spread evenly only sends rows above HEAVY_ROW_EDGES through the pass (as the hub splitter), and
+    its 33..64-edge rows do not inherit the class threshold as their one-wave limit; an explicit threshold is obeyed."""
+    from clane_amd import engine as E
+    V, d = 30_000, 2048                         # 8-KiB rows: the L2s hold 4 096 of them
+    rng = np.random.default_rng(3)
+    deg = rng.integers(40, 81, size=V)
+    rowptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    even = HostCSR(V, rowptr, rng.integers(0, V, size=int(rowptr[-1])).astype(np.int32))
+    share = E.hot_read_share(even, d * 4)
+    assert 4096 / V <= share < E.MIN_HOT_READ_SHARE
+    hot = rng.integers(0, 500, size=int(rowptr[-1]))            # every edge reads one of 500 rows
+    skewed = HostCSR(V, rowptr, hot.astype(np.int32))
+    assert E.hot_read_share(skewed, d * 4) == 1.0
+    assert E.hot_read_share(even, 64) == 1.0                    # the whole table fits
+    X = torch.zeros(V, d)
+    kern = OracleKernels()
+    e_even = SweepEngine(even, X, "cpu", kernels=kern)
+    assert not e_even.class_affinity and e_even.class_threshold == E.HEAVY_ROW_EDGES and e_even.class_rows[0] is None
+    assert e_even.long_threshold == E.LONG_THRESHOLD_BY_ROWS_PER_WAVE[1]        # 32: the row-split kernel takes 40..80
+    e_skew = SweepEngine(skewed, X, "cpu", kernels=kern)
+    assert e_skew.class_affinity and e_skew.class_threshold == 64 and e_skew.class_rows[0] is not None
+    assert e_skew.long_threshold == 64
+    e_forced = SweepEngine(even, X, "cpu", kernels=kern, class_threshold=64)
+    assert e_forced.class_threshold == 64 and e_forced.class_rows[0] is not None
+    assert e_even.kernel_config()["class_affinity"] is False and e_skew.kernel_config()["class_affinity"] is True
+
+
 def test_kernel_backend_contract_is_enforced():
     """Every call the engine makes on its kernel object is an abstract method of ``KernelBackend``: an implementation
     that lacks one cannot be instantiated (so nothing -- the CSR check, say -- is skipped silently), the engine does
