@@ -1,21 +1,26 @@
 #!/bin/bash
 # Re-take the whole per-round profile set on the GPU box (everything profiles/README.md lists that depends on the K3
 # kernels).  Needed whenever SweepEngine.kernel_config() changes: bench.py refuses PMC entries taken with another one.
-#   tools/refresh_profiles.sh <tag> [part]      part: pmc | bench | all (default all); ~20 GPU-minutes in all
+#   tools/refresh_profiles.sh <tag> [part]      part: pmc | pmc1 | pmc2 | bench | all (default all); ~25 GPU-minutes in all
+#   (one gpurun call is at most 20 minutes: pmc1 = config 3 and its column slices + config 2, pmc2 = config 4's shape + the
+#   16M-vertex capacity run; copy gpurun_out/profiles/traffic.json into profiles/ before the bench part)
 # Results land in gpurun_out/profiles/: copy them to profiles/ and commit.
 set -e
-R="$(cd "$(dirname "$0")/.." && pwd)"; TAG=${1:-r02}; PART=${2:-all}
+R="$(cd "$(dirname "$0")/.." && pwd)"; TAG=${1:-r03}; PART=${2:-all}
 P="$R/gpurun_out/profiles"; mkdir -p "$P"
 cd "$R"
-if [ "$PART" = pmc ] || [ "$PART" = all ]; then
+if [ "$PART" = pmc ] || [ "$PART" = pmc1 ] || [ "$PART" = all ]; then
   tools/profile_bench.sh rmat2m $TAG
   for N in 8 4 2; do
     CLANE_PROFILE_KEY=rmat2m_column_slice_of_$N tools/profile_bench.sh rmat2m $TAG --column-slice-of $N --steps 60
   done
   tools/profile_bench.sh rmat200k $TAG --steps 100
+  cp "$P/traffic.json" "$R/profiles/traffic.json"      # the bench lines below quote it
+fi
+if [ "$PART" = pmc ] || [ "$PART" = pmc2 ] || [ "$PART" = all ]; then
   tools/profile_bench.sh powerlaw10m $TAG
   tools/profile_bench.sh rmat16m $TAG --steps 8 --warmup 2
-  cp "$P/traffic.json" "$R/profiles/traffic.json"      # the bench lines below quote it
+  cp "$P/traffic.json" "$R/profiles/traffic.json"
 fi
 if [ "$PART" = bench ] || [ "$PART" = all ]; then
   tools/profile_slices.sh $TAG
