@@ -241,6 +241,12 @@ def make_parser():
                          "none = off)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow)")
+    ap.add_argument("--rehearse-rccl", action="store_true",
+                    help="one GPU, ONE rank, but a real RCCL process group: everything an N > 1 run does -- group "
+                         "start-up, the agreement check, the column split's collectives, the comm block, the "
+                         "north_star_literal block with its in-place all-gathers -- goes through the real library (each "
+                         "collective is the identity on one rank).  Shows no scaling; catches API, dtype and stream "
+                         "mistakes that the gloo rehearsals cannot.  Not a headline number.")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (RCCL refuses that: use --backend gloo)")
     ap.add_argument("--host-sync", default="auto", choices=["auto", "every-sweep", "pipelined"],
@@ -268,24 +274,28 @@ def make_parser():
 class Ranks:
     """The process group as bench.py uses it (a no-op on one GPU)."""
 
-    def __init__(self, world, rank, dev, pg):
+    def __init__(self, world, rank, dev, pg, rehearsal=False):
         self.world, self.rank, self.dev, self.pg = world, rank, dev, pg
+        # `grouped`: there is a process group and every collective is really issued -- N > 1, or the one-rank RCCL
+        # rehearsal (--rehearse-rccl), where each is the identity but goes through the real library
+        self.rehearsal = bool(rehearsal)
+        self.grouped = world > 1 or self.rehearsal
 
     def barrier(self):
-        if self.world > 1:
+        if self.grouped:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(self, values):
         t = torch.tensor(list(values), dtype=torch.float64, device=self.dev)
-        if self.world > 1:
+        if self.grouped:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.tolist()
 
     def gather_objects(self, obj):
-        if self.world == 1:
+        if not self.grouped:
             return [obj]
         import torch.distributed as dist
         out = [None] * self.world
@@ -328,7 +338,7 @@ def generate_input(args, ranks: Ranks):
         from clane_amd.engine import column_slice
         c0, c1 = column_slice(d, X.dtype, args.column_slice_of, 0)
         X = X[:, c0:c1].contiguous()
-    if world > 1:       # every rank generated the graph on its own GPU from the same seed: make sure they agree
+    if ranks.grouped:   # every rank generated the graph on its own GPU from the same seed: make sure they agree
         mine = (csr.num_edges, int(csr.colidx.astype(np.int64).sum()), int(csr.rowptr[::997].sum()),
                 float(X[::9973].double().sum()))
         everyone = ranks.gather_objects(mine)
@@ -355,8 +365,13 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
     from clane_amd.engine import SweepEngine
     world, rank, dev = ranks.world, ranks.rank, ranks.dev
     t0 = time.perf_counter()
-    eng = SweepEngine(csr, X, dev, process_group=ranks.pg, chunks=args.chunks, long_threshold=args.long_threshold,
-                      hub_threshold=args.hub_threshold, exchange=exchange,
+    comm = None
+    if ranks.rehearsal:     # one rank, real RCCL: the engine keeps the division it is given and issues every collective
+        from clane_amd.comm import TorchComm
+        comm = TorchComm(ranks.pg, force_collectives=True)
+        exchange = "columns" if exchange == "auto" else exchange
+    eng = SweepEngine(csr, X, dev, process_group=ranks.pg, comm=comm, chunks=args.chunks,
+                      long_threshold=args.long_threshold, hub_threshold=args.hub_threshold, exchange=exchange,
                       hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs,
                       class_threshold=args.class_threshold, class_chunk=args.class_chunk)
     torch.cuda.synchronize()
@@ -389,12 +404,12 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
 
     host_sync = "pipelined" if args.pipelined else args.host_sync
     pipelined = host_sync == "pipelined" or (
-        host_sync == "auto" and eng.estimated_sweep_seconds() < (Embedder.LAGGED_BELOW_ESTIMATE_S if world > 1
+        host_sync == "auto" and eng.estimated_sweep_seconds() < (Embedder.LAGGED_BELOW_ESTIMATE_S if ranks.grouped
                                                                   else Embedder.LAGGED_BELOW_S))
     out["pipelined"], out["host_sync"] = pipelined, host_sync
     eng.time_kernels = time_kernels
     eng.kernel_events = []
-    eng.time_collectives = world > 1
+    eng.time_collectives = ranks.grouped
     eng.collective_events = []
     wall, local_wall, hip_ms = [], [], []
     delta = float("nan")
@@ -471,7 +486,7 @@ def describe_parallelism(args, world, eng, X, E) -> str:
     if args.column_slice_of:
         return (f"REHEARSAL on 1 GPU of one rank of the column split x{args.column_slice_of}: columns "
                 f"[0:{X.shape[1]}) of X and Z, whole graph; not a headline number")
-    if world == 1:
+    if world == 1 and eng.exchange == "none":
         return f"1 GPU, {chunks} launch block(s)/sweep"
     if eng.columns:
         return (f"column split x{world}: every GPU holds the whole graph and columns [{eng.col0}:{eng.col1}) "
@@ -564,6 +579,16 @@ def main():
     dev = _hip.require_gpu("cuda:0" if (args.share_gpu or masked) else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     pg = None
+    if args.rehearse_rccl:
+        if world != 1:
+            raise SystemExit("--rehearse-rccl is the ONE-rank rehearsal of the N > 1 flow")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(minutes=30))
+        pg = dist.group.WORLD
     if world > 1:
         # rank 0 spends seconds in the CPU oracle while the others wait inside a collective: well within this
         patience = datetime.timedelta(minutes=30)
@@ -578,7 +603,7 @@ def main():
         else:
             dist.init_process_group("gloo", timeout=patience)
         pg = dist.group.WORLD
-    ranks = Ranks(world, rank, dev, pg)
+    ranks = Ranks(world, rank, dev, pg, rehearsal=args.rehearse_rccl)
 
     gen, V, _, d, dname, gseed, xseed = WORKLOADS[args.workload]
     t0 = time.perf_counter()
@@ -610,8 +635,11 @@ def main():
     }
     if m["calibration_bytes"] is not None:
         result["calibration"] = {"kernel": "l1_distance_kernel", "bytes_read": m["calibration_bytes"]}
-    if world > 1:
+    if ranks.grouped:
         result["comm"] = comm_block(args, ranks, m)
+    if ranks.rehearsal:
+        result["rehearsal"] = ("ONE rank in a real RCCL group with every collective issued (--rehearse-rccl): the N > 1 "
+                               "flow through the real library; not a headline number")
 
     # ---- parity: the first GPU sweep (and P itself) against the C oracle, which builds its OWN P -------------
     Z1_oracle = None
@@ -633,14 +661,14 @@ def main():
                 parity_p = O.rel_l2(P_gpu.float(), P_oracle)
                 result["parity_P_rel_l2_vs_oracle"] = parity_p
                 failed = failed or not parity_p < PARITY_P_TOL[dname]
-            if world == 1 and not args.no_cpu_baseline and not failed:
+            if world == 1 and not ranks.rehearsal and not args.no_cpu_baseline and not failed:
                 result["cpu_baseline"] = cpu_baseline(csr, Xf, P_oracle, args.gamma, Z1_oracle, first)
                 result["cpu_baseline_torch"] = cpu_baseline_torch(csr, Xf, P_oracle, args.gamma)
         failed = ranks.agree_to_fail(failed)
         if failed:                  # every rank leaves, non-zero, together
             if rank == 0:
                 print(json.dumps(result), flush=True)
-            if world > 1:
+            if ranks.grouped:
                 dist.destroy_process_group()
             raise SystemExit(f"parity check failed: {result.get('parity_rel_l2_vs_oracle_after_1_sweep')} "
                              f"(P: {result.get('parity_P_rel_l2_vs_oracle')})")
@@ -679,7 +707,7 @@ def main():
                 if rank == 0:
                     print(json.dumps(result), flush=True)
 
-    if world > 1 and args.also_exchange not in ("none", eng.exchange) and not args.column_slice_of:
+    if ranks.grouped and args.also_exchange not in ("none", eng.exchange) and not args.column_slice_of:
         # Whatever happens in here, the main record above must come out: past the deadline every rank prints /
         # leaves on its own (a rank stuck in a collective cannot be talked to).
         def give_up():
@@ -724,7 +752,7 @@ def main():
         timer.cancel()
         result["north_star_literal"] = block
     emit()
-    if world > 1:
+    if ranks.grouped:
         dist.barrier()              # leave together
         dist.destroy_process_group()
     if failed:

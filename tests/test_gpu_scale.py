@@ -694,3 +694,39 @@ def test_bench_main_record_survives_a_stuck_literal_block():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
     assert r["comm"]["ranks_seen"] == 2 and "no result within" in r["north_star_literal"]["error"]
+
+
+def test_bench_n_gpu_flow_through_real_rccl_with_one_rank():
+    """`bench.py --rehearse-rccl`: the whole N > 1 flow of bench.py -- `init_process_group("nccl")`, the input agreement
+    check (`all_gather_object`), the column split's collectives (all-reduce of the partial dot products, of the norms,
+    of the delta), barriers and MAX-reductions of the timing protocol, the `comm` block, and the `north_star_literal`
+    block with its in-place `all_gather_into_tensor` per chunk issued async from side streams -- through the REAL
+    RCCL library with the one rank this box can give it.  Each collective is the identity, so the numbers must be the
+    plain one-GPU run's; what this catches are API / dtype / stream mistakes that gloo accepts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    common = ["--workload", "tiny", "--steps", "3", "--warmup", "1", "--blocks", "2", "--no-cpu-baseline"]
+    plain = subprocess.run([sys.executable, str(ROOT / "bench.py")] + common, capture_output=True, text=True, timeout=600,
+                           cwd=ROOT, env=env)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    run = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--rehearse-rccl"] + common, capture_output=True,
+                         text=True, timeout=600, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    r0 = json.loads([ln for ln in plain.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert "rehearsal" in r and r["n_gpus"] == 1 and "cpu_baseline" not in r
+    comm = r["comm"]
+    assert comm["backend"] == "nccl" and comm["ranks_seen"] == 1 and comm["exchange"] == "columns"
+    assert comm["collectives_issued"]["all_reduce"] > 10 and comm["collective_detail"]["sweeps_timed"] > 0
+    assert r["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and r["parity_P_rel_l2_vs_oracle"] < 2e-6
+    assert r["last_delta"] == pytest.approx(r0["last_delta"], rel=5e-5)
+    lit = r["north_star_literal"]
+    assert "error" not in lit and lit["exchange"] == "allgather_all" and lit["comm"]["backend"] == "nccl"
+    assert lit["comm"]["collectives_issued"]["all_gather"] >= 4 * (3 * 2 + 1)        # 4 chunks per sweep, in place
+    assert lit["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
+    assert lit["last_delta"] == pytest.approx(r0["last_delta"], rel=5e-5)
