@@ -63,31 +63,13 @@ struct RangeStats {
     A max, sum;
 };
 
-// What a row's scoring needs before its first gather can be addressed: the first (<= 64) columns, one per lane, and --
-// when the row fits one pack per lane -- the source row's pack.  edge_score_kernel requests the NEXT row's head before it
-// gathers the current row, as K3's row kernel does with its next chunk.
-template <typename T, int VEC>
-struct RowHead {
-    int c;
-    Pack<T, VEC> s0;
-};
-template <typename T, int VEC, int LPR>
-__device__ __forceinline__ RowHead<T, VEC> load_row_head(const int32_t *__restrict__ colidx, int64_t ea, int64_t eb,
-                                                          const T *__restrict__ zsrc, int d) {
-    RowHead<T, VEC> h{0, Pack<T, VEC>{}};
-    const int lane = lane_id(), sl = lane % LPR;
-    if (ea + lane < eb) h.c = colidx[ea + lane];
-    if (d <= LPR * VEC && sl * VEC < d) h.s0 = load_pack<T, VEC>(zsrc + sl * VEC);
-    return h;
-}
-
 template <typename T, int VEC, int LPR, int U>
 __device__ __forceinline__ RangeStats<typename Elem<T>::acc_t> score_edge_range(const int32_t *__restrict__ colidx, int64_t ea, int64_t eb,
                                                  int64_t src_row, const T *__restrict__ Z, int64_t ldz, int d,
                                                  int mode, typename Elem<T>::acc_t D,
                                                  const typename Elem<T>::acc_t *__restrict__ sq,
                                                  typename Elem<T>::acc_t *__restrict__ scores, bool softmax,
-                                                 bool want_stats = false, const RowHead<T, VEC> *head = nullptr) {
+                                                 bool want_stats = false) {
     using A = typename Elem<T>::acc_t;
     constexpr int EPW = kWave / LPR;
     constexpr bool kTransposed = (U == 8 && LPR >= 8);
@@ -98,8 +80,7 @@ __device__ __forceinline__ RangeStats<typename Elem<T>::acc_t> score_edge_range(
     const T *zsrc = Z + src_row * ldz;
     const A nsrc = mode == kScorePerEdge ? sqrt(sq[src_row]) : A(0);
     Pack<T, VEC> s0{};
-    if (head != nullptr) s0 = head->s0;                    // requested while the previous row was gathering
-    else if (single && sl * VEC < d) s0 = load_pack<T, VEC>(zsrc + sl * VEC);
+    if (single && sl * VEC < d) s0 = load_pack<T, VEC>(zsrc + sl * VEC);
     A run_m = -A(INFINITY), run_s = A(0);
 
     for (int64_t e = ea; e < eb; e += kWave) {
@@ -107,7 +88,7 @@ __device__ __forceinline__ RangeStats<typename Elem<T>::acc_t> score_edge_range(
         const int n = left < kWave ? int(left) : kWave;
         // Lanes past the end of the row hold the chunk's FIRST column: every address formed below is
         // valid, so the gathers need no branch (see pin_loaded in device_utils.h for why that matters).
-        int c = (head != nullptr && e == ea) ? head->c : (lane < n ? colidx[e + lane] : 0);
+        int c = lane < n ? colidx[e + lane] : 0;
         c = lane < n ? c : lane_get_uniform(c, 0);
         A mine = A(0);  // score of edge e + lane
         for (int j = 0; j < n; j += EPW * U) {
@@ -192,10 +173,9 @@ __device__ __forceinline__ A global_denominator(int mode, const double *__restri
     return mode == kScoreReference ? sqrt(A(sums2[0])) * sqrt(A(sums2[1])) : A(1);
 }
 
-// One wave per source row, rows of at most `long_threshold` edges.  Same workgroup structure as K3's row kernel
-// (round 3): the block's rowptr slice staged in LDS, waves CLAIM rows from an LDS counter (a wave on a 60-edge row
-// does not hold back the others), and the next claimed row's head -- its first columns, its source pack -- is requested
-// before the current row's gathers, so a row costs one dependent round trip, not two.
+// (Round 3 tried K3's row-kernel structure here as well -- rowptr slice in LDS, rows claimed from an LDS counter, the next
+// row's first columns and source pack requested before the current row's gathers: 1.378 -> 1.401 ms at config 3, the 14
+// extra registers cost what the prefetch saved.  The static interleave stays.)
 template <typename T, int VEC, int LPR, int U>
 __global__ __launch_bounds__(kBlock) void edge_score_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t nrows, int64_t row0,
@@ -203,49 +183,35 @@ __global__ __launch_bounds__(kBlock) void edge_score_kernel(
     const typename Elem<T>::acc_t *__restrict__ sq, typename Elem<T>::acc_t *__restrict__ scores,
     int64_t long_threshold, bool fuse_softmax, int rows_per_block) {
     using A = typename Elem<T>::acc_t;
-    __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
-    __shared__ int s_next;
-    const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
-    const int nb = int((row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows) - row_begin);
-    for (int i = threadIdx.x; i <= nb; i += kBlock) s_rowptr[i] = rowptr[row_begin + i];
-    if (threadIdx.x == 0) s_next = kWavesPerBlock;
-    __syncthreads();
+    const int64_t row_end = row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows;
     const A D = global_denominator<A>(mode, sums2);
-
-    // next row of this block with work for the one-wave kernel, for the calling wave (wave-uniform); nb when none is left
-    auto claim = [&]() -> int {
-        for (;;) {
-            int v = 0;
-            if (lane == 0) v = atomicAdd(&s_next, 1);
-            const int row = __builtin_amdgcn_readfirstlane(v);
-            if (row >= nb) return nb;
-            const int64_t dg = s_rowptr[row + 1] - s_rowptr[row];
-            if (dg > 0 && !(long_threshold > 0 && dg > long_threshold)) return row;
-        }
-    };
-    int cur = wave;
-    if (cur < nb) {
-        const int64_t dg = s_rowptr[cur + 1] - s_rowptr[cur];
-        if (dg == 0 || (long_threshold > 0 && dg > long_threshold)) cur = claim();
-    }
-    RowHead<T, VEC> head{0, Pack<T, VEC>{}};
-    if (cur < nb)
-        head = load_row_head<T, VEC, LPR>(colidx, s_rowptr[cur], s_rowptr[cur + 1], Z + (row0 + row_begin + cur) * ldz, d);
-    while (cur < nb) {
-        const int nxt = claim();
-        RowHead<T, VEC> head_next{0, Pack<T, VEC>{}};
-        if (nxt < nb)
-            head_next = load_row_head<T, VEC, LPR>(colidx, s_rowptr[nxt], s_rowptr[nxt + 1],
-                                                   Z + (row0 + row_begin + nxt) * ldz, d);
-        score_edge_range<T, VEC, LPR, U>(colidx, s_rowptr[cur], s_rowptr[cur + 1], row0 + row_begin + cur, Z, ldz, d, mode, D,
-                                         sq, scores, fuse_softmax, false, &head);
-        cur = nxt;
-        head = head_next;
+    for (int64_t r = row_begin + wave; r < row_end; r += kWavesPerBlock) {
+        const int64_t e0 = rowptr[r];
+        const int64_t e1 = rowptr[r + 1];
+        if (e0 == e1 || (long_threshold > 0 && e1 - e0 > long_threshold)) continue;
+        score_edge_range<T, VEC, LPR, U>(colidx, e0, e1, row0 + r, Z, ldz, d, mode, D, sq, scores, fuse_softmax);
     }
 }
 
+// Narrow rows (LPR < 64): one SUB-WAVE per source row, 64/LPR rows per wave in flight -- the K1 counterpart
+// of spmm_update_subrow_kernel, with the same row claiming: every sub-wave takes its rows from the workgroup's
+// LDS counter on its own and the wave advances all of them by one group of 8 edges per iteration, so a wave's
+// time is the SUM of its rows' groups / (64/LPR) instead of the maximum over a fixed group of rows (r03: the
+// statically grouped version ran at 4.0 TB/s on the 10M-vertex power-law graph where K3 reaches 6.1 over the
+// same rows).  A sub-wave is in one of four states, uniform over its LPR lanes:
+//   claim   -- take the next row of <= long_threshold edges, load its source pack;
+//   score   -- LPR buffered edges (one column per lane), consumed 8 at a time: 8 branch-free neighbour-row
+//              loads, 8 partial dots, the transposed butterfly over the LPR lanes, the finished scores handed
+//              to lane = edge; after a chunk the running max / sum of the row and one coalesced store;
+//   rescale -- a row of more than LPR edges is soft-maxed by a second pass over the sub-wave's own stores (each
+//              lane re-reads what it wrote), except for its last chunk, which leaves normalised from the registers;
+//              four chunks per visit (independent loads: one round trip), so a row of up to 5 chunks is done in
+//              the visit that finished its last chunk, a longer one while the other sub-waves keep gathering;
+//   done    -- no rows left in the block: the lanes carry on with zero-weight reads of table row 0 (an L1 hit).
+// Every edge goes through the same fma chain and the same exchange tree as in score_edge_range: the scores are
+// bit-identical to the one-wave and the long-row kernels'.
 #ifndef CLANE_K1_MIN_WAVES
 #define CLANE_K1_MIN_WAVES 7      // edge_score_subrow_kernel: __launch_bounds__ 2nd argument (waves per SIMD), 0 = unconstrained;
                                   // 7 = 72 VGPRs, no spills (config 4's shape: 4.61 -> 4.41 ms; 8 spills: 6.41, profiles/r03_k1_subrow.md)
