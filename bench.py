@@ -749,11 +749,16 @@ def main():
                 failed = True
         except Exception as exc:            # noqa: BLE001 -- reported in the record; the main measurement stands
             block["error"] = f"{type(exc).__name__}: {exc}"
-        timer.cancel()
         result["north_star_literal"] = block
+    else:
+        timer = None
     emit()
     if ranks.grouped:
-        dist.barrier()              # leave together
+        # leave together.  The deadline stays armed until everybody is here: a rank that fell out of the block above
+        # on its own (an exception the others did not have) would otherwise wait for ranks stuck in a collective.
+        dist.barrier()
+        if timer is not None:
+            timer.cancel()
         dist.destroy_process_group()
     if failed:
         raise SystemExit("north_star_literal: parity check failed")
