@@ -66,7 +66,6 @@ TARGET_SEGMENTS = 512                   # two workgroups per CU
 # against 20.7 on a near-regular 2M / 128M graph (profiles/r03_threshold_robustness.md).  Below MIN_HOT_READ_SHARE only
 # rows that need their work spread anyway (above HEAVY_ROW_EDGES: the class pass doubles as the hub splitter, a
 # 2M-edge row scored by ONE workgroup took build_P from 6.6 to 29 ms) take the pass.
-OVERLAP_PASSES_BELOW_S = 1.5e-3         # estimated sweep (gather-model bytes at the HBM peak) below which the passes overlap
 L2_BYTES_ALL_XCDS = 8 * 4 * 1024 * 1024
 MIN_HOT_READ_SHARE = 0.2
 HEAVY_ROW_EDGES = 4096
@@ -166,8 +165,7 @@ class SweepEngine:
                  exchange: str = "auto", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
-                 phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False,
-                 overlap_passes: Optional[bool] = None):
+                 phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
@@ -447,19 +445,6 @@ class SweepEngine:
         self.side_streams = None
         if overlap_chunks and len(self.blocks) > 1 and self.device.type == "cuda":
             self.side_streams = [torch.cuda.Stream(self.device) for _ in range(2)]
-        # One launch block (one GPU, or a column-split rank): the class pass and the one-(sub-)wave pass own different
-        # rows, write different partials and only the class pass uses the slab -- they can run side by side.  Two
-        # bandwidth-bound kernels gain nothing from that (config 3: 2.3 + 1.6 ms either way, and per-kernel times stop
-        # meaning anything), but SHORT passes are latency-bound -- a 4M-edge graph, a rank's 128-byte column slice at 8
-        # GPUs: 0.25 + 0.32 ms of kernels that each leave most of the card idle at their ramp and tail -- so the class
-        # pass goes to a stream of its own when a sweep is estimated below OVERLAP_PASSES_BELOW_S (the same estimate on
-        # every rank).  The workgroup -> XCD dealing the class pass leans on holds with two launches in flight
-        # (tools/xcc_concurrent.py, profiles/r02_gather_rows_ceiling.md).
-        if overlap_passes is None:
-            overlap_passes = self.estimated_sweep_seconds() < OVERLAP_PASSES_BELOW_S
-        self.overlap_passes = (bool(overlap_passes) and len(self.blocks) == 1 and self.device.type == "cuda"
-                               and self.d > 0 and self.class_rows[0] is not None)
-        self._pass_stream = torch.cuda.Stream(self.device) if self.overlap_passes else None
         self.time_kernels = False
         # bench.py, N > 1: HIP events on the sweep's stream around what it spends waiting for the other ranks -- the
         # row exchange still outstanding after its own kernels (what the overlap did not hide) and the scalar all-reduce
@@ -725,13 +710,10 @@ class SweepEngine:
                     continue
                 if self.class_rows[i] is not None:
                     rows_c, slot_ptr, it_e0, it_len, it_slot, _, ipb = self.class_rows[i]
-                    own = torch.cuda.stream(self._pass_stream) if self.overlap_passes else contextlib.nullcontext()
-                    with own:        # a bound call captures the current stream
-                        call = self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
-                                          ipb, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
-                                          Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:],
-                                          mirror=mir)
-                    steps.append(("side" if self.overlap_passes else "call", call))
+                    steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
+                                                     ipb, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
+                                                     Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:],
+                                                     mirror=mir)))
                 if self.split_rows[i] is not None:
                     rows_s, seg_ptr, seg_row = self.split_rows[i]
                     steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
@@ -788,7 +770,7 @@ class SweepEngine:
             plan = self._plans[key] = self._build_plan(parity, float(gamma))
         events = None
         if self.time_kernels and len(self.kernel_events) < self.MAX_TIMED_SWEEPS * len(self.blocks):
-            events = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in self.blocks]
+            events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in self.blocks]
             self.kernel_events.extend((i,) + tuple(ev) for i, ev in enumerate(events))
         per_block, final = plan
         works = []
@@ -799,7 +781,6 @@ class SweepEngine:
             start.record(main)
             for st in side:
                 st.wait_event(start)
-        pass_done = None
         for i, steps in enumerate(per_block):
             ctx = torch.cuda.stream(side[i % 2]) if side else contextlib.nullcontext()
             with ctx:
@@ -807,16 +788,6 @@ class SweepEngine:
                     kind = step[0]
                     if kind == "call":
                         step[1]()
-                    elif kind == "side":            # the class pass on its own stream, beside the row pass (overlap_passes)
-                        here, ps = torch.cuda.current_stream(self.device), self._pass_stream
-                        began = torch.cuda.Event()
-                        began.record(here)          # everything queued so far (the previous sweep) comes first
-                        ps.wait_event(began)
-                        if events is not None:
-                            events[i][5].record(ps)
-                        step[1]()
-                        pass_done = events[i][6] if events is not None else torch.cuda.Event()
-                        pass_done.record(ps)
                     elif kind == "event":
                         if events is not None:
                             events[step[1]][step[2]].record()
@@ -829,8 +800,6 @@ class SweepEngine:
                 done = torch.cuda.Event()
                 done.record(st)
                 main.wait_event(done)
-        if pass_done is not None:
-            torch.cuda.current_stream(self.device).wait_event(pass_done)
         final()
         mine = self.delta_pp[parity:parity + 1]
         cev = None
@@ -883,10 +852,8 @@ class SweepEngine:
         """{'split','hub','mid','main'} -> ms per SWEEP (summed over the blocks, averaged over the recorded
         sweeps); call after a synchronize.  Event order per block: 0 start, 4 after split, 1 after hub, 2 after mid,
         3 after main."""
-        # events 5 / 6 bracket the class pass on its own stream when the passes overlap (else 0 -> 4 on the sweep's stream)
-        t = np.array([((e5.elapsed_time(e6) if self.overlap_passes else e0.elapsed_time(e4)), e4.elapsed_time(e1),
-                       e1.elapsed_time(e2), e2.elapsed_time(e3))
-                      for _, e0, e1, e2, e3, e4, e5, e6 in self.kernel_events]).reshape(-1, 4)
+        t = np.array([(e0.elapsed_time(e4), e4.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3))
+                      for _, e0, e1, e2, e3, e4 in self.kernel_events]).reshape(-1, 4)
         self.kernel_events = []
         if not len(t):
             return {}
@@ -948,7 +915,7 @@ class SweepEngine:
                 "class_threshold": self.class_threshold, "class_chunk": self.class_chunk, "class_k1": self.class_k1,
                 "class_phases": self.class_phases, "phase_threshold": self.phase_threshold,
                 "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
-                "class_affinity": self.class_affinity, "overlap_passes": self.overlap_passes,
+                "class_affinity": self.class_affinity,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 
     def exchange_bytes_per_sweep(self) -> int:
