@@ -730,3 +730,43 @@ def test_bench_n_gpu_flow_through_real_rccl_with_one_rank():
     assert lit["comm"]["collectives_issued"]["all_gather"] >= 3 * 2 + 2             # one in-place all-gather per sweep
     assert lit["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
     assert lit["last_delta"] == pytest.approx(r0["last_delta"], rel=5e-5)
+
+
+# ---- float64 content embeddings (a `C.npy` of dtype float64, reference golden G6) at config 2's size ----------------
+def test_config2_shape_in_float64(dev):
+    """The reference computes in whatever dtype `C.npy` holds (graph.py:52-58: a float64 file gives float64 embeddings,
+    golden G6).  Config 2's graph (R-MAT 200k / 4M) with d = 128 float64 -- 1-KiB rows: the one-wave-per-row kernels,
+    the XCD-affine class pass and its combine, K1's class softmax, all in double -- `build_P` and three sweeps through
+    the engine against the PyTorch-CPU oracle in float64, to 1e-13; per-edge mode on the hub rows against the float64
+    restatement; bitwise repeatability."""
+    V, E, d, gamma = 200_000, 4_000_000, 128, 0.76
+    csr = synth.rmat_csr(V, E, seed=1, device=str(dev))
+    X = synth.gaussian_X(V, d, seed=2).double() + 1e-9 * synth.gaussian_X(V, d, seed=3).double()   # not fp32-representable
+    eng = SweepEngine(csr, X, dev)
+    assert eng.dtype == torch.float64 and eng.acc_dtype == torch.float64 and eng.class_rows[0] is not None
+    eng.build_P()
+    P = eng.P_global()
+    P_or = O.build_P_values(csr.rowptr, csr.colidx, X)
+    assert P.dtype == torch.float64 and O.rel_l2(P, P_or) < 1e-13
+    Ps = O.as_sparse(csr.rowptr, csr.colidx, P_or)
+    Z_or = X
+    for _ in range(3):
+        delta = eng.sweep(gamma)
+        Z_or, delta_or = O.sweep(csr.rowptr, csr.colidx, P_or, X, Z_or, gamma, Ps)
+        assert delta == pytest.approx(float(delta_or), rel=1e-12)
+    Z = eng.get_Z()
+    assert Z.dtype == torch.float64 and O.rel_l2(Z, Z_or) < 1e-13
+    eng_b = SweepEngine(csr, X, dev)
+    eng_b.build_P()
+    for _ in range(3):
+        eng_b.sweep(gamma)
+    assert torch.equal(eng_b.P, eng.P) and torch.equal(eng_b.Zcur, eng.Zcur)
+    del eng_b
+    eng_p = SweepEngine(csr, X, dev, cosine_mode="per_edge")
+    eng_p.build_P()
+    P_pe = eng_p.P_global().numpy()
+    hubs = np.argsort(np.diff(csr.rowptr))[-3:]
+    for r, want in per_edge_rows_f64(csr, X, list(hubs) + [11, 12, 13]).items():
+        a, b = csr.rowptr[r], csr.rowptr[r + 1]
+        if b > a:
+            assert np.linalg.norm(P_pe[a:b] - want) <= 1e-12 * np.linalg.norm(want), r
