@@ -233,12 +233,13 @@ def make_parser():
                          "plan: rows divided, one in-place RCCL all-gather of the updated rows per sweep; allgather = "
                          "the same for the live rows only; halo / halo_p2p = rows sent only to the ranks that read "
                          "them (clane_amd/halo.py, partition.py; DESIGN.md section 6)")
-    ap.add_argument("--also-exchange", default="allgather_all",
-                    choices=["none", "columns", "halo", "halo_p2p", "allgather", "allgather_all"],
-                    help="N > 1: after the main division's timed blocks, rebuild the engine with THIS division and report "
-                         "its sweeps/s, parity and collective time in `north_star_literal` (default allgather_all = "
-                         "north_star's row partition + one all-gather per sweep; skipped when it is the main division; "
-                         "none = off)")
+    ap.add_argument("--also-exchange", default="allgather_all,allgather,halo",
+                    help="N > 1: after the main division's timed blocks, rebuild the engine with each of these divisions "
+                         "(comma-separated) and report its sweeps/s, parity and collective time in the same record: "
+                         "allgather_all = north_star's row partition + one all-gather of the owned rows per sweep -> "
+                         "`north_star_literal`; the others (allgather = the same for the rows that change and are read; "
+                         "halo) -> `other_divisions`.  The main division is skipped; none = off.  One run of the "
+                         "driver's on 8 GPUs then compares every division on real links.")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow)")
     ap.add_argument("--rehearse-rccl", action="store_true",
@@ -707,61 +708,76 @@ def main():
                 if rank == 0:
                     print(json.dumps(result), flush=True)
 
-    if ranks.grouped and args.also_exchange not in ("none", eng.exchange) and not args.column_slice_of:
-        # Whatever happens in here, the main record above must come out: past the deadline every rank prints /
-        # leaves on its own (a rank stuck in a collective cannot be talked to).
+    also = [] if (args.also_exchange == "none" or not ranks.grouped or args.column_slice_of) else \
+        [x for x in args.also_exchange.split(",") if x and x != eng.exchange
+         and not (ranks.rehearsal and x not in ("columns", "allgather", "allgather_all"))]   # what ONE rank can be made to issue
+    timer = None
+    if also:
+        # Whatever happens in here, the main record above must come out: past the deadline (per division) every rank
+        # prints / leaves on its own (a rank stuck in a collective cannot be talked to).
         def give_up():
-            result["north_star_literal"] = {"exchange": args.also_exchange, "error": f"no result within "
-                                            f"{LITERAL_DEADLINE_S:.0f} s: printed without it"}
+            result.setdefault("north_star_literal", {"exchange": "allgather_all"})
+            result["also_exchange_error"] = (f"a division measured after the main one gave no result within "
+                                             f"{LITERAL_DEADLINE_S:.0f} s: printed as far as it got")
             emit()
             os._exit(0)
-        timer = threading.Timer(LITERAL_DEADLINE_S, give_up)
-        timer.daemon = True
-        timer.start()
-        block = {"exchange": args.also_exchange}
-        try:
-            main_division = eng.exchange
-            del m["eng"]
-            eng = None                      # the first engine's tables go back to the allocator before the second is built
-            torch.cuda.empty_cache()
-            m2 = measure_division(args, ranks, csr, X, args.also_exchange, time_kernels=False)
-            e2 = m2["eng"]
-            block.update({
-                "what": ("north_star's division: node rows of Z partitioned across the GPUs, every GPU holds the full Z, "
-                         "ONE in-place RCCL all-gather of the updated rows per sweep (per launch chunk, overlapped with "
-                         "the next chunk's kernels)" if args.also_exchange == "allgather_all" else
-                         f"the same graph divided with exchange={args.also_exchange}"),
-                "value": m2["value"], "unit": "sweeps/s", "ms_per_step": m2["ms_per_step"],
-                "ms_per_step_min": m2["ms_per_step_min"], "ms_per_step_max": m2["ms_per_step_max"],
-                "ms_per_step_hip_events": m2["ms_per_step_hip_events"], "steps": args.steps, "blocks": max(1, args.blocks),
-                "build_P_ms": m2["build_P_ms"], "last_delta": m2["delta"],
-                "parallelism": describe_parallelism(args, world, e2, X, E),
-                "host_sync": "pipelined" if m2["pipelined"] else "after every sweep",
-                "vs_main_division": m2["value"] / m["value"], "main_division": main_division,
-                "comm": comm_block(args, ranks, m2)})
-            bad = False
-            if rank == 0 and Z1_oracle is not None and m2["Z1"] is not None:
-                from oracle import clane_oracle as O
-                block["parity_rel_l2_vs_oracle_after_1_sweep"] = O.rel_l2(m2["Z1"].float(), Z1_oracle)
-                bad = not block["parity_rel_l2_vs_oracle_after_1_sweep"] < PARITY_TOL[dname]
-            if ranks.agree_to_fail(bad):
-                block["error"] = "parity check failed"
-                failed = True
-        except Exception as exc:            # noqa: BLE001 -- reported in the record; the main measurement stands
-            block["error"] = f"{type(exc).__name__}: {exc}"
-        result["north_star_literal"] = block
-    else:
-        timer = None
+        main_division, main_value = eng.exchange, m["value"]
+        del m["eng"]
+        eng = None                          # the first engine's tables go back to the allocator before the next is built
+        for exchange in also:
+            if timer is not None:
+                timer.cancel()
+            timer = threading.Timer(LITERAL_DEADLINE_S, give_up)
+            timer.daemon = True
+            timer.start()
+            block = {"exchange": exchange}
+            try:
+                torch.cuda.empty_cache()
+                m2 = measure_division(args, ranks, csr, X, exchange, time_kernels=False)
+                e2 = m2.pop("eng")
+                block.update({
+                    "what": {"allgather_all": "north_star's division: node rows of Z partitioned across the GPUs, every GPU "
+                                              "holds the full Z, ONE in-place RCCL all-gather of the owned rows per sweep (per "
+                                              "launch chunk, overlapped with the next chunk's kernels)",
+                             "allgather": "the same row partition and in-place all-gather, of the rows that CAN change and "
+                                          "ARE read only (outdeg > 0 and indeg > 0): rows without out-edges are never "
+                                          "updated (embedder.py:88-89), rows nobody reads are synchronised once at the end",
+                             "halo": "rows partitioned, each updated row sent only to the ranks that read it: one "
+                                     "all_to_all_single per launch chunk into a compact per-rank table"}.get(
+                                         exchange, f"the same graph divided with exchange={exchange}"),
+                    "value": m2["value"], "unit": "sweeps/s", "ms_per_step": m2["ms_per_step"],
+                    "ms_per_step_min": m2["ms_per_step_min"], "ms_per_step_max": m2["ms_per_step_max"],
+                    "ms_per_step_hip_events": m2["ms_per_step_hip_events"], "steps": args.steps,
+                    "blocks": max(1, args.blocks), "build_P_ms": m2["build_P_ms"], "last_delta": m2["delta"],
+                    "parallelism": describe_parallelism(args, world, e2, X, E),
+                    "host_sync": "pipelined" if m2["pipelined"] else "after every sweep",
+                    "vs_main_division": m2["value"] / main_value, "main_division": main_division,
+                    "comm": comm_block(args, ranks, dict(m2, eng=e2))})
+                bad = False
+                if rank == 0 and Z1_oracle is not None and m2["Z1"] is not None:
+                    from oracle import clane_oracle as O
+                    block["parity_rel_l2_vs_oracle_after_1_sweep"] = O.rel_l2(m2["Z1"].float(), Z1_oracle)
+                    bad = not block["parity_rel_l2_vs_oracle_after_1_sweep"] < PARITY_TOL[dname]
+                del e2, m2
+                if ranks.agree_to_fail(bad):
+                    block["error"] = "parity check failed"
+                    failed = True
+            except Exception as exc:        # noqa: BLE001 -- reported in the record; the main measurement stands
+                block["error"] = f"{type(exc).__name__}: {exc}"
+            if exchange == "allgather_all":
+                result["north_star_literal"] = block
+            else:
+                result.setdefault("other_divisions", {})[exchange] = block
     emit()
     if ranks.grouped:
-        # leave together.  The deadline stays armed until everybody is here: a rank that fell out of the block above
+        # leave together.  The deadline stays armed until everybody is here: a rank that fell out of a block above
         # on its own (an exception the others did not have) would otherwise wait for ranks stuck in a collective.
         dist.barrier()
         if timer is not None:
             timer.cancel()
         dist.destroy_process_group()
     if failed:
-        raise SystemExit("north_star_literal: parity check failed")
+        raise SystemExit("a division measured after the main one failed its parity check")
 
 
 if __name__ == "__main__":

@@ -639,6 +639,14 @@ def test_bench_four_ranks_share_one_gpu_with_an_idle_column_rank():
     assert lit["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and lit["comm"]["exchange_bytes_per_sweep"] > 0
     assert len(lit["comm"]["exchange_bytes_per_sweep_by_rank"]) == 4
     assert lit["last_delta"] == pytest.approx(r["last_delta"], rel=5e-5)
+    # ... and the leaner row splits, so that one run on real links compares every division
+    others = r["other_divisions"]
+    assert set(others) == {"allgather", "halo"}
+    for name, blk in others.items():
+        assert "error" not in blk and blk["comm"]["exchange"] == name and blk["comm"]["ranks_seen"] == 4
+        assert blk["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and blk["value"] > 0
+        assert blk["comm"]["exchange_bytes_per_sweep"] <= lit["comm"]["exchange_bytes_per_sweep"]
+        assert blk["last_delta"] == pytest.approx(r["last_delta"], rel=5e-5)
 
 
 # ---- the row-binning heuristics on graphs off their tuning set (results must not depend on them) --------------------
@@ -693,7 +701,8 @@ def test_bench_main_record_survives_a_stuck_literal_block():
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
-    assert r["comm"]["ranks_seen"] == 2 and "no result within" in r["north_star_literal"]["error"]
+    assert r["comm"]["ranks_seen"] == 2 and "no result within" in r["also_exchange_error"]
+    assert "value" not in r["north_star_literal"]
 
 
 def test_bench_n_gpu_flow_through_real_rccl_with_one_rank():
@@ -730,6 +739,7 @@ def test_bench_n_gpu_flow_through_real_rccl_with_one_rank():
     assert lit["comm"]["collectives_issued"]["all_gather"] >= 3 * 2 + 2             # one in-place all-gather per sweep
     assert lit["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
     assert lit["last_delta"] == pytest.approx(r0["last_delta"], rel=5e-5)
+    assert set(r["other_divisions"]) == {"allgather"} and "error" not in r["other_divisions"]["allgather"]
 
 
 # ---- float64 content embeddings (a `C.npy` of dtype float64, reference golden G6) at config 2's size ----------------
