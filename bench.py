@@ -721,6 +721,10 @@ def main():
                                              f"{LITERAL_DEADLINE_S:.0f} s: printed as far as it got")
             emit()
             os._exit(0)
+        # a safety copy for the logs: should a later division take the process down (a fault, an abort inside the
+        # library), the measurement of the main division has been seen
+        log("main division measured; the record so far (the ONE stdout line follows after the other divisions): "
+            + json.dumps(result))
         main_division, main_value = eng.exchange, m["value"]
         del m["eng"]
         eng = None                          # the first engine's tables go back to the allocator before the next is built
