@@ -273,7 +273,7 @@ class KernelBackend(abc.ABC):
     @abc.abstractmethod
     def edge_score_class(self, rowptr, colidx, item_e0, item_len, item_slot, item_row, items_per_block, class_rows,
                          slot_ptr, row0, Z, d, mode, sums2, sq, scores, stats=None, fuse_softmax=False,
-                         n_slots=None): ...
+                         n_slots=None, row_parts=1): ...
     @abc.abstractmethod
     def edge_score_finalize(self, rowptr, colidx, nrows, row0, mode, sums2, sq, scores): ...
     @abc.abstractmethod
@@ -425,7 +425,7 @@ class HipKernels(KernelBackend):
 
     def edge_score_class(self, rowptr, colidx, item_e0, item_len, item_slot, item_row, items_per_block: int, class_rows,
                          slot_ptr, row0: int, Z, d: int, mode: int, sums2, sq, scores, stats=None,
-                         fuse_softmax: bool = False, n_slots: Optional[int] = None):
+                         fuse_softmax: bool = False, n_slots: Optional[int] = None, row_parts: int = 1):
         """K1 over the class rows' work items (XCD-affine gathers); with `fuse_softmax` every listed row leaves
         soft-maxed (stats: 2 accumulate-type elements per slot).  ``n_slots`` = slot_ptr[-1] when the caller knows it
         on the host (the engine does): without it the size check of `stats` reads it back from the device, which
@@ -443,7 +443,8 @@ class HipKernels(KernelBackend):
             _vec(item_slot, torch.int32, "item_slot"), _vec(item_row, torch.int32, "item_row"),
             n_items // items_per_block, items_per_block, _vec(class_rows, torch.int32, "class_rows"),
             _vec(slot_ptr, torch.int64, "slot_ptr"), class_rows.numel(), row0, zp, ldz, d, mode, _ptr(sums2), _ptr(sq),
-            _vec(scores, acc, "scores"), SCORE_FUSE_SOFTMAX if fuse_softmax else 0,
+            _vec(scores, acc, "scores"),
+            (SCORE_FUSE_SOFTMAX | ((max(1, min(255, int(row_parts))) & 0xff) << 8)) if fuse_softmax else 0,
             None if stats is None else _vec(stats, acc, "stats"), self._stream(Z)), "clane_edge_score_class")
 
     def edge_score_finalize(self, rowptr, colidx, nrows: int, row0: int, mode: int, sums2, sq, scores):

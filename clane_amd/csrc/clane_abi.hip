@@ -222,9 +222,13 @@ int edge_score_class(const int64_t *rowptr, const int32_t *colidx, const int64_t
             colidx, item_e0, item_len, item_slot, item_row, items_per_block, row0, Z, ldz, d, mode, sums2, sq, scores,
             fuse ? stats : nullptr);
     });
-    if (fuse)
-        edge_softmax_class_kernel<typename Elem<T>::acc_t><<<unsigned(n_rows), kBlock, 0, (hipStream_t)stream>>>(
-            rowptr, class_rows, slot_ptr, stats, scores);
+    if (fuse) {
+        int parts = (flags >> 8) & 0xff;        // CLANE_SCORE_ROW_PARTS(n): workgroups per row of the rescale pass
+        if (parts < 1) parts = 1;
+        edge_softmax_class_kernel<typename Elem<T>::acc_t>
+            <<<dim3(unsigned(n_rows), unsigned(parts)), kBlock, 0, (hipStream_t)stream>>>(rowptr, class_rows, slot_ptr,
+                                                                                            stats, scores);
+    }
     return check_launch("edge_score_class");
 }
 
@@ -451,7 +455,7 @@ const char *clane_build_info(void) {
     return "arch=gfx950;SPMM_U=" CLANE_STR(CLANE_SPMM_U) ";LONG_U=" CLANE_STR(CLANE_LONG_U) ";LONG_WAVES=" CLANE_STR(
         CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM)
         ";TARGET_GRID=" CLANE_STR(CLANE_TARGET_GRID) ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH)
-        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP);
+        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";COMBINE_LOADS=" CLANE_STR(CLANE_COMBINE_LOADS);
 }
 
 int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *stream) {

@@ -445,6 +445,9 @@ __global__ __launch_bounds__(kBlock) void edge_score_class_kernel(
 // l, l + 64, ... in slot order, then a fixed butterfly -- the association depends on the slot count alone (not on the
 // thread count, not on which wave), and a 4 000-slot hub is a chain of 64 dependent steps instead of 4 000 (r03; every
 // thread used to walk the whole list: 0.38 ms of config 4's build_P).
+// gridDim.y workgroups share one row's rescale pass (CLANE_SCORE_ROW_PARTS: a 2M-edge row rescaled by ONE workgroup was
+// 2.3 ms of a 6.6 ms build_P); each forms the row's {max, total} itself -- the same way, so all parts agree -- and a
+// part whose share of the row is empty leaves before doing so.
 template <typename A>
 __global__ __launch_bounds__(kBlock) void edge_softmax_class_kernel(const int64_t *__restrict__ rowptr,
                                                                     const int32_t *__restrict__ class_rows,
@@ -454,6 +457,11 @@ __global__ __launch_bounds__(kBlock) void edge_softmax_class_kernel(const int64_
     const int i = blockIdx.x;
     const int lane = lane_id();
     const int64_t r = class_rows[i];
+    const int64_t row_e0 = rowptr[r], row_e1 = rowptr[r + 1];
+    const int64_t share = ceil_div(ceil_div(row_e1 - row_e0, int64_t(gridDim.y)), kBlock) * kBlock;
+    const int64_t my_e0 = row_e0 + int64_t(blockIdx.y) * share;
+    if (my_e0 >= row_e1) return;
+    const int64_t my_e1 = my_e0 + share < row_e1 ? my_e0 + share : row_e1;
     const int64_t s0 = slot_ptr[i], s1 = slot_ptr[i + 1];
     A m = -A(INFINITY);
     for (int64_t s = s0 + lane; s < s1; s += kWave) m = fmax(m, stats[2 * s]);
@@ -461,8 +469,7 @@ __global__ __launch_bounds__(kBlock) void edge_softmax_class_kernel(const int64_
     A total = A(0);
     for (int64_t s = s0 + lane; s < s1; s += kWave) total += stats[2 * s + 1] * exp_acc<A>(stats[2 * s] - m);
     total = group_sum<kWave>(total);
-    const int64_t e1 = rowptr[r + 1];
-    for (int64_t e = rowptr[r] + threadIdx.x; e < e1; e += kBlock) scores[e] = exp_acc<A>(scores[e] - m) / total;
+    for (int64_t e = my_e0 + threadIdx.x; e < my_e1; e += kBlock) scores[e] = exp_acc<A>(scores[e] - m) / total;
 }
 
 }  // namespace clane

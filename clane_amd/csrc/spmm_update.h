@@ -692,6 +692,10 @@ __global__ __launch_bounds__(kBlock) void spmm_class_chunk_kernel(
 // heavy row's chain of dependent loads is a kCombineWaves-th of what one wave would walk (config 3's heaviest row:
 // 280 slots; the 2.4e9-edge test's hubs: 4 688).
 constexpr int kCombineWaves = CLANE_COMBINE_WAVES;
+#ifndef CLANE_COMBINE_LOADS
+#define CLANE_COMBINE_LOADS 16    // slot loads in flight per wave of the combine (rows of fewer slots take the plain loop)
+#endif
+constexpr int kCombineLoads = CLANE_COMBINE_LOADS;
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kernel(
@@ -717,8 +721,21 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = A(0);
         if (ok) {
+            // kCombineLoads slots requested back to back, then added in slot order: a mega-hub's share is thousands of
+            // slots (a 2M-edge row: 3 920 per wave), and with 4 loads in flight a wave streamed them at 8 GB/s
+            int64_t s = a;
+            for (; s + kCombineLoads <= b; s += kCombineLoads) {
+                Pack<A, VEC> part[kCombineLoads];
+#pragma unroll
+                for (int u = 0; u < kCombineLoads; ++u) part[u] = load_pack<A, VEC>(slab + (s + u) * ld_slab + c0);
+#pragma unroll
+                for (int u = 0; u < kCombineLoads; ++u) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] += part[u].v[k];
+                }
+            }
 #pragma unroll 4
-            for (int64_t s = a; s < b; ++s) {
+            for (; s < b; ++s) {
                 const Pack<A, VEC> part = load_pack<A, VEC>(slab + s * ld_slab + c0);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] += part.v[k];

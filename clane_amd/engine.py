@@ -66,6 +66,7 @@ TARGET_SEGMENTS = 512                   # two workgroups per CU
 # against 20.7 on a near-regular 2M / 128M graph (profiles/r03_threshold_robustness.md).  Below MIN_HOT_READ_SHARE only
 # rows that need their work spread anyway (above HEAVY_ROW_EDGES: the class pass doubles as the hub splitter, a
 # 2M-edge row scored by ONE workgroup took build_P from 6.6 to 29 ms) take the pass.
+SOFTMAX_EDGES_PER_WORKGROUP = 1 << 17     # build_P: edges of one class row that one workgroup of the rescale pass takes
 L2_BYTES_ALL_XCDS = 8 * 4 * 1024 * 1024
 MIN_HOT_READ_SHARE = 0.2
 HEAVY_ROW_EDGES = 4096
@@ -296,6 +297,9 @@ class SweepEngine:
         self.P_valid = False
         deg = np.diff(self.local.rowptr)
         self.max_degree = int(deg.max()) if deg.size else 0
+        # workgroups that share the final softmax rescale of one class row in build_P: one, until a row is long enough for
+        # that single workgroup to be the tail of build_P (a 2M-edge row: 2.3 ms of 6.6; config 3's 70k-edge hub: one)
+        self.softmax_row_parts = int(min(64, max(1, -(-self.max_degree // SOFTMAX_EDGES_PER_WORKGROUP))))
         # per block: row lists relative to the block's first row (the kernels get rowptr / X / Z_new offset to it)
         self.long_rows: List[Optional[torch.Tensor]] = []     # every row above score_threshold (K1 / K2 slice these)
         self.mid_rows: List[Optional[torch.Tensor]] = []      # long_threshold < deg <= hub_threshold: 4 waves/row
@@ -651,7 +655,7 @@ class SweepEngine:
                     k.edge_score_class(rp, self.colidx, it_e0, it_len, it_slot, it_row, ipb, rows_c,
                                        slot_ptr, b.row0, Z, self.d, mode, self.sums2, sq, self.P,
                                        self.slabs[i % len(self.slabs)], fuse_softmax=True,
-                                       n_slots=self.class_slots[i])
+                                       n_slots=self.class_slots[i], row_parts=self.softmax_row_parts)
         elif self.E_loc > 0:
             # column split: dot products of the owned columns, summed over the GPUs, then denominators + softmax
             if busy:

@@ -51,6 +51,9 @@ extern "C" {
 
 /* flags of clane_edge_score_* */
 #define CLANE_SCORE_FUSE_SOFTMAX 1
+/* clane_edge_score_class_* with CLANE_SCORE_FUSE_SOFTMAX: n (1..255) workgroups share the final rescale pass of each
+ * listed row -- for graphs with rows of millions of edges; results do not depend on n; 0 means 1 */
+#define CLANE_SCORE_ROW_PARTS(n) (((n) & 0xff) << 8)
 
 /* flags of clane_spmm_update_* */
 #define CLANE_SPMM_SINKS_UNTOUCHED 1

@@ -68,7 +68,8 @@ class OracleKernels(KernelBackend):
                     scores[rp[r]:rp[r + 1]] = torch.softmax(scores[rp[r]:rp[r + 1]], 0)
 
     def edge_score_class(self, rowptr, colidx, item_e0, item_len, item_slot, item_row, items_per_block, class_rows,
-                         slot_ptr, row0, Z, d, mode, sums2, sq, scores, stats=None, fuse_softmax=False, n_slots=None):
+                         slot_ptr, row0, Z, d, mode, sums2, sq, scores, stats=None, fuse_softmax=False, n_slots=None,
+                         row_parts=1):
         """K1 over the class rows' items; checks the same layout contract as spmm_update_class."""
         assert n_slots is None or n_slots == int(slot_ptr[-1])
         e0, ln, rw = _np(item_e0), _np(item_len), _np(item_row)
