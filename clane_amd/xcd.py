@@ -64,6 +64,8 @@ CLASS_CHUNK = 256
 PHASES_BY_ROWS_PER_WAVE = {1: 4, 2: 2, 4: 1, 8: 1}
 PHASE_THRESHOLD = 512
 CLASS_ITEMS_PIECE_EDGES = 1 << 28
+import os
+ITEM_ORDER = os.environ.get("CLANE_ITEM_ORDER", "none")      # experiment: none | heavy | all (see class_items)
 CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
 
 
@@ -145,6 +147,11 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
         if not in_group.any():
             continue
         per_class = [np.nonzero(in_group & (item_cls == c))[0] for c in range(XCD_CLASSES)]
+        if ITEM_ORDER == "all" or (ITEM_ORDER == "heavy" and g < max(1, phases)):
+            # items of one class in the order of their first column instead of row by row: chunks of DIFFERENT rows that
+            # gather the same stretch of the table run next to each other (slots, and with them the order of every sum,
+            # stay row-major)
+            per_class = [pc[np.argsort(colidx[e0[pc]], kind="stable")] for pc in per_class]
         nblk = max(-(-len(pc) // items_per_block) for pc in per_class)
         flat = XCD_CLASSES * nblk * items_per_block
         g_e0 = np.zeros(flat, dtype=np.int64)
