@@ -240,6 +240,9 @@ class SweepEngine:
         self.phase_threshold = max(int(phase_threshold), self.class_threshold) if self.class_phases > 1 else 0
         if self.class_threshold and not (64 <= self.class_chunk <= 4096 and self.class_chunk % 64 == 0):
             raise ValueError("class_chunk must be a multiple of 64 in [64, 4096]")
+        # a row one of whose (phase, class) segments alone is more than one XCD's L2 holds: its chunks are scheduled by
+        # column, next to the other such rows' (xcd.class_items)
+        self.mega_segment_edges = int(L2_BYTES_ALL_XCDS // 8 // max(self.ld * X.element_size(), 1)) if self.d > 0 else 0
         self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
         if self.p2p and self.world > 8:
             raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
@@ -327,7 +330,8 @@ class SweepEngine:
             rows_c = np.nonzero(is_class)[0]
             if rows_c.size:
                 rows_abs = rows_c + b.local_start
-                phased = dict(phase_threshold=self.phase_threshold, phases=self.class_phases)
+                phased = dict(phase_threshold=self.phase_threshold, phases=self.class_phases,
+                              mega_segment_edges=self.mega_segment_edges)
                 # items per workgroup follow the item count (few chunks in a launch -- a chunk of a rank's rows --
                 # get smaller workgroups): class_items picks it after its one counting pass over the edges
                 items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk, None,
@@ -919,7 +923,7 @@ class SweepEngine:
                 "class_threshold": self.class_threshold, "class_chunk": self.class_chunk, "class_k1": self.class_k1,
                 "class_phases": self.class_phases, "phase_threshold": self.phase_threshold,
                 "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
-                "class_affinity": self.class_affinity,
+                "class_affinity": self.class_affinity, "mega_segment_edges": self.mega_segment_edges,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 
     def exchange_bytes_per_sweep(self) -> int:

@@ -64,8 +64,6 @@ CLASS_CHUNK = 256
 PHASES_BY_ROWS_PER_WAVE = {1: 4, 2: 2, 4: 1, 8: 1}
 PHASE_THRESHOLD = 512
 CLASS_ITEMS_PIECE_EDGES = 1 << 28
-import os
-ITEM_ORDER = os.environ.get("CLANE_ITEM_ORDER", "none")      # experiment: none | heavy | all (see class_items)
 CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
 
 
@@ -84,7 +82,7 @@ def row_pieces(rowptr: np.ndarray, max_edges: int):
 
 def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: Optional[int],
                 row_ids: Optional[np.ndarray] = None, colidx_dev: Optional[torch.Tensor] = None,
-                phase_threshold: int = 0, phases: int = 1) -> dict:
+                phase_threshold: int = 0, phases: int = 1, mega_segment_edges: int = 0) -> dict:
     """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
     (xcd_class(column), column)): every class segment of a row is cut into chunks of at most `chunk` edges.
     Slots -- where the partial sums go -- are numbered row by row, class by class, chunk by chunk, so a row's slots
@@ -92,7 +90,8 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     `items_per_block` items of ONE class, block j of class b at block index 8 j + b, padded with empty items
     (len 0, slot -1).  With `phases` > 1 the rows above `phase_threshold` edges are cut by (phase, class) -- their
     edges sorted by xcd_subclass -- and their blocks come first, phase by phase (each phase a whole number of
-    8-block rounds, so block index % 8 stays the class), then the blocks of the other rows.  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
+    8-block rounds, so block index % 8 stays the class), then the blocks of the other rows.  Inside a class the items go row
+    by row, except those of mega rows (`mega_segment_edges`), which come first ordered by their first column.  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
     item's row, default `rows` itself), int64 slot_ptr [rows + 1] and the items_per_block used (None on entry: chosen
     by `items_per_block_for` from the item count, once the O(E) counting pass has it -- the layout itself is cheap)."""
     n = rows.size
@@ -137,6 +136,9 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     np.cumsum(nchunk.reshape(n, NS).sum(1), out=slot_ptr[1:])
     item_cls = (seg_of % NS) % XCD_CLASSES
     heavy = sizes > phase_threshold if (phases > 1 and phase_threshold > 0) else np.zeros(n, dtype=bool)
+    # rows whose average (phase, class) segment exceeds `mega_segment_edges` edges (0 = none): see the item order below
+    mega = (sizes > mega_segment_edges * XCD_CLASSES * np.where(heavy, max(1, phases), 1)) if mega_segment_edges > 0 \
+        else np.zeros(n, dtype=bool)
     # launch groups, in order: the heavy rows' items phase by phase, then everybody else's
     item_group = np.where(heavy[seg_of // NS], (seg_of % NS) // XCD_CLASSES, max(1, phases))
     ids = (rows if row_ids is None else row_ids).astype(np.int32)
@@ -147,11 +149,19 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
         if not in_group.any():
             continue
         per_class = [np.nonzero(in_group & (item_cls == c))[0] for c in range(XCD_CLASSES)]
-        if ITEM_ORDER == "all" or (ITEM_ORDER == "heavy" and g < max(1, phases)):
-            # items of one class in the order of their first column instead of row by row: chunks of DIFFERENT rows that
-            # gather the same stretch of the table run next to each other (slots, and with them the order of every sum,
-            # stay row-major)
-            per_class = [pc[np.argsort(colidx[e0[pc]], kind="stable")] for pc in per_class]
+        if mega.any():
+            # MEGA rows -- one (phase, class) segment of the row alone is more than an L2 holds -- come first in their
+            # class, their items in the order of their first column instead of row by row: chunks of DIFFERENT mega rows
+            # that gather the same stretch of the table then run next to each other and share it through the L2 (ten rows
+            # that read all 2M vertices: class pass 3.03 -> 1.68 ms).  Row by row, such a row has left the L2 long
+            # before the next one comes by; for rows whose segments fit (config 3's 70k-edge hub: 2.2 MB) row order is
+            # the better one (2.35 vs 2.41 ms).  Slots, and with them the order of every sum, stay row-major.
+            ordered = []
+            for pc in per_class:
+                is_mega = mega[seg_of[pc] // NS]
+                first = pc[is_mega]
+                ordered.append(np.concatenate([first[np.argsort(colidx[e0[first]], kind="stable")], pc[~is_mega]]))
+            per_class = ordered
         nblk = max(-(-len(pc) // items_per_block) for pc in per_class)
         flat = XCD_CLASSES * nblk * items_per_block
         g_e0 = np.zeros(flat, dtype=np.int64)

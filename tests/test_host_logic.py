@@ -751,6 +751,44 @@ def test_per_sweep_log_lines_are_the_references(tmp_path):
     assert got[-1].endswith(" 0") and abs(len(got) - len(want)) <= 3
 
 
+def test_mega_rows_items_are_scheduled_by_column():
+    """Rows one of whose (phase, class) segments alone is more than an L2 holds (`mega_segment_edges`): their work items
+    come first in their class and in the order of their first column, so that chunks of different mega rows gathering
+    the same stretch of the table run next to each other; the other rows' items keep row order behind them; slots (the
+    order of every sum) and the items themselves are what they were."""
+    from clane_amd.xcd import class_items, xcd_class
+    rng = np.random.default_rng(9)
+    V = 4000
+    deg = np.full(6, 40)
+    deg[[1, 4]] = V                                   # two rows that read every vertex
+    cols = []
+    for k in deg:
+        c = np.sort(rng.choice(V, size=k, replace=False))
+        cols.append(c[np.lexsort((c, xcd_class(c)))])            # (class, column) order, as the engine lays class rows out
+    rowptr = np.zeros(7, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    colidx = np.concatenate(cols).astype(np.int32)
+    rows = np.arange(6)
+    plain = class_items(rowptr, colidx, rows, 64, 8)
+    mega = class_items(rowptr, colidx, rows, 64, 8, mega_segment_edges=100)     # 4000 / 8 = 500 edges a class > 100
+    assert np.array_equal(plain["slot_ptr"], mega["slot_ptr"])
+    key = lambda it: sorted(zip(it["e0"][it["len"] > 0].tolist(), it["len"][it["len"] > 0].tolist(),   # noqa: E731
+                                it["slot"][it["len"] > 0].tolist(), it["row"][it["len"] > 0].tolist()))
+    assert key(plain) == key(mega)                    # the same items with the same slots, in another order
+    ipb = mega["items_per_block"]
+    for c in range(8):
+        blocks = [b for b in range(len(mega["e0"]) // ipb) if b % 8 == c]
+        seq = [i for b in blocks for i in range(b * ipb, (b + 1) * ipb) if mega["len"][i] > 0]
+        is_mega = np.isin(mega["row"][seq], [1, 4])
+        n_mega = int(is_mega.sum())
+        assert n_mega > 0 and is_mega[:n_mega].all() and not is_mega[n_mega:].any()       # mega rows first
+        first_col = colidx[mega["e0"][seq[:n_mega]]]
+        assert (np.diff(first_col) >= 0).all() and len(set(mega["row"][seq[:n_mega]])) == 2   # by column, rows interleaved
+        rest_rows = mega["row"][seq[n_mega:]]
+        assert (np.diff(rest_rows) >= 0).all()                                          # the others: row by row
+        assert bool((xcd_class(colidx[mega["e0"][seq]].astype(np.int64)) == c).all())
+
+
 @pytest.mark.parametrize("chunks,hot", [(1, True), (3, True), (1, False)])
 def test_class_affine_rows_layout_and_result(chunks, hot):
     """Rows above `class_threshold` edges: edges sorted by (XCD class of the column, column), cut into chunks of one class, chunk
