@@ -331,7 +331,8 @@ class SweepEngine:
             if rows_c.size:
                 rows_abs = rows_c + b.local_start
                 phased = dict(phase_threshold=self.phase_threshold, phases=self.class_phases,
-                              mega_segment_edges=self.mega_segment_edges)
+                              mega_segment_edges=self.mega_segment_edges,
+                              mega_min_edges=self.part.padded_vertices // 4)
                 # items per workgroup follow the item count (few chunks in a launch -- a chunk of a rank's rows --
                 # get smaller workgroups): class_items picks it after its one counting pass over the edges
                 items = class_items(self.local.rowptr, self.local.colidx, rows_abs, self.class_chunk, None,

@@ -82,7 +82,7 @@ def row_pieces(rowptr: np.ndarray, max_edges: int):
 
 def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk: int, items_per_block: Optional[int],
                 row_ids: Optional[np.ndarray] = None, colidx_dev: Optional[torch.Tensor] = None,
-                phase_threshold: int = 0, phases: int = 1, mega_segment_edges: int = 0) -> dict:
+                phase_threshold: int = 0, phases: int = 1, mega_segment_edges: int = 0, mega_min_edges: int = 0) -> dict:
     """Work items of the XCD-affine pass over `rows` (absolute local row ids whose edges are sorted by
     (xcd_class(column), column)): every class segment of a row is cut into chunks of at most `chunk` edges.
     Slots -- where the partial sums go -- are numbered row by row, class by class, chunk by chunk, so a row's slots
@@ -137,8 +137,10 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     item_cls = (seg_of % NS) % XCD_CLASSES
     heavy = sizes > phase_threshold if (phases > 1 and phase_threshold > 0) else np.zeros(n, dtype=bool)
     # rows whose average (phase, class) segment exceeds `mega_segment_edges` edges (0 = none): see the item order below
-    mega = (sizes > mega_segment_edges * XCD_CLASSES * np.where(heavy, max(1, phases), 1)) if mega_segment_edges > 0 \
-        else np.zeros(n, dtype=bool)
+    # and that read at least `mega_min_edges` table rows (the engine passes a quarter of the table: two such rows
+    # share much of what they gather; 256 hubs that each read 3.6 % of a 33M-row table do not, and lost 4 % by column)
+    mega = ((sizes > mega_segment_edges * XCD_CLASSES * np.where(heavy, max(1, phases), 1)) & (sizes >= mega_min_edges)) \
+        if mega_segment_edges > 0 else np.zeros(n, dtype=bool)
     # launch groups, in order: the heavy rows' items phase by phase, then everybody else's
     item_group = np.where(heavy[seg_of // NS], (seg_of % NS) // XCD_CLASSES, max(1, phases))
     ids = (rows if row_ids is None else row_ids).astype(np.int32)

@@ -770,7 +770,10 @@ def test_mega_rows_items_are_scheduled_by_column():
     colidx = np.concatenate(cols).astype(np.int32)
     rows = np.arange(6)
     plain = class_items(rowptr, colidx, rows, 64, 8)
-    mega = class_items(rowptr, colidx, rows, 64, 8, mega_segment_edges=100)     # 4000 / 8 = 500 edges a class > 100
+    mega = class_items(rowptr, colidx, rows, 64, 8, mega_segment_edges=100,    # 4000 / 8 = 500 edges a class > 100
+                       mega_min_edges=V // 4)
+    sparse_hubs = class_items(rowptr, colidx, rows, 64, 8, mega_segment_edges=100, mega_min_edges=2 * V)
+    assert all(np.array_equal(plain[k], sparse_hubs[k]) for k in plain)         # long rows that share little: row order
     assert np.array_equal(plain["slot_ptr"], mega["slot_ptr"])
     key = lambda it: sorted(zip(it["e0"][it["len"] > 0].tolist(), it["len"][it["len"] > 0].tolist(),   # noqa: E731
                                 it["slot"][it["len"] > 0].tolist(), it["row"][it["len"] > 0].tolist()))
