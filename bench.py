@@ -248,6 +248,8 @@ def make_parser():
                          "north_star_literal block with its in-place all-gathers -- goes through the real library (each "
                          "collective is the identity on one rank).  Shows no scaling; catches API, dtype and stream "
                          "mistakes that the gloo rehearsals cannot.  Not a headline number.")
+    ap.add_argument("--no-delta-stream-ab", action="store_true",
+                    help="N > 1: skip the extra timed blocks with the delta's all-reduce on its own stream (comm.delta_stream_ab)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (RCCL refuses that: use --backend gloo)")
     ap.add_argument("--host-sync", default="auto", choices=["auto", "every-sweep", "pipelined"],
@@ -438,6 +440,40 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
         local_wall.append(mine)
         hip_ms.append(ev0.elapsed_time(ev1))
     eng.time_kernels = eng.time_collectives = False
+    # The same protocol once more with the delta's all-reduce on a stream of its own (SweepEngine(delta_stream=True)):
+    # off by default because one rank cannot show whether it pays (profiles/r02_delta_stream_ab.md) -- a run between
+    # real GPUs can, and this is where it says so.  `value` stays the default's.
+    ab = None
+    if ranks.grouped and not args.no_delta_stream_ab:
+        try:
+            eng.use_delta_stream(True)
+            for _ in range(3):
+                eng.sweep(args.gamma)
+            on = []
+            for _ in range(min(3, max(1, args.blocks))):
+                ranks.barrier()
+                t0 = time.perf_counter()
+                if pipelined:
+                    ticket = eng.sweep_launch(args.gamma)
+                    for _ in range(args.steps - 1):
+                        following = eng.sweep_launch(args.gamma)
+                        eng.sweep_wait(ticket)
+                        ticket = following
+                    eng.sweep_wait(ticket)
+                else:
+                    for _ in range(args.steps):
+                        eng.sweep(args.gamma)
+                torch.cuda.synchronize()
+                ranks.barrier()
+                on.append(ranks.max_over_ranks([time.perf_counter() - t0])[0])
+            ab = {"off_ms_per_step": statistics.median(wall) / args.steps * 1e3,
+                  "on_ms_per_step": statistics.median(on) / args.steps * 1e3,
+                  "note": "on = the all-reduce of the delta and its copy to the host on a stream of their own "
+                          "(SweepEngine(delta_stream=True)); the record's value is the default (off)"}
+        except Exception as exc:            # noqa: BLE001 -- an extra; the measurement above stands
+            ab = {"error": f"{type(exc).__name__}: {exc}"}
+        finally:
+            eng.use_delta_stream(False)
     med = statistics.median(wall)
     out.update({
         "delta": delta, "elapsed": med, "value": args.steps / med, "ms_per_step": med / args.steps * 1e3,
@@ -447,6 +483,7 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
         "ktimes": eng.kernel_times_ms() if time_kernels else {}, "ctimes": eng.collective_times_ms(),
         # this rank's own clock, before the closing barrier: the spread over the ranks says who waits for whom
         "rank_ms_per_step": ranks.gather_objects(statistics.median(local_wall) / args.steps * 1e3),
+        "delta_stream_ab": ab,
     })
     return out
 
@@ -479,7 +516,8 @@ def comm_block(args, ranks: Ranks, m) -> dict:
                                          "exchange still outstanding once the rank's own kernels are done (what the "
                                          "per-chunk overlap did not hide) + the all-reduce of the delta scalar"},
             "ms_per_step_by_rank": per_rank, "ms_per_step_rank_min": min(per_rank), "ms_per_step_rank_max": max(per_rank),
-            "collectives_issued": dict(eng.comm.calls) if hasattr(eng.comm, "calls") else None}
+            "collectives_issued": dict(eng.comm.calls) if hasattr(eng.comm, "calls") else None,
+            "delta_stream_ab": m.get("delta_stream_ab")}
 
 
 def describe_parallelism(args, world, eng, X, E) -> str:

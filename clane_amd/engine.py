@@ -463,6 +463,16 @@ class SweepEngine:
         self._own_vertex = None          # stage_Z(pieces=True) on a row split: vertex id of every own row
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
 
+    def use_delta_stream(self, on: bool) -> None:
+        """Switch the delta's all-reduce + host copy onto a stream of their own (or back onto the sweep's) between
+        sweeps: the constructor's ``delta_stream`` made switchable, so that one run on real GPUs can time both
+        (bench.py's `comm.delta_stream_ab`).  Results are bit-identical either way."""
+        if self.device.type != "cuda" or not (self.world > 1 or self._forced):
+            return
+        torch.cuda.synchronize(self.device)         # nothing of the other mode is in flight
+        self._delta_busy = [False, False]
+        self._delta_stream = torch.cuda.Stream(self.device) if on else None
+
     def _build_p2p_mirrors(self, deg) -> None:
         """halo_p2p: for each destination parity and own chunk, where every finished row has to go -- (rank q,
         row of q's table) for each rank q that reads it.  q's table rows come from q's own layout (the start of

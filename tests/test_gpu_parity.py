@@ -1076,6 +1076,8 @@ def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
     assert comm["exchange_bytes_per_sweep"] == 0 and comm["collective_ms_per_sweep"] > 0      # the scalar all-reduce
     assert comm["collective_detail"]["sweeps_timed"] > 0 and len(comm["ms_per_step_by_rank"]) == 2
     assert comm["ms_per_step_rank_min"] <= comm["ms_per_step_rank_max"] <= r2["ms_per_step_max"] * 1.5
+    ab = comm["delta_stream_ab"]                # the delta's all-reduce on its own stream, timed beside the default
+    assert "error" not in ab and ab["on_ms_per_step"] > 0 and ab["off_ms_per_step"] == pytest.approx(r2["ms_per_step"])
     # ... and north_star's literal division (rows + one all-gather per sweep) measured beside the default one
     lit = r2["north_star_literal"]
     assert lit["exchange"] == "allgather_all" and "error" not in lit and lit["value"] > 0
