@@ -155,8 +155,7 @@ class Embedder(object):
 
     def _stage(self, engine, world: int):
         """This sweep's embeddings on their way to the host."""
-        pieces = (world > 1 and self._writer is not None and self._parts_dir is not None
-                  and engine.device.type == "cuda")
+        pieces = world > 1 and self._writer is not None and self._parts_dir is not None
         if pieces and self._writer.assembler is None:
             self._writer.assembler = _PartsAssembler(self._parts_dir, engine.comm.rank, world,
                                                      (engine.V, engine.d_full), engine.dtype)

@@ -585,9 +585,17 @@ class SweepEngine:
         whoever wants the whole matrix puts the ranks' pieces together on the host (``StagedZ.piece``,
         ``place_piece``; ``Embedder`` does, through files).  Without ``pieces`` a multi-GPU run gathers synchronously
         (``get_Z``: collective), as a host-memory engine does."""
-        if self.device.type != "cuda" or (self.world > 1 and not pieces):
+        if self.world > 1 and not pieces:
             return StagedZ(ready=self.get_Z())
         by_rows = self.world > 1 and not self.columns          # this rank's own rows; else all rows (of its columns)
+        if self.device.type != "cuda":          # host-memory engine (the CPU suite's test double): nothing to overlap
+            if self.world == 1:
+                return StagedZ(ready=self.get_Z())
+            if by_rows:
+                own = torch.cat([self._zrows(self.Zcur, b)[:, :self.d] for b in self.blocks]).clone()
+                return StagedZ(ready=own, where={"kind": "rows", "vertex": torch.from_numpy(self.local.vertex.astype(np.int64))})
+            return StagedZ(ready=self.Zcur[self.pos, :self.d].clone(),
+                           where={"kind": "columns", "c0": self.col0, "c1": self.col1})
         n_rows = self.part.n_local if by_rows else self.V
         with self._stage_cv:
             if self._stage_free is None:

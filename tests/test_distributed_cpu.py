@@ -90,6 +90,35 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         counts = [None] * world
         dist.all_gather_object(counts, (emb.sweep_counts, eng.estimated_sweep_seconds()))
         assert all(c == counts[0] for c in counts)      # same decisions, and the estimate behind the lagged check agrees
+
+        # --save_history on several ranks: every rank stages only the part of Z it holds, the writer
+        # threads hand the parts over through a directory, rank 0's sink gets whole matrices in order -- the same
+        # ones a single process keeps in history["Z"]
+        g3 = Graph(root)
+        g3._attach_engine(SweepEngine(g3.csr, g3.X, "cpu", OracleKernels(), process_group=dist.group.WORLD,
+                                      chunks=chunks, seed=3, exchange=exchange))
+        got = []
+        emb3 = Embedder(g3, CosineSimilarity(), torch.device("cpu"), gamma=gamma, tolerence=3, verbose=False,
+                        save_history=True, history_sink=lambda o, s, Z: got.append((o, s, Z)),
+                        history_parts_dir=Path(out_dir) / "parts")
+        emb3.iterate()
+        Z3 = g3.Z                                                       # collective: every rank takes part
+        if rank == 0:
+            g4 = Graph(root)
+            g4._attach_engine(SweepEngine(g4.csr, g4.X, "cpu", OracleKernels()))
+            solo = Embedder(g4, CosineSimilarity(), torch.device("cpu"), gamma=gamma, tolerence=3, verbose=False,
+                            save_history=True)
+            solo.iterate()
+            want = [(o, s_, Z) for o, zs in enumerate(solo.history["Z"]) for s_, Z in enumerate(zs)]
+            assert [(o, s_) for o, s_, _ in got][:8] == [(o, s_) for o, s_, _ in want][:8] and len(got) > 8
+            for (_, _, Za), (_, _, Zb) in zip(got[:8], want[:8]):       # far from the fixed point: sweep for sweep
+                assert O.rel_l2(Za, Zb) < 1e-6
+            assert O.rel_l2(got[-1][2], Z3) < 1e-7                    # the last matrix handed over IS the result
+        else:
+            assert got == []                                            # only rank 0's sink sees matrices
+        dist.barrier()
+        if rank == 0:
+            assert list((Path(out_dir) / "parts").iterdir()) == []      # every part was consumed
         (Path(out_dir) / f"ok{rank}").write_text("ok")
         dist.barrier()              # leave together: a rank tearing gloo down while others still talk can abort
     finally:
