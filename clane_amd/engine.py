@@ -219,9 +219,19 @@ class SweepEngine:
             chunks = 1 if row_world == 1 else 4
         self.hot_rows_first = bool(hot_rows_first)
         self.halo = row_world > 1 and exchange in ("halo", "halo_p2p")
-        rows_per_wave = 64 // lanes_per_row(self.d, X.dtype) if self.d > 0 else 1
+        # Everything that decides the LAYOUT (which rows are class rows, hence the order of every row's edges) follows
+        # from `d_plan`: the rank's own width -- except in a column split, where it is the widest slice (rank 0's) on
+        # EVERY rank, one without columns included: build_P all-reduces the partial dot products element by element, so
+        # all ranks must hold their edges in one order, even when their slices straddle a lane-layout boundary (33 packs
+        # over two ranks: 32 and 16 lanes per row, class thresholds 64 and 256).
+        d_plan = self.d
+        if self.columns:
+            c0, c1 = column_slice(self.d_full, X.dtype, self.world, 0)
+            d_plan = c1 - c0
+        ld_plan = _round_up(d_plan, _hip.VEC_ELEMS[X.dtype])
+        rows_per_wave = 64 // lanes_per_row(d_plan, X.dtype) if d_plan > 0 else 1
         # how much of the gather traffic XCD affinity could serve from the L2s at all (same number on every rank)
-        self.hot_read_share = hot_read_share(csr, self.ld * X.element_size()) if self.d > 0 else 1.0
+        self.hot_read_share = hot_read_share(csr, ld_plan * X.element_size()) if d_plan > 0 else 1.0
         self.class_affinity = True
         if class_threshold is None:         # XCD-affine long rows, whatever the division
             class_threshold = CLASS_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
@@ -242,7 +252,7 @@ class SweepEngine:
             raise ValueError("class_chunk must be a multiple of 64 in [64, 4096]")
         # a row one of whose (phase, class) segments alone is more than one XCD's L2 holds: its chunks are scheduled by
         # column, next to the other such rows' (xcd.class_items)
-        self.mega_segment_edges = int(L2_BYTES_ALL_XCDS // 8 // max(self.ld * X.element_size(), 1)) if self.d > 0 else 0
+        self.mega_segment_edges = int(L2_BYTES_ALL_XCDS // 8 // max(ld_plan * X.element_size(), 1)) if d_plan > 0 else 0
         self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
         if self.p2p and self.world > 8:
             raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")

@@ -186,3 +186,51 @@ def test_one_rank_group_with_forced_collectives(tmp_path, exchange):
         assert plain.exchange == "none" and not plain.columns           # without the flag: the one-GPU plan
     finally:
         dist.destroy_process_group()
+
+
+def _uneven_columns_worker(rank: int, world: int, port: int, out_dir: str):
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(0)
+        V, d = 500, 132                                  # 33 packs of 4 floats: 17 + 16 over two ranks
+        deg = rng.integers(0, 12, size=V)
+        deg[[3, 77, 200, 333]] = [100, 150, 200, 70]     # between the class thresholds of the two widths (64 / 256)
+        rowptr = np.zeros(V + 1, dtype=np.int64)
+        np.cumsum(deg, out=rowptr[1:])
+        colidx = np.concatenate([np.sort(rng.choice(V, size=k, replace=False)) for k in deg]).astype(np.int32)
+        from clane_amd.engine import SweepEngine, column_slice, lanes_per_row
+        from clane_amd.partition import HostCSR
+        from oracle import clane_oracle as O
+        from tests.oracle_kernels import OracleKernels
+        csr = HostCSR(V, rowptr, colidx)
+        X = torch.from_numpy(rng.standard_normal((V, d)).astype(np.float32))
+        widths = [column_slice(d, X.dtype, world, r) for r in range(world)]
+        assert [lanes_per_row(c1 - c0, X.dtype) for c0, c1 in widths] == [32, 16]     # the ranks' kernels differ ...
+        eng = SweepEngine(csr, X, "cpu", OracleKernels(), process_group=dist.group.WORLD, exchange="columns")
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (eng.class_threshold, eng.class_phases, eng.phase_threshold, eng.class_affinity,
+                                          eng.local.colidx.tobytes()))
+        assert all(e == everyone[0] for e in everyone)   # ... their edge order must not: build_P all-reduces P element-wise
+        eng.build_P()
+        P_or = O.build_P_values(rowptr, colidx, X)
+        assert O.rel_l2(eng.P_global(), P_or) < 3e-6
+        Z = X.clone()
+        for _ in range(3):
+            delta = eng.sweep(0.76)
+            Z, d_or = O.sweep(rowptr, colidx, P_or, X, Z, 0.76)
+            assert abs(delta - float(d_or)) <= 1e-5 * max(1.0, float(d_or))
+        assert O.rel_l2(eng.get_Z(), Z) < 1e-6
+        (Path(out_dir) / f"ok{rank}").write_text("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_ranks_of_different_width_share_one_edge_order(tmp_path):
+    """A column split whose slices straddle a lane-layout boundary (33 packs over 2 ranks: 32 and 16 lanes per row): the
+    row-binning thresholds follow the row width, but the class-sorted edge order must be the same on every rank --
+    build_P all-reduces the partial dot products element by element."""
+    mp.spawn(_uneven_columns_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
