@@ -259,6 +259,8 @@ class _PartsAssembler:
     def __init__(self, parts_dir: Path, rank: int, world: int, shape, dtype: torch.dtype):
         self.dir, self.rank, self.world, self.shape, self.dtype = Path(parts_dir), rank, world, tuple(shape), dtype
         self.dir.mkdir(parents=True, exist_ok=True)
+        for stale in list(self.dir.glob(f"*.r{rank}.pt")) + list(self.dir.glob(f"*.r{rank}.tmp")):
+            stale.unlink()                      # an interrupted run's parts: every rank clears its own, before it writes any
 
     def _path(self, outer: int, sweep: int, rank: int) -> Path:
         return self.dir / f"o{outer}_s{sweep}.r{rank}.pt"
