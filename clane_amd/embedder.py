@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import collections
 import math
+import os
 import time
 import queue
 import threading
@@ -157,7 +158,10 @@ class Embedder(object):
         """This sweep's embeddings on their way to the host."""
         pieces = world > 1 and self._writer is not None and self._parts_dir is not None
         if pieces and self._writer.assembler is None:
-            self._writer.assembler = _PartsAssembler(self._parts_dir, engine.comm.rank, world,
+            # a directory of this run's own (rank 0 names it, every rank learns the name: a collective, on this -- the
+            # sweep's -- thread, where all ranks are in step): parts an interrupted run left behind cannot be mistaken
+            run = engine.comm.all_gather_object(f"run-{os.getpid()}-{time.time_ns()}")[0]
+            self._writer.assembler = _PartsAssembler(self._parts_dir / run, engine.comm.rank, world,
                                                      (engine.V, engine.d_full), engine.dtype)
         return engine.stage_Z(pieces=True) if pieces else engine.stage_Z()
 
@@ -259,8 +263,6 @@ class _PartsAssembler:
     def __init__(self, parts_dir: Path, rank: int, world: int, shape, dtype: torch.dtype):
         self.dir, self.rank, self.world, self.shape, self.dtype = Path(parts_dir), rank, world, tuple(shape), dtype
         self.dir.mkdir(parents=True, exist_ok=True)
-        for stale in list(self.dir.glob(f"*.r{rank}.pt")) + list(self.dir.glob(f"*.r{rank}.tmp")):
-            stale.unlink()                      # an interrupted run's parts: every rank clears its own, before it writes any
 
     def _path(self, outer: int, sweep: int, rank: int) -> Path:
         return self.dir / f"o{outer}_s{sweep}.r{rank}.pt"
