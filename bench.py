@@ -593,6 +593,10 @@ def roofline_block(args, world, m) -> dict:
 
 def main():
     args = make_parser().parse_args()
+    unknown = [x for x in args.also_exchange.split(",") if x not in ("", "none", "columns", "halo", "halo_p2p", "allgather",
+                                                                     "allgather_all")]
+    if unknown:
+        raise SystemExit(f"--also-exchange: unknown division(s) {unknown}")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher: be the launcher
         raise SystemExit(launch_ranks(args.gpus))
     if os.environ.get("CLANE_BENCH_WATCHDOG_S"):                # debugging aid: every rank dumps its stack every S seconds
