@@ -24,7 +24,7 @@ from .similarity import CosineSimilarity, Similarity
 
 
 class Embedder(object):
-    LAGGED_BELOW_S = 1e-3
+    LAGGED_BELOW_S = 1e-3             # one GPU: the host check lags one sweep when a sweep is ESTIMATED below this
     # Several ranks decide by the engine's ESTIMATE of a sweep (gather-model bytes at the HBM peak), which measured
     # sweeps undercut by cache hits (config 3: 0.65-0.85 of it at N = 1..8): 2 ms of estimate is ~1.3-1.7 ms of sweep,
     # where the host round trip plus the scalar all-reduce (~50 us) is 3 % or more.
@@ -78,9 +78,9 @@ class Embedder(object):
         # GPU never waits for the host.  The stopping rule is unchanged: when it says stop, the sweep launched ahead
         # is discarded (the ping-pong partner still holds the right embeddings) -- counts, deltas and embeddings are
         # bit-identical either way.  It costs one discarded sweep per propagate and saves the host round trip of
-        # every sweep, so it pays when sweeps are short.  None (default): on one GPU, switched on inside a propagate
-        # once a sweep has taken less than LAGGED_BELOW_S; on several GPUs, on when the engine's estimate of a sweep
-        # (the same number on every rank) is below LAGGED_BELOW_ESTIMATE_S; True / False: always / never.  Off with save_history.
+        # every sweep, so it pays when sweeps are short.  None (default): on when the engine's estimate of a sweep (the
+        # same number on every rank and in every run) is below LAGGED_BELOW_S on one GPU, LAGGED_BELOW_ESTIMATE_S on
+        # several; True / False: always / never.  Off with save_history.
         self.lagged_check = lagged_check
         self.sweeps_launched = 0
         self._round_was_idle = False
@@ -186,12 +186,13 @@ class Embedder(object):
         can_lag = not self.save_history
         ahead = bool(self.lagged_check) and can_lag
         world = engine.world
-        auto = self.lagged_check is None and can_lag and world == 1
-        if self.lagged_check is None and can_lag and world > 1:
-            # several ranks must decide alike, so not by a stopwatch: by the same estimate on every rank.  Lagging also
-            # hides the latency of the per-sweep scalar all-reduce.
-            ahead = engine.estimated_sweep_seconds() < self.LAGGED_BELOW_ESTIMATE_S
-        fastest = math.inf                          # shortest synchronous sweep seen in this propagate (auto mode)
+        if self.lagged_check is None and can_lag:
+            # decided by the engine's estimate of a sweep, not by a stopwatch: several ranks must decide alike (the
+            # estimate is the same number on every rank), and on one GPU the number of launches of a run is then the
+            # same from run to run (round 2 switched by measured sweep times).  Lagging also hides the latency of the
+            # per-sweep scalar all-reduce, hence the higher limit on several GPUs.
+            limit = self.LAGGED_BELOW_ESTIMATE_S if world > 1 else self.LAGGED_BELOW_S
+            ahead = engine.estimated_sweep_seconds() < limit
         ticket = None                               # the launched sweep whose delta has not been read yet
         if ahead and not idle:
             ticket = engine.sweep_launch(self.gamma)
@@ -204,9 +205,7 @@ class Embedder(object):
                 amount_updated = engine.sweep_wait(ticket)
                 ticket = following
             else:
-                t_sweep = time.perf_counter()
                 amount_updated = engine.sweep(self.gamma)
-                fastest = min(fastest, time.perf_counter() - t_sweep)
                 self.sweeps_launched += 1
             n_sweeps += 1
             if self.save_history:
@@ -238,10 +237,6 @@ class Embedder(object):
                     ticket = None
                 else:
                     self.sweeps_launched += 1
-            elif auto and not ahead and not stop and not idle and n_sweeps >= 2 and fastest < self.LAGGED_BELOW_S:
-                ahead = True                        # short sweeps: from here on launch one ahead
-                ticket = engine.sweep_launch(self.gamma)
-                self.sweeps_launched += 1
             if self.verbose:        # the reference prints the 0-d tensor itself (embedder.py:104): "tensor(25.7074) 10"
                 shown = torch.tensor(amount_updated, dtype=self._delta_dtype)
                 print(shown, self.tolerences['propagation'].value)
