@@ -233,13 +233,14 @@ def make_parser():
                          "plan: rows divided, one in-place RCCL all-gather of the updated rows per sweep; allgather = "
                          "the same for the live rows only; halo / halo_p2p = rows sent only to the ranks that read "
                          "them (clane_amd/halo.py, partition.py; DESIGN.md section 6)")
-    ap.add_argument("--also-exchange", default="allgather_all,allgather,halo",
+    ap.add_argument("--also-exchange", default="allgather_all,allgather",
                     help="N > 1: after the main division's timed blocks, rebuild the engine with each of these divisions "
                          "(comma-separated) and report its sweeps/s, parity and collective time in the same record: "
                          "allgather_all = north_star's row partition + one all-gather of the owned rows per sweep -> "
                          "`north_star_literal`; the others (allgather = the same for the rows that change and are read; "
-                         "halo) -> `other_divisions`.  The main division is skipped; none = off.  One run of the "
-                         "driver's on 8 GPUs then compares every division on real links.")
+                         "halo, halo_p2p) -> `other_divisions`.  The main division is skipped; none = off.  The default "
+                         "adds the two in-place all-gather forms; `halo` (all_to_all_single with uneven splits) is left to "
+                         "an explicit request: nothing measured after the main division may put its record at risk.")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 flow)")
     ap.add_argument("--rehearse-rccl", action="store_true",

@@ -623,7 +623,8 @@ def test_bench_four_ranks_share_one_gpu_with_an_idle_column_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     run = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--backend", "gloo", "--share-gpu",
                           "--workload", "tiny12", "--exchange", "columns", "--steps", "3", "--warmup", "1", "--blocks",
-                          "3"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                          "3", "--also-exchange", "allgather_all,allgather,halo"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert run.returncode == 0, run.stderr[-3000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
