@@ -177,6 +177,30 @@ def main():
                edge_dst=np.array([e[1] for e in edges7]))
     np.savez_compressed(OUT / "g7_readme5.npz", **res)
 
+    # ---- G11: a 320-vertex graph with what the karate-sized fixtures lack -- a hub row of 300 edges (above the
+    # class threshold of narrow rows: the XCD-affine pass of the GPU path gets a fixture made by the real reference),
+    # one of 100, self-loops, duplicate edge lines, string ids in shuffled order, sinks; d = 8, gamma = 0.9
+    rng11 = np.random.default_rng(11)
+    V11 = 320
+    vids11 = [f"n{int(i):03d}" for i in rng11.permutation(V11)]
+    edges11 = []
+    for v in range(V11):
+        if v in (5, 77, 150, 319):                       # sinks
+            continue
+        k = 300 if v == 17 else 100 if v == 200 else int(rng11.integers(1, 7))
+        for u in rng11.choice(V11, size=k, replace=False):
+            edges11.append((vids11[v], vids11[int(u)]))
+    edges11 += [(vids11[3], vids11[3]), (vids11[17], vids11[17]), edges11[0], edges11[10], edges11[10]]   # self-loops, duplicates
+    order11 = rng11.permutation(len(edges11))
+    edges11 = [edges11[int(i)] for i in order11]         # arbitrary line order in the E file
+    X11 = torch.normal(0, 1, [V11, 8], generator=torch.Generator().manual_seed(11)).numpy()
+    root = tmp / "g11"
+    _write_root(root, vids11, edges11, X11)
+    res = _run_embedder(G, S, E, root, 0.9)
+    res.update(vertex_ids=np.array(vids11), edge_src=np.array([e[0] for e in edges11]),
+               edge_dst=np.array([e[1] for e in edges11]))
+    np.savez_compressed(OUT / "g11_hubs320_d8_g0.9.npz", **res)
+
     # ---- G8: Cora-shaped synthetic (2708 / 5429 / d=1433 binary BoW); literal loop is
     # 16 s/sweep so: build_P + ONE literal sweep through the reference's own propagate body.
     rng = np.random.default_rng(0)
