@@ -201,6 +201,26 @@ def main():
                edge_dst=np.array([e[1] for e in edges11]))
     np.savez_compressed(OUT / "g11_hubs320_d8_g0.9.npz", **res)
 
+    # ---- G12: wide rows (d = 256: one 1-KiB row per wave instruction on the GPU, class threshold 64) with hub rows of
+    # 120 and 70 edges and a cycle-rich background, gamma = 0.76
+    rng12 = np.random.default_rng(12)
+    V12 = 150
+    vids12 = [str(1000 + i) for i in range(V12)]
+    edges12 = []
+    for v in range(V12):
+        if v % 37 == 0:                                  # sinks
+            continue
+        k = 120 if v == 9 else 70 if v == 101 else int(rng12.integers(1, 9))
+        for u in rng12.choice(V12, size=k, replace=False):
+            edges12.append((vids12[v], vids12[int(u)]))
+    X12 = torch.normal(0, 1, [V12, 256], generator=torch.Generator().manual_seed(12)).numpy()
+    root = tmp / "g12"
+    _write_root(root, vids12, edges12, X12)
+    res = _run_embedder(G, S, E, root, 0.76)
+    res.update(vertex_ids=np.array(vids12), edge_src=np.array([e[0] for e in edges12]),
+               edge_dst=np.array([e[1] for e in edges12]))
+    np.savez_compressed(OUT / "g12_hubs150_d256_g0.76.npz", **res)
+
     # ---- G8: Cora-shaped synthetic (2708 / 5429 / d=1433 binary BoW); literal loop is
     # 16 s/sweep so: build_P + ONE literal sweep through the reference's own propagate body.
     rng = np.random.default_rng(0)

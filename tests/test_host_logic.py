@@ -23,7 +23,7 @@ from .oracle_kernels import OracleKernels
 
 KARATE_LIKE = ["g4_karate_d2.npz", "g4_karate_d16.npz", "g5_symkarate_d16_g0.5.npz",
                "g5_symkarate_d16_g0.76.npz", "g5_symkarate_d2_g0.76.npz", "g7_readme5.npz", "g6_tiny_f64.npz",
-               "g11_hubs320_d8_g0.9.npz"]
+               "g11_hubs320_d8_g0.9.npz", "g12_hubs150_d256_g0.76.npz"]
 
 
 def graph_from_golden(tmp_path, name):
