@@ -18,9 +18,11 @@ line; started under torchrun (WORLD_SIZE set) it is one of the ranks.  The graph
 scaling is STRONG: by default every GPU sweeps d/N columns of all rows (no exchange per sweep, DESIGN.md 6.1);
 `--exchange allgather_all` is north_star's literal plan (rows divided, one in-place RCCL all-gather of the
 updated rows per sweep), `halo` / `halo_p2p` / `allgather` are the leaner row splits.  At N > 1 the record also
-carries a `comm` block (what RCCL saw, time inside the collectives) and -- `--also-exchange`, default
-allgather_all -- the same measurement of north_star's literal division in `north_star_literal`, so ONE record
-answers both "what scales" and "what north_star asked for".  Rank 0 prints one JSON line.
+carries a `comm` block (what RCCL saw, time inside the collectives, the delta-stream variant timed beside the default)
+and -- `--also-exchange`, default allgather_all,allgather -- the same measurement of north_star's literal division
+in `north_star_literal` and of the live-rows all-gather in `other_divisions`, so ONE record answers both "what
+scales" and "what north_star asked for".  `--rehearse-rccl` runs that whole N > 1 flow through the real RCCL
+library with the one rank a one-GPU box can give it.  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
