@@ -20,10 +20,16 @@ ap.add_argument("--scale", type=float, default=1.0, help="1.0: 2M vertices (the 
 ap.add_argument("--steps", type=int, default=15)
 ap.add_argument("--out", default=None)
 ap.add_argument("--no-oracle", action="store_true")
+ap.add_argument("--mild-rmat", action="store_true", help="instead: R-MAT graphs of decreasing skew (where the read-skew rule flips)")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
 V = int(2_000_000 * args.scale)
-GRAPHS = {
+MILD = {     # R-MAT with less and less skew than the tuning set's (0.57, 0.19, 0.19, 0.05): where does affinity stop paying?
+    f"R-MAT {abcd} (40M edges)": (lambda abcd=abcd: synth.rmat_csr(V, int(40_000_000 * args.scale), seed=21, abcd=abcd,
+                                                                  device=str(dev)))
+    for abcd in ((0.50, 0.20, 0.20, 0.10), (0.45, 0.22, 0.22, 0.11), (0.40, 0.23, 0.23, 0.14), (0.33, 0.25, 0.25, 0.17))
+}
+GRAPHS = MILD if args.mild_rmat else {
     "near-regular (rows of 48..80 edges)": lambda: synth.regular_csr(V, 48, 80, device=str(dev)),
     "uniform random (40M pairs, Poisson degrees)": lambda: synth.uniform_random_csr(V, int(40_000_000 * args.scale), device=str(dev)),
     "star-heavy (10 rows that read every vertex)": lambda: synth.star_csr(V, 10, V, device=str(dev)),
