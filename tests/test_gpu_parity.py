@@ -608,6 +608,7 @@ def test_powerlaw_generator_and_bf16_sweep(dev):
 
 @pytest.mark.parametrize("exchange,world,fused,d", [
     ("columns", 4, True, 256), ("columns", 3, True, 256), ("columns", 4, True, 6), ("columns", 2, True, 100),
+    ("columns", 2, True, 132),        # 33 packs: slices of 32 and 16 lanes per row, ONE class-sorted edge order (r03 fix)
     ("halo", 4, True, 256), ("halo", 3, True, 256), ("halo", 4, False, 256), ("allgather", 4, True, 256),
     ("halo_p2p", 4, True, 256), ("halo_p2p", 3, True, 100)])
 def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, fused, d):
