@@ -953,6 +953,7 @@ class SweepEngine:
                 "class_phases": self.class_phases, "phase_threshold": self.phase_threshold,
                 "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
                 "class_affinity": self.class_affinity, "mega_segment_edges": self.mega_segment_edges,
+                "class_items_per_block": [c[6] for c in self.class_rows if c is not None][:1],
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
 
     def exchange_bytes_per_sweep(self) -> int:

@@ -64,7 +64,10 @@ CLASS_CHUNK = 256
 PHASES_BY_ROWS_PER_WAVE = {1: 4, 2: 2, 4: 1, 8: 1}
 PHASE_THRESHOLD = 512
 CLASS_ITEMS_PIECE_EDGES = 1 << 28
-CLASS_ITEMS_PER_BLOCK = 32              # 16 / 32 / 64 measured alike (profiles/r02_class_threshold_sweep.md)
+# Chunks per workgroup, at most.  Round 2 found 16 / 32 / 64 alike on config 3 and took 32; measured again in round 3
+# across shapes (profiles/r03_items_per_block.md): 16 is within 1 % of the best everywhere and ahead of 32 where a
+# launch holds fewer chunks -- config 2 (108 k chunks) 0.141 -> 0.107 ms for the class pass, config 3 2.355 -> 2.29 ms.
+CLASS_ITEMS_PER_BLOCK = 16
 
 
 
