@@ -39,7 +39,8 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         gold = load_golden(name)
         k = load_golden("g2_karate_csr.npz")
         src, dst = (gold["edge_src"], gold["edge_dst"]) if "edge_src" in gold.files else (k["edge_src"], k["edge_dst"])
-        root = write_data_root(Path(out_dir) / f"r{rank}", k["vertex_ids"], src, dst, gold["X"])
+        vids = gold["vertex_ids"] if "vertex_ids" in gold.files else k["vertex_ids"]
+        root = write_data_root(Path(out_dir) / f"r{rank}", vids, src, dst, gold["X"])
         g = Graph(root)
         eng = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), process_group=dist.group.WORLD, chunks=chunks, seed=3,
                           exchange=exchange)
@@ -57,7 +58,10 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
             dist.all_gather_object(widths, eng.d)
             assert sum(widths) == g.X.shape[1]                                # every column exactly once
         else:
-            assert 0 < eng.exchange_bytes_per_sweep() <= full + 4 * eng.ld * 4 * world
+            assert 0 <= eng.exchange_bytes_per_sweep() <= full + 4 * eng.ld * 4 * world
+            received = [None] * world       # a rank may read nothing remote (few rows, all of them sinks): not all may
+            dist.all_gather_object(received, eng.exchange_bytes_per_sweep())
+            assert sum(received) > 0 and (world > 4 or received[rank] > 0)
 
         # build_P: every rank assembles the full P in the reference's (row, col) order
         P = g.build_P(CosineSimilarity())
@@ -144,12 +148,24 @@ def test_three_rank_gloo(tmp_path, exchange):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
-def test_eight_rank_gloo_columns_with_idle_ranks(tmp_path):
-    """The driver's largest case, rehearsed on CPU: 8 ranks, column split of a d=16 matrix (4 packs: ranks 4-7 hold
-    no column and only join the collectives) -- same collective sequence on every rank, same result."""
+@pytest.mark.parametrize("exchange,name,chunks", [
+    ("columns", "g5_symkarate_d16_g0.76.npz", 1),          # 4 packs of d=16: ranks 4-7 hold no column
+    ("allgather_all", "g4_karate_d2.npz", 1),              # north_star's plan: 34 rows over 8 ranks, padded spans
+    ("allgather_all", "g5_symkarate_d16_g0.76.npz", 4),    # 5 rows per rank in 4 chunks: 2-row and 1-row chunks
+    ("allgather", "g4_karate_d2.npz", 2),                  # live / quiet split: karate has 9 sinks + never-read rows
+    ("allgather", "g5_symkarate_d16_g0.76.npz", 4),
+    ("halo", "g4_karate_d2.npz", 1),
+    ("halo", "g5_symkarate_d16_g0.76.npz", 2),
+    ("halo", "g11_hubs320_d8_g0.9.npz", 4),                # 320 rows, hubs: 40 rows per rank, 10 per chunk
+    ("allgather_all", "g11_hubs320_d8_g0.9.npz", 4),
+])
+def test_eight_rank_gloo_every_division(tmp_path, exchange, name, chunks):
+    """The driver's largest case, rehearsed on CPU with the world size it runs: 8 ranks in every division that
+    `bench.py --gpus 8` executes (columns, then allgather_all = north_star's literal plan, then allgather / halo), on
+    graphs with fewer rows than 8 x chunk x a comfortable chunk size -- uneven deals, padded in-place all-gather spans,
+    ranks whose chunks hold one row or none.  Same collective sequence on every rank, same result as the reference."""
     world = 8
-    mp.spawn(_worker, args=(world, _free_port(), 1, "g5_symkarate_d16_g0.76.npz", str(tmp_path), "columns"),
-             nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), chunks, name, str(tmp_path), exchange), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 

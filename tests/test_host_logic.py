@@ -150,7 +150,8 @@ def test_similarity_plugin_surface():
 
 
 # ---- partition ------------------------------------------------------------------------------
-@pytest.mark.parametrize("V,W,C", [(34, 1, 1), (34, 1, 3), (34, 2, 1), (34, 2, 3), (5, 4, 2), (1000, 8, 4)])
+@pytest.mark.parametrize("V,W,C", [(34, 1, 1), (34, 1, 3), (34, 2, 1), (34, 2, 3), (5, 4, 2), (1000, 8, 4),
+                                   (34, 8, 1), (34, 8, 2), (34, 8, 4), (320, 8, 4), (7, 8, 2)])
 @pytest.mark.parametrize("with_mask", [False, True])
 def test_partition_is_a_bijection_with_in_place_allgather_spans(V, W, C, with_mask):
     live = (np.random.default_rng(V + W + C).random(V) < 0.4) if with_mask else None
