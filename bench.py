@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: embedding-update sweeps/sec + achieved HBM GB/s of the K3 SpMM kernel.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--workload rmat2m|rmat200k|powerlaw10m|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--workload rmat2m|uniform2m|rmat200k|powerlaw10m|tiny]
 
 One "step" = one Jacobi sweep  Z <- X + gamma * P Z  over the whole graph, P frozen: the K3
 kernels, the deterministic L1-delta reduction, the host read-back of that scalar (the
@@ -49,11 +49,16 @@ WORKLOADS = {
     "rmat2m": ("rmat", 2_000_000, 40_000_000, 256, "f32", 3, 4),      # BASELINE config 3 (headline metric)
     "rmat200k": ("rmat", 200_000, 4_000_000, 128, "f32", 1, 2),       # BASELINE config 2
     "powerlaw10m": ("powerlaw", 10_000_000, 200_000_000, 128, "bf16", 5, 6),   # BASELINE config 4 (shape)
+    # The roofline's ANCHOR: uniform-random (src, dst) pairs, no hubs, no skew -- nothing for the L2s or the Infinity Cache
+    # to reuse (the 2 GB table is 8x the cache), so the PMC traffic equals the algorithmic bytes and `frac` is a true HBM
+    # fraction with no cache caveat.  Same |V|, |E|, d as the headline.
+    "uniform2m": ("uniform", 2_000_000, 40_000_000, 256, "f32", 12, 4),
     "tiny": ("rmat", 20_000, 200_000, 64, "f32", 7, 8),
     "tiny12": ("rmat", 20_000, 200_000, 12, "f32", 7, 8),             # 3 packs a row: more ranks than packs leaves idle column ranks
     # 8x config 3: a 16 GiB embedding matrix (byte offsets beyond 32 bits, ~85 GB of HBM in use) -- capacity check
     "rmat16m": ("rmat", 16_000_000, 320_000_000, 256, "f32", 9, 10),
 }
+GENERATOR_NAMES = {"rmat": "R-MAT", "powerlaw": "power-law", "uniform": "uniform-random pairs (duplicates merged)"}
 DTYPES = {"f32": torch.float32, "bf16": torch.bfloat16, "f64": torch.float64}
 PARITY_TOL = {"f32": 1e-4, "f64": 1e-10, "bf16": 8e-3}       # bf16: 2^-8 rounding of every stored value
 PARITY_P_TOL = {"f32": 2e-6, "f64": 1e-12, "bf16": 1e-4}     # P itself (fp32 arithmetic on the stored values)
@@ -322,8 +327,9 @@ def generate_input(args, ranks: Ranks):
     world, rank, dev = ranks.world, ranks.rank, ranks.dev
     if os.environ.get("CLANE_BENCH_PERTURB_RANK") == str(rank) and world > 1:
         gseed += 1000           # test hook: this rank draws a different graph, the agreement check must repair it
-    make = (lambda: synth.rmat_csr(V, E, seed=gseed, device=str(dev))) if gen == "rmat" else \
-           (lambda: synth.powerlaw_csr(V, E, seed=gseed, device=str(dev)))
+    make = {"rmat": lambda: synth.rmat_csr(V, E, seed=gseed, device=str(dev)),
+            "powerlaw": lambda: synth.powerlaw_csr(V, E, seed=gseed, device=str(dev)),
+            "uniform": lambda: synth.uniform_random_csr(V, E, seed=gseed, device=str(dev))}[gen]
     if world > 1 and args.share_gpu:
         # Rehearsal with every rank on ONE card: the generator's rocPRIM sort / unique kernels (decoupled look-back:
         # workgroups spin on their predecessors) crawl when several processes run them on a time-sliced GPU -- four
@@ -398,8 +404,7 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
 
     out = {"eng": eng, "build_P_ms": build_p_ms, "calibration_bytes": None, "Z1": None}
     if args.calibrate:      # known-size streaming read in this library's own 16 B/lane access pattern
-        eng.snapshot()
-        eng.distance_from_snapshot()
+        eng.l1_between(0, 1)
         out["calibration_bytes"] = 2 * eng.part.n_local * eng.ld * eng.Zcur.element_size()    # l1_distance reads two matrices
     if not args.no_parity:              # the sweep the oracle is checked against (Z = X before it); collective
         eng.sweep(args.gamma)
@@ -670,7 +675,7 @@ def main():
         "timing": f"{args.warmup} warm-up sweeps, then {max(1, args.blocks)} blocks of exactly {args.steps} sweeps, each "
                   f"bracketed by barrier + torch.cuda.synchronize() (host clock, max over ranks) and by a HIP event pair on "
                   f"the sweep's stream (ms_per_step_hip_events); value / ms_per_step = the median block",
-        "config": {"workload": f"{'R-MAT' if gen == 'rmat' else 'power-law'} |V|={V} |E|={E} d={d} {dname}, "
+        "config": {"workload": f"{GENERATOR_NAMES[gen]} |V|={V} |E|={E} d={d} {dname}, "
                                f"gamma={args.gamma}, CosineSimilarity "
                                f"(reference mode), seeds {gseed}/{xseed}",
                    "parallelism": describe_parallelism(args, world, eng, X, E),

@@ -136,10 +136,10 @@ __device__ __forceinline__ int lane_xor(int v) {
     else if constexpr (M == 8) return dpp_mov<0x128>(v);                 // row_ror:8
     else if constexpr (M == 16) {   // {rows 0 and 2 of a with rows 0 and 2 of b, ...}: r[0] = (a0, b0, a2, b2), r[1] = (a1, b1, a3, b3)
         const auto r = __builtin_amdgcn_permlane16_swap(unsigned(v), unsigned(v), false, false);
-        return int((threadIdx.x & 16) ? r[0] : r[1]);
+        return int((lane_id() & 16) ? r[0] : r[1]);
     } else {
         const auto r = __builtin_amdgcn_permlane32_swap(unsigned(v), unsigned(v), false, false);
-        return int((threadIdx.x & 32) ? r[0] : r[1]);
+        return int((lane_id() & 32) ? r[0] : r[1]);
     }
 #else
     return __shfl_xor(v, M, kWave);

@@ -167,13 +167,17 @@ struct Mirror {
     }
 };
 
-// Epilogue of one row's column tile; returns this lane's share of sum|z_new - z_old|.
+// Epilogue of one row's column tile; returns this lane's share of sum|z_new - z_old| and adds its share of
+// |z_new|^2 (of the STORED values) to `qsum` -- in exactly the order row_sqnorm_kernel (K0, build_p.h) walks a row:
+// lane l takes the packs l, l + LPR, ... and one fma per element.  Every K3 kernel folds `qsum` over the row's lanes
+// with the same butterfly as K0 and stores it to sq_out[row], so the next build_P starts from a norm that is bit for
+// bit K0's without reading Z again (similarity.py:37's norms, one outer round later).
 template <typename T, int VEC>
 __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC> &x, const Pack<T, VEC> &zo,
                                                                const typename Elem<T>::acc_t (&acc)[VEC],
                                                                typename Elem<T>::acc_t gamma, bool has_edges,
                                                                T *__restrict__ dst, const Mirror<T> &mirror,
-                                                               int64_t row, int col) {
+                                                               int64_t row, int col, typename Elem<T>::acc_t &qsum) {
     using A = typename Elem<T>::acc_t;
     Pack<T, VEC> out;
     A rsum = A(0);
@@ -182,7 +186,9 @@ __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC
         const A zold = Elem<T>::to_acc(zo.v[k]);
         const A znew = has_edges ? Elem<T>::to_acc(x.v[k]) + gamma * acc[k] : zold;  // embedder.py:88-92
         out.v[k] = Elem<T>::from_acc(znew);
-        rsum += fabs(Elem<T>::to_acc(out.v[k]) - zold);
+        const A stored = Elem<T>::to_acc(out.v[k]);
+        rsum += fabs(stored - zold);
+        qsum = fma(stored, stored, qsum);
     }
     store_pack_stream<T, VEC>(dst, out);
     if (mirror.row_ptr != nullptr) {
@@ -203,7 +209,8 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, Mirror<T> mirror, typename Elem<T>::acc_t *__restrict__ sq_out,
+    double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
     __shared__ double s_rowsum[kMaxRowsPerBlock];
@@ -257,7 +264,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
         }
         if (!(long_threshold > 0 && e1 - e0 > long_threshold) && !(skip_sinks && e1 == e0)) {
             const int64_t r = row_begin + cur;
-            A rsum = A(0);
+            A rsum = A(0), qsum = A(0);
             for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
                 const int c0 = t0 + sl * VEC;
                 const bool col_ok = c0 < d;
@@ -272,10 +279,14 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
                 for (int k = 0; k < VEC; ++k) acc[k] = A(0);
                 gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
                 fold_subwaves<LPR>(acc);
-                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, mirror, r, c0);
+                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, mirror, r, c0, qsum);
             }
             rsum = group_sum<kWave>(rsum);
             if (lane == 0) s_rowsum[cur] = double(rsum);
+            if (sq_out != nullptr) {             // kernel argument: uniform
+                qsum = group_sum<LPR>(qsum);     // the writers are the lanes of sub-wave 0
+                if (lane == 0) sq_out[r] = qsum;
+            }
         }
         cur = nxt;
         e0 = n0;
@@ -319,7 +330,8 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, Mirror<T> mirror, typename Elem<T>::acc_t *__restrict__ sq_out,
+    double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     static_assert(LPR < kWave, "use spmm_update_kernel for rows that fill a wave");
     static_assert(LPR % U == 0, "a sub-wave's edge buffer is consumed in whole groups of U");
@@ -365,10 +377,14 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
             if (e_next == e_end) {           // row finished (or none yet): write it, claim the next one with work
                 if (have) {
                     const int64_t r = row_begin + mine;
-                    A rsum = A(0);
-                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0);
+                    A rsum = A(0), qsum = A(0);
+                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0, qsum);
                     rsum = group_sum<LPR>(rsum);
                     if (sl == 0) s_rowsum[mine] = double(rsum);
+                    if (sq_out != nullptr) {
+                        qsum = group_sum<LPR>(qsum);
+                        if (sl == 0) sq_out[r] = qsum;
+                    }
                     have = false;
                 }
                 for (;;) {
@@ -385,9 +401,16 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
                     if (dg == 0 && skip_sinks) continue;
                     const int64_t r = row_begin + mine;
                     if (dg == 0) {           // row without out-edges, sinks not skipped: z stays (embedder.py:88-89)
+                        A qsum = A(0);
                         if (col_ok) {
                             const Pack<T, VEC> z0 = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
                             store_pack<T, VEC>(Znew + r * ldo + c0, z0);
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) qsum = fma(Elem<T>::to_acc(z0.v[k]), Elem<T>::to_acc(z0.v[k]), qsum);
+                        }
+                        if (sq_out != nullptr) {
+                            qsum = group_sum<LPR>(qsum);
+                            if (sl == 0) sq_out[r] = qsum;
                         }
                         continue;
                     }
@@ -457,7 +480,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P,
     const int32_t *__restrict__ long_rows, int64_t row0, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
-    Mirror<T> mirror, double *__restrict__ partials) {
+    Mirror<T> mirror, typename Elem<T>::acc_t *__restrict__ sq_out, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ A red[WAVES][kWave][VEC];
     const int lane = lane_id();
@@ -473,7 +496,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     const int64_t a = e0 + wave * seg;
     const int64_t b = a + seg < e1 ? a + seg : e1;
     const EdgeChunk<A> none{0, A(0)};
-    A rsum = A(0);
+    A rsum = A(0), qsum = A(0);
 
     for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
         const int c0 = t0 + sl * VEC;
@@ -499,13 +522,17 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
             }
-            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, mirror, r, c0);
+            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, mirror, r, c0, qsum);
         }
         if (t0 + LPR * VEC < d) __syncthreads();  // red[] is reused by the next column tile
     }
     if (wave == 0) {
         rsum = group_sum<kWave>(rsum);
         if (lane == 0) partials[blockIdx.x] = double(rsum);
+        if (sq_out != nullptr) {
+            qsum = group_sum<kWave>(qsum);  // zero outside sub-wave 0: the same bits as K0's fold over LPR lanes
+            if (lane == 0) sq_out[r] = qsum;
+        }
     }
 }
 
@@ -517,8 +544,8 @@ namespace clane {
 // A 70k-edge row done by one 16-wave workgroup is 4.4k edges per wave in sequence -- a ~0.25 ms tail
 // on every launch, which dominates once a sweep is cut into chunks (multi-GPU) or the graph is small.
 // Rows above `edges_per_segment` are cut into segments; workgroup s gathers segment s exactly like
-// spmm_long_kernel and leaves its partial sum (accumulate type) in slab[s]; spmm_split_combine_kernel
-// then adds a row's segments IN ORDER (reproducible) and runs the usual epilogue.
+// spmm_long_kernel and leaves its partial sum (accumulate type) in slab[s]; spmm_class_combine_kernel
+// then adds a row's segments in a fixed order (reproducible) and runs the usual epilogue.
 template <typename T, typename PT, int VEC, int LPR, int U, int WAVES>
 __global__ __launch_bounds__(WAVES *kWave) void spmm_split_segment_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P,
@@ -560,42 +587,17 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_split_segment_kernel(
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
             }
+            Pack<A, VEC> o;                    // whole packs (the pad columns of Z are zero, so are their sums):
 #pragma unroll
-            for (int k = 0; k < VEC; ++k)
-                if (c0 + k < d) slab[s * ld_slab + c0 + k] = acc[k];
+            for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];   // the combine reads packs
+            store_pack<A, VEC>(slab + s * ld_slab + c0, o);
         }
         if (t0 + LPR * VEC < d) __syncthreads();
     }
 }
 
-// One wave per split row: segments summed in order, then  z = x + gamma * sum,  delta, store.
-template <typename T>
-__global__ __launch_bounds__(kWave) void spmm_split_combine_kernel(
-    const int32_t *__restrict__ split_rows, const int64_t *__restrict__ seg_ptr, int64_t row0,
-    const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
-    const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
-    Mirror<T> mirror, double *__restrict__ partials) {
-    using A = typename Elem<T>::acc_t;
-    const int i = blockIdx.x;
-    const int64_t r = split_rows[i];
-    const int64_t s0 = seg_ptr[i], s1 = seg_ptr[i + 1];
-    A rsum = A(0);
-    for (int c = lane_id(); c < d; c += kWave) {
-        A tot = A(0);
-        for (int64_t s = s0; s < s1; ++s) tot += slab[s * ld_slab + c];
-        const A zold = Elem<T>::to_acc(Zold[(row0 + r) * ldz + c]);
-        const T out = Elem<T>::from_acc(Elem<T>::to_acc(X[r * ldx + c]) + gamma * tot);
-        Znew[r * ldo + c] = out;
-        if (mirror.row_ptr != nullptr) {
-            for (int64_t m = mirror.row_ptr[r]; m < mirror.row_ptr[r + 1]; ++m)
-                mirror.row(mirror.slot[m])[c] = out;
-        }
-        rsum += fabs(Elem<T>::to_acc(out) - zold);
-    }
-    rsum = group_sum<kWave>(rsum);
-    if (lane_id() == 0) partials[i] = double(rsum);
-}
-
+// The segments of a row are then added IN ORDER and the usual epilogue runs: spmm_class_combine_kernel below (a split
+// row's segments are laid out in the slab exactly like a class row's slots).
 }  // namespace clane
 
 namespace clane {
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
     const int32_t *__restrict__ class_rows, const int64_t *__restrict__ slot_ptr, int64_t row0,
     const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
-    Mirror<T> mirror, double *__restrict__ partials) {
+    Mirror<T> mirror, typename Elem<T>::acc_t *__restrict__ sq_out, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ A s_part[kCombineWaves > 1 ? kCombineWaves - 1 : 1][kWave][VEC];
     const int i = blockIdx.x;
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
     const int64_t share = ceil_div(s1 - s0, int64_t(kCombineWaves));
     const int64_t a = s0 + wave * share < s1 ? s0 + wave * share : s1;
     const int64_t b = a + share < s1 ? a + share : s1;
-    A rsum = A(0);
+    A rsum = A(0), qsum = A(0);
     for (int t0 = 0; t0 < d; t0 += kWave * VEC) {       // the same trip count in every wave (barriers inside)
         const int c0 = t0 + lane * VEC;
         const bool ok = c0 < d;
@@ -759,12 +761,16 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
             }
             const Pack<T, VEC> x = load_pack_stream<T, VEC>(X + r * ldx + c0);
             const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
-            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0);
+            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0, qsum);
         }
     }
     if (wave == 0) {
         rsum = group_sum<kWave>(rsum);
         if (lane == 0) partials[i] = double(rsum);
+        if (sq_out != nullptr) {
+            qsum = group_sum<kWave>(qsum);  // lane l holds the packs l, l + 64, ...: K0's order (zero where K0 has no lane)
+            if (lane == 0) sq_out[r] = qsum;
+        }
     }
 }
 

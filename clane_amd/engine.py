@@ -10,7 +10,8 @@ HBM layout per rank (T = float32 / float64 / bfloat16, ld = d rounded up to a 16
 pad columns zero; on N > 1 GPUs with the column split d is the width of the rank's column slice and
 every rank holds all rows; with a row split n_loc < V_pad):
 
-    Zbuf[2]   [V_pad, ld] T    embedding matrix, ping-pong (read old / write new)
+    Zbuf[3]   [V_pad, ld] T    embedding matrix: a sweep reads one, writes another; the third holds the embeddings of
+                               the start of the outer round (embedder.py:58) while the other two ping-pong
     X_loc     [n_loc, ld] T    content embeddings of the owned rows
     rowptr    [n_loc+1] i64, colidx [E_loc] i32 (positions), P [E_loc] acc, indeg [n_loc] i32
     partials  fixed-order L1-delta partial sums (double)
@@ -156,9 +157,15 @@ def place_piece(out: torch.Tensor, piece: dict) -> None:
 
 class SweepEngine:
     STAGE_SLOTS = 3          # copies of Z that may be in flight to the host at once (stage_Z)
+    # Z tables.  Two would do for the sweeps (read old / write new); the third replaces the reference's
+    # `prev_Z = graph.Z.clone()` (embedder.py:58): snapshot() PINS the current table instead of copying 2 GB, and the
+    # sweeps of the round ping-pong between the other two.
+    N_TABLES = 3
     # time_kernels: at most this many sweeps get HIP events.  Hundreds of live timing events slow every launch down
     # (config 2, 200 timed sweeps: 0.475 ms per step with 1 000 events alive, 0.248 ms with 160)
     MAX_TIMED_SWEEPS = 32
+
+    EXCHANGES = ("auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all")
 
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
@@ -166,7 +173,7 @@ class SweepEngine:
                  exchange: str = "auto", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
-                 phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False):
+                 phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
@@ -176,7 +183,9 @@ class SweepEngine:
         "halo_p2p" -- the same tables, mapped into every process of the box (hipIpc): the kernel that finishes a row
         stores it into the tables of the ranks that read it (peer-to-peer over xGMI), there is no exchange step;
         "allgather" -- rows divided, full-size Z on every rank, in-place all-gather of the live rows
-        (partition.py); "allgather_all" -- the same without the live/quiet split."""
+        (partition.py); "allgather_all" -- the same without the live/quiet split.
+        The constructor is a sequence of steps, each a method: the division over the ranks, the class-pass thresholds,
+        the row layout, the row bins, the structure upload, the launch lists, the exchange lists, the tables, scratch."""
         if X.dim() != 2 or X.shape[0] != csr.num_vertices:
             raise ValueError(f"X must be [V, d] with V={csr.num_vertices}, got {tuple(X.shape)}")
         if cosine_mode not in ("reference", "per_edge"):
@@ -188,11 +197,25 @@ class SweepEngine:
         self.dtype = X.dtype
         self.acc_dtype = _hip.acc_dtype(X.dtype)
         self.cosine_mode = cosine_mode
+        self.table_skew = table_skew
+        X = self._choose_division(csr, X, process_group, comm, exchange)
+        self._choose_class_pass(csr, class_threshold, class_chunk, class_k1, class_phases, phase_threshold)
+        self._build_layout(csr, chunks, shuffle, seed, hot_rows_first)
+        self._choose_row_bins(long_threshold, hub_threshold)
+        deg = self._upload_structure()
+        self._bin_rows(deg, split_hubs)
+        self._setup_exchange(deg, fused_pack)
+        self._alloc_tables(X, deg)
+        self._alloc_scratch(delta_stream, overlap_chunks)
+
+    # ---- constructor steps ----------------------------------------------------------------------------------
+    def _choose_division(self, csr: HostCSR, X: torch.Tensor, process_group, comm, exchange: str) -> torch.Tensor:
+        """Who the ranks are and how the sweep is divided over them; returns this rank's columns of X."""
         self.pg = process_group
         self.comm = comm if comm is not None else (TorchComm(process_group) if process_group is not None else None)
         self.world = self.comm.world if self.comm is not None else 1
         rank = self.comm.rank if self.comm is not None else 0
-        if exchange not in ("auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all"):
+        if exchange not in self.EXCHANGES:
             raise ValueError("exchange must be 'auto', 'columns', 'halo', 'halo_p2p', 'allgather' or 'allgather_all', "
                              f"got {exchange!r}")
         # a one-rank group whose comm insists on its collectives keeps the division it is given (RCCL rehearsal on a
@@ -202,39 +225,45 @@ class SweepEngine:
         divided = self.world > 1 or self._forced
         if exchange == "auto":
             exchange = pick_exchange(int(X.shape[1]), X.dtype, self.world)
+        self._exchange_asked = exchange
         self.exchange = exchange if divided else "none"
         self.columns = divided and exchange == "columns"
         self.V, self.d_full = csr.num_vertices, int(X.shape[1])
         self.E_total = csr.num_edges
         self.col0, self.col1 = column_slice(self.d_full, X.dtype, self.world, rank) if self.columns else (0, self.d_full)
-        X_all = X
         if self.columns:
             X = X[:, self.col0:self.col1]
             self.ld_max = _round_up(column_slice(self.d_full, X.dtype, self.world, 0)[1], _hip.VEC_ELEMS[X.dtype])
         self.d = self.col1 - self.col0                 # columns this rank computes (0: an idle rank, d < N packs)
         self.ld = _round_up(self.d, _hip.VEC_ELEMS[X.dtype])
         # rows are divided over `row_world` ranks; a column-split rank owns every row
-        row_world, row_rank = (1, 0) if self.columns else (self.world, rank)
-        if chunks is None:
-            chunks = 1 if row_world == 1 else 4
-        self.hot_rows_first = bool(hot_rows_first)
-        self.halo = row_world > 1 and exchange in ("halo", "halo_p2p")
+        self.row_world, self.row_rank = (1, 0) if self.columns else (self.world, rank)
+        self.halo = self.row_world > 1 and exchange in ("halo", "halo_p2p")
+        self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
+        if self.p2p and self.world > 8:
+            raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
         # Everything that decides the LAYOUT (which rows are class rows, hence the order of every row's edges) follows
         # from `d_plan`: the rank's own width -- except in a column split, where it is the widest slice (rank 0's) on
         # EVERY rank, one without columns included: build_P all-reduces the partial dot products element by element, so
         # all ranks must hold their edges in one order, even when their slices straddle a lane-layout boundary (33 packs
         # over two ranks: 32 and 16 lanes per row, class thresholds 64 and 256).
-        d_plan = self.d
+        self.d_plan = self.d
         if self.columns:
             c0, c1 = column_slice(self.d_full, X.dtype, self.world, 0)
-            d_plan = c1 - c0
-        ld_plan = _round_up(d_plan, _hip.VEC_ELEMS[X.dtype])
-        rows_per_wave = 64 // lanes_per_row(d_plan, X.dtype) if d_plan > 0 else 1
+            self.d_plan = c1 - c0
+        self.ld_plan = _round_up(self.d_plan, _hip.VEC_ELEMS[X.dtype])
+        self.rows_per_wave = 64 // lanes_per_row(self.d_plan, X.dtype) if self.d_plan > 0 else 1
+        return X
+
+    def _choose_class_pass(self, csr: HostCSR, class_threshold, class_chunk, class_k1, class_phases,
+                           phase_threshold) -> None:
+        """Which rows take the XCD-affine pass (xcd.py), in how many phases."""
+        row_bytes = self.ld_plan * torch.empty(0, dtype=self.dtype).element_size()
         # how much of the gather traffic XCD affinity could serve from the L2s at all (same number on every rank)
-        self.hot_read_share = hot_read_share(csr, ld_plan * X.element_size()) if d_plan > 0 else 1.0
+        self.hot_read_share = hot_read_share(csr, row_bytes) if self.d_plan > 0 else 1.0
         self.class_affinity = True
         if class_threshold is None:         # XCD-affine long rows, whatever the division
-            class_threshold = CLASS_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
+            class_threshold = CLASS_THRESHOLD_BY_ROWS_PER_WAVE[self.rows_per_wave]
             if self.hot_read_share < MIN_HOT_READ_SHARE:    # evenly spread reads: only rows that need splitting anyway
                 class_threshold = max(class_threshold, HEAVY_ROW_EDGES)
                 self.class_affinity = False
@@ -242,7 +271,7 @@ class SweepEngine:
         self.class_chunk = int(class_chunk)
         self.class_k1 = bool(class_k1) and self.class_threshold > 0    # build_P scores the class rows XCD-affine too
         # heavy class rows are also phased in time (xcd.py): phases 1 = off
-        self.class_phases = int(PHASES_BY_ROWS_PER_WAVE[rows_per_wave] if class_phases is None else class_phases)
+        self.class_phases = int(PHASES_BY_ROWS_PER_WAVE[self.rows_per_wave] if class_phases is None else class_phases)
         if self.class_threshold == 0 or self.class_phases < 1:
             self.class_phases = 1
         if self.class_phases & (self.class_phases - 1) or self.class_phases > 8:
@@ -252,21 +281,24 @@ class SweepEngine:
             raise ValueError("class_chunk must be a multiple of 64 in [64, 4096]")
         # a row one of whose (phase, class) segments alone is more than one XCD's L2 holds: its chunks are scheduled by
         # column, next to the other such rows' (xcd.class_items)
-        self.mega_segment_edges = int(L2_BYTES_ALL_XCDS // 8 // max(ld_plan * X.element_size(), 1)) if d_plan > 0 else 0
-        self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
-        if self.p2p and self.world > 8:
-            raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
+        self.mega_segment_edges = int(L2_BYTES_ALL_XCDS // 8 // max(row_bytes, 1)) if self.d_plan > 0 else 0
+
+    def _build_layout(self, csr: HostCSR, chunks, shuffle, seed: int, hot_rows_first: bool) -> None:
+        """Which rows this rank owns, where every row sits in the tables, the rank's CSR relabelled to table rows."""
+        if chunks is None:
+            chunks = 1 if self.row_world == 1 else 4
+        self.hot_rows_first = bool(hot_rows_first)
         if self.halo:
-            self.part = build_halo_layout(csr, self.world, rank, chunks, shuffle=shuffle is not False, seed=seed,
+            self.part = build_halo_layout(csr, self.world, self.row_rank, chunks, shuffle=shuffle is not False, seed=seed,
                                           hot_rows_first=hot_rows_first, class_threshold=self.class_threshold,
                                           phase_threshold=self.phase_threshold, phases=self.class_phases)
             self.blocks: List[Block] = self.part.blocks
             self.local: LocalCSR = self.part.local
         else:
-            live = csr.live_mask() if (row_world > 1 and exchange == "allgather") else None
+            live = csr.live_mask() if (self.row_world > 1 and self._exchange_asked == "allgather") else None
             # all rows on this GPU: lay Z out by descending in-degree, so the rows gathered most often are contiguous
-            hot = csr.indeg() if (row_world == 1 and hot_rows_first and not shuffle) else None
-            self.part = RowPartition.create(self.V, row_world, row_rank, chunks, live_mask=live, shuffle=shuffle,
+            hot = csr.indeg() if (self.row_world == 1 and hot_rows_first and not shuffle) else None
+            self.part = RowPartition.create(self.V, self.row_world, self.row_rank, chunks, live_mask=live, shuffle=shuffle,
                                             seed=seed, priority=hot)
             self.blocks = self.part.blocks(spans_for_one_rank=self._forced and not self.columns)
             self.local = localize(csr, self.part, self.device, class_threshold=self.class_threshold,
@@ -274,13 +306,16 @@ class SweepEngine:
         if self.part.padded_vertices >= 2 ** 31:
             raise ValueError(f"{self.part.padded_vertices} table rows: column indices are 32-bit (ABI v1); divide the "
                              "rows over more GPUs (exchange='halo') or wait for 64-bit indices")
+
+    def _choose_row_bins(self, long_threshold, hub_threshold) -> None:
+        """The degrees at which K1 / K2 / K3 hand a row from the one-(sub-)wave kernels to the workgroup-per-row ones."""
         if long_threshold is None:
-            long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[rows_per_wave]
-            if rows_per_wave == 1 and self.class_threshold and self.class_affinity:
+            long_threshold = LONG_THRESHOLD_BY_ROWS_PER_WAVE[self.rows_per_wave]
+            if self.rows_per_wave == 1 and self.class_threshold and self.class_affinity:
                 # with the class pass taking the rows above class_threshold, the 33..64-edge rows are better off with
                 # one wave each than with a 16-wave workgroup of which 15 waves leave at once (4.34 -> 4.30 ms)
                 long_threshold = max(long_threshold, self.class_threshold)
-            if rows_per_wave > 1:
+            if self.rows_per_wave > 1:
                 # A T-edge row walked by one sub-wave takes T/8 gather groups in sequence -- the tail of its launch.
                 # That is nothing next to a 40M-edge pass and a third of a 4M-edge one (R-MAT 200k/4M/d=128:
                 # 3 545 sweeps/s at T=128, 2 013 at T=1024), so T also scales with the edges of the pass.
@@ -295,9 +330,10 @@ class SweepEngine:
             long_threshold = min(long_threshold, self.class_threshold) if long_threshold > 0 else self.class_threshold
         self.long_threshold = int(long_threshold)
         self.hub_threshold = int(hub_threshold) if hub_threshold is not None else HUB_FACTOR * self.long_threshold
-        dev = self.device
 
-        # ---- graph structure ----------------------------------------------------------
+    def _upload_structure(self) -> np.ndarray:
+        """rowptr / colidx / in-degrees on the card, checked there once; P allocated.  Returns the local out-degrees."""
+        dev = self.device
         self.rowptr = torch.from_numpy(self.local.rowptr).to(dev)
         self.colidx = torch.from_numpy(self.local.colidx).to(dev)
         if self.colidx.numel() == 0:       # a graph without edges: the ABI still wants a real pointer
@@ -313,7 +349,12 @@ class SweepEngine:
         # workgroups that share the final softmax rescale of one class row in build_P: one, until a row is long enough for
         # that single workgroup to be the tail of build_P (a 2M-edge row: 2.3 ms of 6.6; config 3's 70k-edge hub: one)
         self.softmax_row_parts = int(min(64, max(1, -(-self.max_degree // SOFTMAX_EDGES_PER_WORKGROUP))))
-        # per block: row lists relative to the block's first row (the kernels get rowptr / X / Z_new offset to it)
+        return deg
+
+    def _bin_rows(self, deg: np.ndarray, split_hubs: bool) -> None:
+        """Per launch block: the row lists of each kernel (relative to the block's first row: the kernels get rowptr / X /
+        Z_new offset to it), the class items, the slots of the fixed-order delta partials, the slabs."""
+        dev = self.device
         self.long_rows: List[Optional[torch.Tensor]] = []     # every row above score_threshold (K1 / K2 slice these)
         self.mid_rows: List[Optional[torch.Tensor]] = []      # long_threshold < deg <= hub_threshold: 4 waves/row
         self.hub_rows: List[Optional[torch.Tensor]] = []      # hub_threshold < deg <= SPLIT_EDGES: 16 waves/row
@@ -382,9 +423,11 @@ class SweepEngine:
         self.slabs = [torch.zeros(slab_len, dtype=self.acc_dtype, device=dev)
                       for _ in range(2 if len(self.blocks) > 1 else 1)]
 
-        # ---- halo exchange: send lists and send buffers (one per own chunk) -----------------
-        # The kernel that finishes a row also stores it to its slots of the send buffer (`mirrors`: row -> slots,
-        # the inverse of send_rows), so no separate packing pass runs between the kernels and the exchange.
+    def _setup_exchange(self, deg: np.ndarray, fused_pack: bool) -> None:
+        """Halo exchange: send lists and send buffers (one per own chunk).  The kernel that finishes a row also stores
+        it to its slots of the send buffer (`mirrors`: row -> slots, the inverse of send_rows), so no separate packing
+        pass runs between the kernels and the exchange."""
+        dev = self.device
         self.send_rows: List[Optional[torch.Tensor]] = []
         self.send_buf: List[Optional[torch.Tensor]] = []
         self.mirrors: List[Optional[object]] = []
@@ -407,9 +450,23 @@ class SweepEngine:
                                            self.send_buf[-1])
             self.mirrors.append(mirror)
 
-        # ---- embeddings ---------------------------------------------------------------
-        # Vertex order <-> engine order is applied ON THE DEVICE (an upload / download plus one indexed copy):
-        # a 2 GB matrix permuted with host fancy-indexing costs more than a whole iterate() at config 3.
+    def _new_table(self, tag: str, rows: int) -> torch.Tensor:
+        """One of the big [rows, ld] tables (Zbuf0 / Zbuf1 / X), zeroed.  ``table_skew`` = {tag: bytes} (experiments:
+        tools/placement_probe.py) carves it out of a private allocation at that offset from a 2-MiB boundary."""
+        skew = (self.table_skew or {}).get(tag)
+        if skew is None or self.device.type != "cuda":
+            return torch.zeros(rows, self.ld, dtype=self.dtype, device=self.device)
+        es = torch.empty(0, dtype=self.dtype).element_size()
+        nbytes = rows * self.ld * es
+        raw = torch.zeros(nbytes + (4 << 20) + int(skew), dtype=torch.uint8, device=self.device)
+        start = (-raw.data_ptr()) % (2 << 20) + int(skew)
+        return raw[start:start + nbytes].view(self.dtype).view(rows, self.ld)
+
+    def _alloc_tables(self, X: torch.Tensor, deg: np.ndarray) -> None:
+        """The embedding tables (two ping-pong Z buffers, the owned rows of X) and the maps between vertex order and
+        engine order, which is applied ON THE DEVICE (an upload / download plus one indexed copy): a 2 GB matrix permuted
+        with host fancy-indexing costs more than a whole iterate() at config 3."""
+        dev = self.device
         if self.halo:
             self.table_vertex = torch.from_numpy(self.part.table_vertex).to(dev)   # int64 [table_rows]
             self.slot = torch.from_numpy(self.part.vertex_slot).to(dev)            # int64 [V]
@@ -417,24 +474,27 @@ class SweepEngine:
             self.pos = torch.from_numpy(self.part.position_of_vertex()).to(dev)    # int64 [V]
         if self.p2p:        # own allocations that the other processes map; views[q][p] = rank q's table p
             self._shared = [self.k.shareable_matrix((self.part.padded_vertices, self.ld), self.dtype, dev)
-                            for _ in range(2)]
+                            for _ in range(self.N_TABLES)]
             self.Zbuf = [b.tensor for b in self._shared]
             self.peer_tables, self._mapped = self.comm.share_matrices(self.k, self._shared)
             self._build_p2p_mirrors(deg)
         else:
-            self.Zbuf = [torch.zeros(self.part.padded_vertices, self.ld, dtype=self.dtype, device=dev)
-                         for _ in range(2)]
-        self.cur = 0
+            self.Zbuf = [self._new_table(f"Z{i}", self.part.padded_vertices) for i in range(self.N_TABLES)]
+        # cur: the table holding the current embeddings; hold: the one snapshot() pinned (never a sweep's destination);
+        # _prev_cur: what cur was before the latest sweep_launch (discard_launch); _tick: which of the two delta slots
+        # the next launch uses
+        self.cur, self.hold, self._prev_cur, self._tick = 0, None, 0, 0
         Xd = X.to(dev)                                                             # this rank's columns, [V, d]
         verts = torch.from_numpy(self.local.vertex).to(dev)
         ok = verts >= 0
-        self.X_loc = torch.zeros(self.part.n_local, self.ld, dtype=self.dtype, device=dev)
+        self.X_loc = self._new_table("X", self.part.n_local)
         self.X_loc[ok, :self.d] = Xd[verts[ok]]
         self.quiet_stale = False          # other ranks' quiet rows are only refreshed when Z is read out
         self._load_Z(Xd)
-        del Xd
 
-        # ---- scalars / scratch --------------------------------------------------------
+    def _alloc_scratch(self, delta_stream: bool, overlap_chunks: bool) -> None:
+        """Scalars, reduction workspaces, streams, timing state."""
+        dev = self.device
         self.ws = torch.zeros(self.k.reduce_ws_len(), dtype=torch.float64, device=dev)
         self.sums2 = torch.zeros(2, dtype=torch.float64, device=dev)
         self.delta = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -453,12 +513,15 @@ class SweepEngine:
         if self.device.type == "cuda" and (self.world > 1 or self._forced) and delta_stream:
             self._delta_stream = torch.cuda.Stream(self.device)
         self.block_out = torch.zeros(len(self.blocks), dtype=torch.float64, device=dev)
-        self.sq_loc = torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev)
+        # |z_v|^2 of the owned rows, one copy per Z table: the K3 kernel that writes a row of Zbuf[p] also
+        # writes its norm to sq_pp[p] (K0 fused into K3's epilogue); rows without out-edges keep the value K0 gave them
+        # when Z was loaded (`sq_valid`).  build_P reads sq_pp[cur]: no pass over Z (similarity.py:37's two norms).
+        self.sq_pp = [torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev) for _ in range(self.N_TABLES)]
+        self.sq_valid = False
         self.sq_full: Optional[torch.Tensor] = None
-        self.snap: Optional[torch.Tensor] = None
         self.sweeps_done = 0
         # optional per-kernel timing with HIP events on the launch stream (bench.py)
-        self._plans = {}                 # (parity, gamma, stream) -> launch list (see _build_plan)
+        self._plans = {}                 # (src, dst, tick, gamma, stream) -> launch list (see _build_plan)
         # Alternate chunks go to two side streams, so the tail of one chunk's kernels overlaps the head of the
         # next chunk's (a chunk at 8 GPUs is only ~0.25 ms of kernels: ramp-up and tail are a third of it).
         self.side_streams = None
@@ -472,7 +535,6 @@ class SweepEngine:
         self._stage_cv, self._stage_free = threading.Condition(), None      # stage_Z: slots made on first use
         self._own_vertex = None          # stage_Z(pieces=True) on a row split: vertex id of every own row
         self.kernel_events = []          # [(block, start, after_hub, after_mid, after_main)]
-
     def use_delta_stream(self, on: bool) -> None:
         """Switch the delta's all-reduce + host copy onto a stream of their own (or back onto the sweep's) between
         sweeps: the constructor's ``delta_stream`` made switchable, so that one run on real GPUs can time both
@@ -484,13 +546,13 @@ class SweepEngine:
         self._delta_stream = torch.cuda.Stream(self.device) if on else None
 
     def _build_p2p_mirrors(self, deg) -> None:
-        """halo_p2p: for each destination parity and own chunk, where every finished row has to go -- (rank q,
+        """halo_p2p: for each destination table and own chunk, where every finished row has to go -- (rank q,
         row of q's table) for each rank q that reads it.  q's table rows come from q's own layout (the start of
         the chunk's halo slice and the rows the ranks before me put there), gathered once."""
         me, W, dev = self.comm.rank, self.world, self.device
         mine = [(b.exchange.recv_start, list(b.exchange.out_splits)) for b in self.blocks]
         layouts = self.comm.all_gather_object(mine)
-        self.mirrors_p2p = [[None] * len(self.blocks) for _ in range(2)]
+        self.mirrors_p2p = [[None] * len(self.blocks) for _ in range(self.N_TABLES)]
         for i, b in enumerate(self.blocks):
             ex = b.exchange
             if ex.send_rows.size == 0:
@@ -514,9 +576,9 @@ class SweepEngine:
             np.cumsum(np.bincount(rel, minlength=b.nrows), out=row_ptr[1:])
             slot = place[np.argsort(rel, kind="stable")].astype(np.int32)
             rp_d, slot_d = torch.from_numpy(row_ptr).to(dev), torch.from_numpy(slot).to(dev)
-            for parity in range(2):
-                self.mirrors_p2p[parity][i] = self._make_mirror(rp_d, slot_d,
-                                                                [self.peer_tables[q][parity] for q in range(W)])
+            for table in range(self.N_TABLES):
+                self.mirrors_p2p[table][i] = self._make_mirror(rp_d, slot_d,
+                                                               [self.peer_tables[q][table] for q in range(W)])
 
     def _barrier(self) -> None:
         """Every rank has got here and its queued device work is done (an all-reduce, then the host waits)."""
@@ -554,9 +616,12 @@ class SweepEngine:
             first[held, :self.d] = Zd[self.table_vertex[held]]
         else:
             first[self.pos, :self.d] = Zd
-        # BOTH ping-pong buffers: rows without out-edges never change (embedder.py:88-89), so the sweep
-        # kernel leaves them alone (CLANE_SPMM_SINKS_UNTOUCHED) and relies on the two copies agreeing.
-        self.Zbuf[1].copy_(first)
+        # EVERY table: rows without out-edges never change (embedder.py:88-89), so the sweep
+        # kernel leaves them alone (CLANE_SPMM_SINKS_UNTOUCHED) and relies on all copies agreeing.
+        for other in self.Zbuf[1:]:
+            other.copy_(first)
+        self.cur, self.hold, self._prev_cur = 0, None, 0
+        self.sq_valid = False
         self.P_valid = False
         self.quiet_stale = False
         if self.p2p:        # nobody may store into a table that its owner is still loading
@@ -663,16 +728,24 @@ class SweepEngine:
         mode = _hip.SCORE_MODES[self.cosine_mode]
         busy = self.d > 0                   # a column-split rank without columns only joins the collectives
         sq = None
-        if self.cosine_mode == "reference":
+        if not self.sq_valid:               # Z was loaded from outside (X, set_Z): K0 once, for every table's copy
             if busy:
                 for b in self.blocks:
-                    k.row_sqnorm(self._zrows(Z, b), self.d, self.sq_loc[self._rows(b)])
-            k.degree_weighted_sums(self.sq_loc, self.rowptr, self.indeg, part.n_local, self.ws, self.sums2)
+                    k.row_sqnorm(self._zrows(Z, b), self.d, self.sq_pp[self.cur][self._rows(b)])
+            for i in range(self.N_TABLES):
+                if i != self.cur:
+                    self.sq_pp[i].copy_(self.sq_pp[self.cur])
+            self.sq_valid = True
+        sq_own = self.sq_pp[self.cur]       # after a sweep: written by the K3 kernels, bit for bit what K0 would give
+        if self.cosine_mode == "reference":
+            k.degree_weighted_sums(sq_own, self.rowptr, self.indeg, part.n_local, self.ws, self.sums2)
             self._all_reduce(self.sums2)    # partial over the owned rows, or over the owned columns: a sum either way
         else:
             if self.sq_full is None:
                 self.sq_full = torch.zeros(part.padded_vertices, dtype=self.acc_dtype, device=self.device)
-            if busy:
+            if self.row_world == 1:         # every table row is an own row, in table order (a column rank: of its columns)
+                self.sq_full.copy_(sq_own)
+            elif busy:
                 k.row_sqnorm(Z, self.d, self.sq_full)   # row split: every rank holds valid copies of all rows it reads
             if self.columns:
                 self._all_reduce(self.sq_full)
@@ -721,13 +794,13 @@ class SweepEngine:
     def _bind(self, method: str, *args, **kwargs):
         return self.k.bind(method, *args, **kwargs)              # HipKernels: the pre-marshalled ABI call
 
-    def _build_plan(self, cur: int, gamma: float):
-        """Launch lists of one sweep reading Zbuf[cur]: per block, bound kernel calls, event marks and the
-        exchange; then the final reduction.  Everything that can be computed once (views, pointers, offsets,
+    def _build_plan(self, cur: int, dst: int, tick: int, gamma: float):
+        """Launch lists of one sweep reading Zbuf[cur] and writing Zbuf[dst]: per block, bound kernel calls, event
+        marks and the exchange; then the final reduction (into delta slot `tick`).  Everything that can be computed once (views, pointers, offsets,
         the stream each call goes to) is, so the per-sweep host cost is a few microseconds per launch -- it
         matters at 8 GPUs, where a sweep is ~1 ms of GPU time."""
         k = self.k
-        Zold, Znew = self.Zbuf[cur], self.Zbuf[1 - cur]
+        Zold, Znew = self.Zbuf[cur], self.Zbuf[dst]
         per_block = []
         for i, b in enumerate(self.blocks):
             steps = []
@@ -735,7 +808,8 @@ class SweepEngine:
             with ctx:            # bound calls capture the current stream
                 rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
                 po = self.partial_off[i]
-                mir = self.mirrors_p2p[1 - cur][i] if self.p2p else self.mirrors[i]
+                mir = self.mirrors_p2p[dst][i] if self.p2p else self.mirrors[i]
+                sq_new = self.sq_pp[dst][b.local_start:]           # the finished rows' norms go with Z_new
                 po_mid = po + k.spmm_partials_len(b.nrows, 0)
                 po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
                 po_split = po_hub + (0 if self.hub_rows[i] is None else self.hub_rows[i].numel())
@@ -750,26 +824,27 @@ class SweepEngine:
                     steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
                                                      ipb, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
                                                      Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:],
-                                                     mirror=mir)))
+                                                     mirror=mir, sq_out=sq_new)))
                 if self.split_rows[i] is not None:
                     rows_s, seg_ptr, seg_row = self.split_rows[i]
                     steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
                                                      seg_row, self.segment_edges, b.row0, Zold, Xb, gamma, Zn, self.d,
-                                                     self.slabs[i % len(self.slabs)], self.partials[po_split:], mirror=mir)))
+                                                     self.slabs[i % len(self.slabs)], self.partials[po_split:], mirror=mir,
+                                                     sq_out=sq_new)))
                 steps.append(("event", i, 4))
                 if self.hub_rows[i] is not None:
                     steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
                                                      b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:],
-                                                     mirror=mir)))
+                                                     mirror=mir, sq_out=sq_new)))
                 steps.append(("event", i, 1))
                 if self.mid_rows[i] is not None:
                     steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.mid_rows[i], 4,
                                                      b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:],
-                                                     mirror=mir)))
+                                                     mirror=mir, sq_out=sq_new)))
                 steps.append(("event", i, 2))
                 steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb,
                                                  gamma, Zn, self.d, self.long_threshold, self.partials[po:],
-                                                 sinks_untouched=True, mirror=mir)))
+                                                 sinks_untouched=True, mirror=mir, sq_out=sq_new)))
                 steps.append(("event", i, 3))
                 if b.span is not None:
                     steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))
@@ -782,7 +857,7 @@ class SweepEngine:
                                   ex.out_splits, ex.in_splits))
             per_block.append(steps)
         final = self._bind("reduce_partials", self.partials, self.partials.numel(), self.ws,
-                           self.delta_pp[cur:cur + 1])
+                           self.delta_pp[tick:tick + 1])
         return per_block, final
 
     def sweep(self, gamma: float) -> float:
@@ -792,19 +867,23 @@ class SweepEngine:
     def sweep_launch(self, gamma: float) -> int:
         """Enqueue one sweep (kernels, exchange, delta reduction, all-reduce, copy of the delta to pinned host
         memory) and return a ticket for ``sweep_wait``.  Nothing blocks the host, so the NEXT sweep can be
-        launched before this one's delta is read: it reads the buffer this one writes, and if the host
-        then decides to stop, ``discard_launch()`` drops it -- the ping-pong partner still holds this sweep's Z."""
+        launched before this one's delta is read: it reads the table this one writes, and if the host
+        then decides to stop, ``discard_launch()`` drops it -- the table it read still holds this sweep's Z.
+        The destination is the table that is neither the current one nor the one ``snapshot()`` pinned."""
         if not self.P_valid:
             raise RuntimeError("sweep() before build_P()")
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-        parity = self.cur
+        src = self.cur
+        dst = next(i for i in range(self.N_TABLES) if i != src and i != self.hold)
+        parity = self._tick                 # delta slot of this launch (two launches may be in flight)
+        self._tick ^= 1
         if self._delta_stream is not None and self._delta_busy[parity]:
             torch.cuda.current_stream(self.device).wait_event(self._delta_ev[parity])   # its last all-reduce has read delta_pp[parity]
             self._delta_busy[parity] = False
-        key = (parity, float(gamma), stream)
+        key = (src, dst, parity, float(gamma), stream)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._plans[key] = self._build_plan(parity, float(gamma))
+            plan = self._plans[key] = self._build_plan(src, dst, parity, float(gamma))
         events = None
         if self.time_kernels and len(self.kernel_events) < self.MAX_TIMED_SWEEPS * len(self.blocks):
             events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in self.blocks]
@@ -867,7 +946,7 @@ class SweepEngine:
             self._delta_host[parity:parity + 1].copy_(mine, non_blocking=True)
             if self._delta_ev is not None:
                 self._delta_ev[parity].record()
-        self.cur = 1 - self.cur
+        self._prev_cur, self.cur = src, dst
         self.sweeps_done += 1
         self.quiet_stale = True
         return parity
@@ -880,9 +959,9 @@ class SweepEngine:
 
     def discard_launch(self) -> None:
         """Forget the most recent ``sweep_launch`` (a sweep launched ahead of a stop decision): the current
-        embeddings are again those of the sweep before it.  What it wrote sits in the buffer the next real sweep
-        overwrites; rows without out-edges were not touched by it either."""
-        self.cur = 1 - self.cur
+        embeddings are again those of the sweep before it.  What it wrote sits in a table that a later sweep
+        overwrites; rows without out-edges were not touched by it either.  (One launch can be taken back, not two.)"""
+        self.cur = self._prev_cur
         self.sweeps_done -= 1
 
     def kernel_times_ms(self):
@@ -967,21 +1046,24 @@ class SweepEngine:
 
     # ---- outer-loop delta (embedder.py:58-60) -------------------------------------------
     def snapshot(self) -> None:
-        if self.snap is None:
-            self.snap = torch.empty(self.part.n_local, self.ld, dtype=self.dtype, device=self.device)
-        for b in self.blocks:
-            self.snap[self._rows(b)].copy_(self._zrows(self.Zcur, b))
+        """Remember the current embeddings (the reference's ``prev_Z = graph.Z.clone()``, embedder.py:58) WITHOUT a
+        copy: the current table is pinned -- no sweep writes to it until the next snapshot() or set_Z()."""
+        self.hold = self.cur
 
-    def distance_from_snapshot(self) -> float:
-        if self.snap is None:
-            raise RuntimeError("distance_from_snapshot() before snapshot()")
-        for i, b in enumerate(self.blocks):
+    def l1_between(self, i: int, j: int) -> float:
+        """sum |Zbuf[i] - Zbuf[j]| over the owned rows, all ranks (embedder.py:60's reduction)."""
+        for n, b in enumerate(self.blocks):
             if self.d > 0:
-                self.k.l1_distance(self._zrows(self.Zcur, b), self.snap[self._rows(b)], self.d, self.ws,
-                                   self.block_out[i:i + 1])
+                self.k.l1_distance(self._zrows(self.Zbuf[i], b), self._zrows(self.Zbuf[j], b), self.d, self.ws,
+                                   self.block_out[n:n + 1])
         self.k.reduce_partials(self.block_out, len(self.blocks), self.ws, self.delta)
         self._all_reduce(self.delta)
         return float(self.delta.item())
+
+    def distance_from_snapshot(self) -> float:
+        if self.hold is None:
+            raise RuntimeError("distance_from_snapshot() before snapshot()")
+        return self.l1_between(self.cur, self.hold)
 
     # ---- collectives ------------------------------------------------------------------
     def _all_reduce(self, t: torch.Tensor) -> None:

@@ -55,7 +55,8 @@ def test_missing_library_fails_loudly(tmp_path):
 def test_argument_validation_reaches_last_error():
     # invalid arguments are rejected on the host before any launch: safe without a GPU
     lib = _hip.load_library()
-    rc = lib.clane_spmm_update_f32(None, None, None, 4, 0, None, 8, None, 8, 0.5, None, 8, 8, 0, 0, None, None, None)
+    rc = lib.clane_spmm_update_f32(None, None, None, 4, 0, None, 8, None, 8, 0.5, None, 8, 8, 0, 0, None, None, None,
+                                   None)
     assert rc == -1 and b"delta_partials" in lib.clane_last_error()
     rc = lib.clane_row_sqnorm_f32(None, 4, 0, 0, None, None)
     assert rc == -1 and b"bad shape" in lib.clane_last_error()

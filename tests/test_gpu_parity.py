@@ -336,7 +336,54 @@ def test_class_pass_random_engines(dev):
             assert delta == pytest.approx(float((got - Z).abs().sum()), rel=1e-5 if dtype != torch.bfloat16 else 2e-2,
                                           abs=1e-9), tag
             Z = got                                  # follow the GPU's (bf16-rounded) trajectory
+            assert_norms_are_k0s(eng, tag)
         del eng
+
+
+def assert_norms_are_k0s(eng, tag=""):
+    """The squared row norms the K3 kernels leave behind (SweepEngine.sq_pp, K0 fused into K3's epilogue) are BIT FOR
+    BIT what row_sqnorm_kernel (K0) computes from the table those kernels wrote -- for every owned row, sinks included."""
+    want = torch.zeros_like(eng.sq_pp[eng.cur])
+    for b in eng.blocks:
+        eng.k.row_sqnorm(eng._zrows(eng.Zcur, b), eng.d, want[eng._rows(b)])
+    got = eng.sq_pp[eng.cur]
+    assert torch.equal(got, want), (tag, int((got != want).sum()), float((got - want).abs().max()))
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.float32, 256), (torch.float32, 100), (torch.float32, 1433), (torch.float64, 64),
+                                     (torch.bfloat16, 128), (torch.bfloat16, 24), (torch.float32, 2)])
+@pytest.mark.parametrize("kw", [dict(), dict(class_threshold=0), dict(class_threshold=0, split_hubs=False, chunks=3),
+                                dict(class_threshold=16, class_chunk=64, chunks=2), dict(long_threshold=8, hub_threshold=40,
+                                                                                         class_threshold=0)])
+def test_k3_row_norms_are_bitwise_k0(dev, dtype, d, kw):
+    """K0 fused into K3: after sweeps through every K3 kernel -- one (sub-)wave per row, 4- and 16-wave
+    rows, split hub rows + combine, class chunks + combine -- build_P's norms come from the sweep, not from a pass over Z,
+    and they are the same bits.  Also after set_Z (K0 itself runs once) and after a discarded launch."""
+    csr = ragged_csr(5000, seed=11, max_deg=30, hubs=(4500, 700, 129, 65, 64, 5000, 300, 33))
+    X = synth.gaussian_X(5000, d, seed=3).to(dtype)
+    eng = SweepEngine(csr, X, dev, **kw)
+    eng.build_P()
+    assert_norms_are_k0s(eng, "after load")
+    for i in range(3):
+        eng.sweep(0.7)
+        assert_norms_are_k0s(eng, f"sweep {i}")
+    eng.snapshot()                          # the pinned table is never a destination: three tables rotate
+    t = eng.sweep_launch(0.7)
+    eng.sweep_wait(t)
+    t2 = eng.sweep_launch(0.7)
+    eng.sweep_wait(t2)
+    eng.discard_launch()
+    assert_norms_are_k0s(eng, "after a discarded launch")
+    P_before = eng.P.clone()
+    eng.build_P()                           # from the fused norms ...
+    P_fused = eng.P.clone()
+    eng.sq_valid = False
+    eng.build_P()                           # ... and from K0 over the same table: the same P, bit for bit
+    assert torch.equal(P_fused, eng.P) and not torch.equal(P_before, P_fused)
+    assert eng.distance_from_snapshot() > 0
+    eng.set_Z(X.float() * 2)
+    eng.build_P()
+    assert_norms_are_k0s(eng, "after set_Z")
 
 
 def test_spmm_row_block_with_row0_offset(dev, k):
@@ -1307,3 +1354,18 @@ def test_integration_stub_from_the_docs_runs(tmp_path):
     delta = state.sweep(0.76)
     Z_or, d_or = O.sweep(g.csr.rowptr, g.csr.colidx, P_or, g.X, g.X, 0.76)
     assert O.rel_l2(state.Z[state.cur].cpu(), Z_or) < 1e-6 and delta == pytest.approx(float(d_or), rel=1e-5)
+
+
+def test_lane_xor_exchanges_on_the_card(tmp_path):
+    """The DPP / v_permlane*_swap forms of lane ^ M (device_utils.h: every butterfly of K1 / K3 stands on them) against
+    __shfl_xor, compiled here with the box's hipcc and run on the card: a compiler or ROCm bump that changes what these
+    builtins do is caught by the suite, not by a wrong delta."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "lane_xor_check"
+    src = Path(__file__).resolve().parent.parent / "tools" / "lane_xor_check.hip"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++20", f"-I{src.parent.parent / 'clane_amd' / 'csrc'}",
+                    "-o", str(exe), str(src)], check=True, timeout=300)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "lane_xor check: 0 mismatches" in out.stdout, out.stdout + out.stderr

@@ -44,8 +44,7 @@ for W, ct, cc in [(W, ct, cc) for W in args.world for ct in args.class_threshold
     eng.P.copy_(torch.rand(eng.P.numel(), device=dev) / 20)       # any frozen weights: traffic is what is timed
     eng.P_valid = True
     if args.calibrate:
-        eng.snapshot()
-        eng.distance_from_snapshot()
+        eng.l1_between(0, 1)
     for _ in range(5):
         eng.sweep(0.76)
     torch.cuda.synchronize()
