@@ -122,11 +122,12 @@ def cpu_baseline(csr, Xf, P_host, gamma, Z1_oracle, first, budget_s=15.0):
                       f"{threads} threads), P from the oracle's own build_P (graph.py:118-128)"}
 
 
-def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=8.0):
+def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=12.0):
     """The PyTorch-CPU restatement SURVEY 8d names --  Z = X + gamma * (P @ Z)  plus the L1 delta, as in
     oracle/clane_oracle.py:sweep -- with P as a torch.sparse_csr_tensor (its CPU kernel is parallel over rows; the COO
     form of torch.sparse.mm is not: 0.127 sweeps/s on 128 threads against 0.130 on one in round 2), on all host
-    threads and on ONE thread.  FULL sweeps (1 warm-up + up to 10 timed) when one fits the budget; else a bounded
+    threads and on ONE thread.  FULL sweeps (1 warm-up + up to 10 timed, at least one) whenever a warm-up and one timed
+    sweep fit the budget (config 3 on all threads: ~4 s a sweep -- it does; SURVEY 8d asks for full sweeps); else a bounded
     SAMPLE of the workload, a seeded random 1/m of the rows (same degree mix; every m-th row would not do: R-MAT's hubs
     sit on the ids with trailing zero bits), scaled by the share of the edges the sample holds -- `sample` says which."""
     import warnings
@@ -175,7 +176,7 @@ def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=8.0):
 
     def figure(threads, probe_rows):
         probe, _, _, _ = timed(max(1, V // probe_rows), threads, 1)           # a small probe sizes the sample
-        stride = 1 if probe * 3 <= budget_s else max(2, int(np.ceil(probe * 3 / budget_s)))
+        stride = 1 if probe * 2 <= budget_s else max(2, int(np.ceil(probe * 3 / budget_s)))
         per, share, n_rows, reps = timed(stride, threads, 10 if stride == 1 else 2)
         what = (f"{reps} full sweeps (after 1 warm-up), best" if stride == 1 else
                 f"a random 1/{stride} of the rows ({n_rows} rows, {share:.1%} of the edges), best of {reps}, scaled to a "
@@ -234,12 +235,16 @@ def make_parser():
     ap.add_argument("--class-chunk", type=int, default=256)
     ap.add_argument("--no-split-hubs", action="store_true", help="hub rows by one workgroup each (no segment split)")
     ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all"],
-                    help="N > 1: auto = columns while a rank's row slice is >= 64 bytes, else halo; columns = every GPU "
-                         "holds d/N columns of every row, no exchange per sweep; allgather_all = north_star's literal "
+    ap.add_argument("--exchange", default="auto",
+                    choices=["auto", "columns", "grid", "halo", "halo_p2p", "allgather", "allgather_all"],
+                    help="N > 1: auto = columns while a rank's row slice is >= 64 bytes, else grid / halo; columns = every GPU "
+                         "holds d/N columns of every row, no exchange per sweep; grid = R row groups x C column groups "
+                         "(--grid-cols C): row SLICES exchanged inside a column group; allgather_all = north_star's literal "
                          "plan: rows divided, one in-place RCCL all-gather of the updated rows per sweep; allgather = "
                          "the same for the live rows only; halo / halo_p2p = rows sent only to the ranks that read "
                          "them (clane_amd/halo.py, partition.py; DESIGN.md section 6)")
+    ap.add_argument("--grid-cols", type=int, default=None,
+                    help="--exchange grid: column groups C (a divisor of N; default: the most whose slices stay 128 bytes wide)")
     ap.add_argument("--also-exchange", default="allgather_all,allgather",
                     help="N > 1: after the main division's timed blocks, rebuild the engine with each of these divisions "
                          "(comma-separated) and report its sweeps/s, parity and collective time in the same record: "
@@ -385,7 +390,7 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
     eng = SweepEngine(csr, X, dev, process_group=ranks.pg, comm=comm, chunks=args.chunks,
                       long_threshold=args.long_threshold, hub_threshold=args.hub_threshold, exchange=exchange,
                       hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs,
-                      class_threshold=args.class_threshold, class_chunk=args.class_chunk)
+                      class_threshold=args.class_threshold, class_chunk=args.class_chunk, grid_cols=args.grid_cols)
     torch.cuda.synchronize()
     log(f"engine up in {time.perf_counter() - t0:.1f}s ({eng.exchange}); rank rows={eng.part.n_local} edges={eng.E_loc} "
         f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
@@ -535,6 +540,12 @@ def describe_parallelism(args, world, eng, X, E) -> str:
                 f"[0:{X.shape[1]}) of X and Z, whole graph; not a headline number")
     if world == 1 and eng.exchange == "none":
         return f"1 GPU, {chunks} launch block(s)/sweep"
+    if eng.grid:
+        return (f"2-D division: {eng.R} row groups x {eng.C} column groups (rank = r * {eng.C} + c); a GPU holds columns "
+                f"[{eng.col0}:{eng.col1}) (rank 0) of its row group's rows; {chunks} launch block(s)/sweep, row slices "
+                f"exchanged among the {eng.R} ranks of a column group over RCCL per chunk "
+                f"({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep), partial dot products of build_P "
+                f"all-reduced among the {eng.C} ranks of a row group, one scalar all-reduce over all")
     if eng.columns:
         return (f"column split x{world}: every GPU holds the whole graph and columns [{eng.col0}:{eng.col1}) "
                 f"(rank 0) of X and Z; no exchange per sweep, one scalar all-reduce (RCCL); build_P all-reduces "
@@ -601,8 +612,8 @@ def roofline_block(args, world, m) -> dict:
 
 def main():
     args = make_parser().parse_args()
-    unknown = [x for x in args.also_exchange.split(",") if x not in ("", "none", "columns", "halo", "halo_p2p", "allgather",
-                                                                     "allgather_all")]
+    unknown = [x for x in args.also_exchange.split(",") if x not in ("", "none", "columns", "grid", "halo", "halo_p2p",
+                                                                     "allgather", "allgather_all")]
     if unknown:
         raise SystemExit(f"--also-exchange: unknown division(s) {unknown}")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher: be the launcher
@@ -696,7 +707,7 @@ def main():
     Z1_oracle = None
     failed = False
     if not args.no_parity:
-        P_gpu = eng.P_global() if (world == 1 or eng.columns) else None     # row splits: each rank holds its rows of P
+        P_gpu = eng.P_global() if eng.row_world == 1 else None      # row splits: each rank holds its rows of P
         if rank == 0:
             from oracle import clane_oracle as O
             from oracle import clane_oracle_c as OC
@@ -751,12 +762,14 @@ def main():
     printed = threading.Event()
     lock = threading.Lock()
 
-    def emit():
+    def emit(extra=None):
+        """Print the record once (rank 0).  `result` is only ever written under `lock`, so the copy that is dumped --
+        by the main thread here, or by the deadline thread -- is never a half-written one."""
         with lock:
             if not printed.is_set():
                 printed.set()
                 if rank == 0:
-                    print(json.dumps(result), flush=True)
+                    print(json.dumps(dict(result, **(extra or {}))), flush=True)
 
     also = [] if (args.also_exchange == "none" or not ranks.grouped or args.column_slice_of) else \
         [x for x in args.also_exchange.split(",") if x and x != eng.exchange
@@ -766,11 +779,14 @@ def main():
         # Whatever happens in here, the main record above must come out: past the deadline (per division) every rank
         # prints / leaves on its own (a rank stuck in a collective cannot be talked to).
         def give_up():
-            result.setdefault("north_star_literal", {"exchange": "allgather_all"})
-            result["also_exchange_error"] = (f"a division measured after the main one gave no result within "
-                                             f"{LITERAL_DEADLINE_S:.0f} s: printed as far as it got")
-            emit()
-            os._exit(0)
+            # the main record still comes out, but the process leaves NON-ZERO: a hang is a failure the launcher and
+            # the driver must see (1 if a parity check had already failed, else 3); never re-exec, never retry
+            extra = {"also_exchange_error": (f"a division measured after the main one gave no result within "
+                                             f"{LITERAL_DEADLINE_S:.0f} s: printed as far as it got")}
+            if "north_star_literal" not in result:
+                extra["north_star_literal"] = {"exchange": "allgather_all"}
+            emit(extra)
+            os._exit(1 if failed else 3)
         # a safety copy for the logs: should a later division take the process down (a fault, an abort inside the
         # library), the measurement of the main division has been seen
         log("main division measured; the record so far (the ONE stdout line follows after the other divisions): "
@@ -818,17 +834,23 @@ def main():
                     failed = True
             except Exception as exc:        # noqa: BLE001 -- reported in the record; the main measurement stands
                 block["error"] = f"{type(exc).__name__}: {exc}"
-            if exchange == "allgather_all":
-                result["north_star_literal"] = block
-            else:
-                result.setdefault("other_divisions", {})[exchange] = block
+            with lock:
+                if exchange == "allgather_all":
+                    result["north_star_literal"] = block
+                else:
+                    result.setdefault("other_divisions", {})[exchange] = block
+        if timer is not None:               # every block is stored: the deadline of the last division is over
+            timer.cancel()
     emit()
     if ranks.grouped:
-        # leave together.  The deadline stays armed until everybody is here: a rank that fell out of a block above
-        # on its own (an exception the others did not have) would otherwise wait for ranks stuck in a collective.
+        # leave together.  A rank that fell out of a block above on its own (an exception the others did not have)
+        # must not wait for ever for ranks stuck in a collective: the record is out, so past this deadline just leave,
+        # non-zero.
+        last = threading.Timer(LITERAL_DEADLINE_S, lambda: os._exit(1 if failed else 3))
+        last.daemon = True
+        last.start()
         dist.barrier()
-        if timer is not None:
-            timer.cancel()
+        last.cancel()
         dist.destroy_process_group()
     if failed:
         raise SystemExit("a division measured after the main one failed its parity check")

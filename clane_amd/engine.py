@@ -95,14 +95,28 @@ def _round_up(a: int, b: int) -> int:
 
 
 MIN_SLICE_ROW_BYTES = 64
+GRID_SLICE_ROW_BYTES = 128
+
+
+def pick_division(d: int, dtype: torch.dtype, world: int):
+    """(exchange, column groups) for ``exchange="auto"``.  Column split while a rank's slice of a row is at least
+    MIN_SLICE_ROW_BYTES (HBM is fetched in 64/128-byte lines: below that every gather drags in bytes of columns the rank
+    does not own -- measured on the 10M-vertex bf16 graph).  Narrower rows: the 2-D division -- the most
+    column groups C (a divisor of the world size) whose slices are still GRID_SLICE_ROW_BYTES wide, rows divided over
+    the world / C ranks of a column group with a halo exchange of row SLICES inside it; plain halo when even two
+    column groups are too many."""
+    row_bytes = d * torch.empty(0, dtype=dtype).element_size()
+    world = max(world, 1)
+    if row_bytes // world >= MIN_SLICE_ROW_BYTES:
+        return "columns", world
+    for C in range(world - 1, 1, -1):
+        if world % C == 0 and row_bytes // C >= GRID_SLICE_ROW_BYTES:
+            return "grid", C
+    return "halo", 1
 
 
 def pick_exchange(d: int, dtype: torch.dtype, world: int) -> str:
-    """Column split while a rank's slice of a row is at least MIN_SLICE_ROW_BYTES (HBM is fetched in 64/128-byte
-    lines: below that every gather drags in bytes of columns the rank does not own -- measured on the 10M-vertex
-    bf16 graph); else divide the rows and exchange halo rows."""
-    row_bytes = d * torch.empty(0, dtype=dtype).element_size()
-    return "columns" if row_bytes // max(world, 1) >= MIN_SLICE_ROW_BYTES else "halo"
+    return pick_division(d, dtype, world)[0]
 
 
 def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
@@ -140,7 +154,8 @@ class StagedZ:
         return self._resolve()
 
     def piece(self) -> dict:
-        """{'kind': 'columns', 'c0', 'c1', 'Z': [V, c1 - c0]} or {'kind': 'rows', 'vertex': int64 [n], 'Z': [n, d]}."""
+        """{'kind': 'columns', 'c0', 'c1', 'Z': [V, c1 - c0]}, {'kind': 'rows', 'vertex': int64 [n], 'Z': [n, d]} or
+        (2-D division) {'kind': 'tile', 'vertex', 'c0', 'c1', 'Z': [n, c1 - c0]}."""
         if self._where is None:
             raise RuntimeError("this copy holds the whole matrix: use result()")
         return dict(self._where, Z=self._resolve())
@@ -148,11 +163,12 @@ class StagedZ:
 
 def place_piece(out: torch.Tensor, piece: dict) -> None:
     """Write one rank's part (``StagedZ.piece()``) into the full ``[V, d]`` matrix ``out``."""
-    if piece["kind"] == "columns":
-        out[:, piece["c0"]:piece["c1"]] = piece["Z"]
+    c0, c1 = piece.get("c0", 0), piece.get("c1", out.shape[1])
+    if "vertex" not in piece:                           # every row, some columns
+        out[:, c0:c1] = piece["Z"]
     else:
         real = piece["vertex"] >= 0                     # padding rows of an equal-size row division hold no vertex
-        out[piece["vertex"][real]] = piece["Z"][real]
+        out[piece["vertex"][real], c0:c1] = piece["Z"][real]
 
 
 class SweepEngine:
@@ -165,7 +181,7 @@ class SweepEngine:
     # (config 2, 200 timed sweeps: 0.475 ms per step with 1 000 events alive, 0.248 ms with 160)
     MAX_TIMED_SWEEPS = 32
 
-    EXCHANGES = ("auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all")
+    EXCHANGES = ("auto", "columns", "grid", "halo", "halo_p2p", "allgather", "allgather_all")
 
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
@@ -173,9 +189,14 @@ class SweepEngine:
                  exchange: str = "auto", comm=None, hot_rows_first: bool = True, split_hubs: bool = True,
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
-                 phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None):
+                 phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None,
+                 grid_cols: Optional[int] = None):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
-        "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
+        "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "grid" / "halo" (pick_division).
+        "grid" -- both at once, for rows too narrow to cut N ways: the N ranks form R row groups x C column groups
+        (``grid_cols`` = C; rank = r * C + c).  Rank (r, c) holds columns slice c of the rows of group r: the row
+        exchange ("halo") runs among the R ranks that hold the same columns and moves SLICES of rows (1/C of the bytes),
+        build_P sums the partial dot products over the C ranks that hold the same rows, the delta over everybody.
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
         is independent per column, so a sweep needs no exchange at all (only the delta scalar is all-reduced);
         build_P all-reduces the partial dot products (E values, once per outer iteration).
@@ -198,7 +219,7 @@ class SweepEngine:
         self.acc_dtype = _hip.acc_dtype(X.dtype)
         self.cosine_mode = cosine_mode
         self.table_skew = table_skew
-        X = self._choose_division(csr, X, process_group, comm, exchange)
+        X = self._choose_division(csr, X, process_group, comm, exchange, grid_cols)
         self._choose_class_pass(csr, class_threshold, class_chunk, class_k1, class_phases, phase_threshold)
         self._build_layout(csr, chunks, shuffle, seed, hot_rows_first)
         self._choose_row_bins(long_threshold, hub_threshold)
@@ -209,47 +230,71 @@ class SweepEngine:
         self._alloc_scratch(delta_stream, overlap_chunks)
 
     # ---- constructor steps ----------------------------------------------------------------------------------
-    def _choose_division(self, csr: HostCSR, X: torch.Tensor, process_group, comm, exchange: str) -> torch.Tensor:
-        """Who the ranks are and how the sweep is divided over them; returns this rank's columns of X."""
+    def _choose_division(self, csr: HostCSR, X: torch.Tensor, process_group, comm, exchange: str,
+                         grid_cols: Optional[int]) -> torch.Tensor:
+        """Who the ranks are and how the sweep is divided over them; returns this rank's columns of X.
+        Every division is an R x C grid of the ranks (rank = r * C + c): C column groups (C = N: "columns"; C = 1: the
+        row divisions), R = N / C row groups.  ``row_comm`` joins the C ranks that hold the same rows (they sum partial
+        dot products in build_P), ``col_comm`` the R ranks that hold the same columns (they exchange rows)."""
         self.pg = process_group
         self.comm = comm if comm is not None else (TorchComm(process_group) if process_group is not None else None)
         self.world = self.comm.world if self.comm is not None else 1
         rank = self.comm.rank if self.comm is not None else 0
         if exchange not in self.EXCHANGES:
-            raise ValueError("exchange must be 'auto', 'columns', 'halo', 'halo_p2p', 'allgather' or 'allgather_all', "
-                             f"got {exchange!r}")
+            raise ValueError("exchange must be 'auto', 'columns', 'grid', 'halo', 'halo_p2p', 'allgather' or "
+                             f"'allgather_all', got {exchange!r}")
         # a one-rank group whose comm insists on its collectives keeps the division it is given (RCCL rehearsal on a
         # one-GPU box, comm.TorchComm(force_collectives=True)); "auto" is then the plain one-GPU plan
         self._forced = self.world == 1 and self.comm is not None and bool(self.comm.force) and exchange in (
             "columns", "allgather", "allgather_all")
         divided = self.world > 1 or self._forced
         if exchange == "auto":
-            exchange = pick_exchange(int(X.shape[1]), X.dtype, self.world)
+            exchange, auto_cols = pick_division(int(X.shape[1]), X.dtype, self.world)
+            grid_cols = grid_cols if grid_cols is not None else auto_cols
+        if exchange == "grid" and divided:
+            if grid_cols is None:
+                grid_cols = pick_division(int(X.shape[1]), X.dtype, self.world)[1]
+                grid_cols = grid_cols if 1 < grid_cols < self.world else next(
+                    (c for c in range(2, self.world) if self.world % c == 0), self.world)
+            if grid_cols < 1 or self.world % grid_cols:
+                raise ValueError(f"grid_cols={grid_cols} does not divide the {self.world} ranks")
+            if grid_cols == self.world:         # one row group: that IS the column split
+                exchange = "columns"
+            elif grid_cols == 1:                # one column group: that IS the halo division
+                exchange = "halo"
         self._exchange_asked = exchange
         self.exchange = exchange if divided else "none"
-        self.columns = divided and exchange == "columns"
+        self.grid = divided and exchange == "grid"
+        self.C = (self.world if exchange == "columns" else grid_cols if self.grid else 1) if divided else 1
+        self.R = self.world // self.C
+        self.r, self.c = divmod(rank, self.C)
+        self.columns = divided and self.C > 1 or (self._forced and exchange == "columns")
+        self.row_comm = self.col_comm = self.comm
+        if self.grid:
+            self.row_comm = self.comm.split([[r * self.C + c for c in range(self.C)] for r in range(self.R)])
+            self.col_comm = self.comm.split([[r * self.C + c for r in range(self.R)] for c in range(self.C)])
         self.V, self.d_full = csr.num_vertices, int(X.shape[1])
         self.E_total = csr.num_edges
-        self.col0, self.col1 = column_slice(self.d_full, X.dtype, self.world, rank) if self.columns else (0, self.d_full)
+        self.col0, self.col1 = column_slice(self.d_full, X.dtype, self.C, self.c) if self.columns else (0, self.d_full)
         if self.columns:
             X = X[:, self.col0:self.col1]
-            self.ld_max = _round_up(column_slice(self.d_full, X.dtype, self.world, 0)[1], _hip.VEC_ELEMS[X.dtype])
-        self.d = self.col1 - self.col0                 # columns this rank computes (0: an idle rank, d < N packs)
+            self.ld_max = _round_up(column_slice(self.d_full, X.dtype, self.C, 0)[1], _hip.VEC_ELEMS[X.dtype])
+        self.d = self.col1 - self.col0                 # columns this rank computes (0: an idle rank, d < C packs)
         self.ld = _round_up(self.d, _hip.VEC_ELEMS[X.dtype])
-        # rows are divided over `row_world` ranks; a column-split rank owns every row
-        self.row_world, self.row_rank = (1, 0) if self.columns else (self.world, rank)
-        self.halo = self.row_world > 1 and exchange in ("halo", "halo_p2p")
+        # rows are divided over the `row_world` ranks of a column group; with one row group a rank owns every row
+        self.row_world, self.row_rank = self.R, self.r
+        self.halo = self.row_world > 1 and exchange in ("halo", "halo_p2p", "grid")
         self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
         if self.p2p and self.world > 8:
             raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
         # Everything that decides the LAYOUT (which rows are class rows, hence the order of every row's edges) follows
-        # from `d_plan`: the rank's own width -- except in a column split, where it is the widest slice (rank 0's) on
-        # EVERY rank, one without columns included: build_P all-reduces the partial dot products element by element, so
-        # all ranks must hold their edges in one order, even when their slices straddle a lane-layout boundary (33 packs
-        # over two ranks: 32 and 16 lanes per row, class thresholds 64 and 256).
+        # from `d_plan`: the rank's own width -- except with several column groups, where it is the widest slice
+        # (group 0's) on EVERY rank, one without columns included: build_P all-reduces the partial dot products element
+        # by element, so all ranks of a row group must hold their edges in one order, even when their slices straddle a
+        # lane-layout boundary (33 packs over two ranks: 32 and 16 lanes per row, class thresholds 64 and 256).
         self.d_plan = self.d
         if self.columns:
-            c0, c1 = column_slice(self.d_full, X.dtype, self.world, 0)
+            c0, c1 = column_slice(self.d_full, X.dtype, self.C, 0)
             self.d_plan = c1 - c0
         self.ld_plan = _round_up(self.d_plan, _hip.VEC_ELEMS[X.dtype])
         self.rows_per_wave = 64 // lanes_per_row(self.d_plan, X.dtype) if self.d_plan > 0 else 1
@@ -289,7 +334,7 @@ class SweepEngine:
             chunks = 1 if self.row_world == 1 else 4
         self.hot_rows_first = bool(hot_rows_first)
         if self.halo:
-            self.part = build_halo_layout(csr, self.world, self.row_rank, chunks, shuffle=shuffle is not False, seed=seed,
+            self.part = build_halo_layout(csr, self.row_world, self.row_rank, chunks, shuffle=shuffle is not False, seed=seed,
                                           hot_rows_first=hot_rows_first, class_threshold=self.class_threshold,
                                           phase_threshold=self.phase_threshold, phases=self.class_phases)
             self.blocks: List[Block] = self.part.blocks
@@ -627,27 +672,35 @@ class SweepEngine:
         if self.p2p:        # nobody may store into a table that its owner is still loading
             self._barrier()
 
+    def _own_columns_in_vertex_order(self) -> torch.Tensor:
+        """[V, ld] on the device: every row (vertex order) of the columns this rank holds (collective when rows are
+        divided: the ranks of a column group put their rows together)."""
+        if self.halo:       # own rows of every rank of the column group, in slot order (slot = owner * n_local + local row)
+            n = self.part.n_local
+            everyone = torch.empty(self.row_world * n, self.ld, dtype=self.dtype, device=self.device)
+            self.col_comm.all_gather_into(everyone, self.Zcur[:n].contiguous())
+            return everyone[self.slot]
+        self._sync_quiet_rows()
+        return self.Zcur[self.pos]
+
     def get_Z(self) -> torch.Tensor:
         """Current embeddings as a fresh CPU tensor [V, d] in vertex order (collective when N > 1)."""
-        if self.halo:       # own rows of every rank, in slot order (slot = owner * n_local + local row)
-            n = self.part.n_local
-            everyone = torch.empty(self.world * n, self.ld, dtype=self.dtype, device=self.device)
-            self.comm.all_gather_into(everyone, self.Zcur[:n].contiguous())
-            return everyone[self.slot, :self.d].cpu()
-        if self.columns:    # column slices of every rank, padded to the widest one
-            mine = torch.zeros(self.part.padded_vertices, self.ld_max, dtype=self.dtype, device=self.device)
-            mine[:, :self.ld] = self.Zcur
-            everyone = torch.empty(self.world * mine.shape[0], self.ld_max, dtype=self.dtype, device=self.device)
-            self.comm.all_gather_into(everyone, mine)
-            everyone = everyone.view(self.world, mine.shape[0], self.ld_max)
-            out = torch.empty(self.V, self.d_full, dtype=self.dtype, device=self.device)
-            for r in range(self.world):
-                c0, c1 = column_slice(self.d_full, self.dtype, self.world, r)
-                if c1 > c0:
-                    out[:, c0:c1] = everyone[r][self.pos, :c1 - c0]
-            return out.cpu()
-        self._sync_quiet_rows()
-        return self.Zcur[self.pos, :self.d].cpu()
+        Zv = self._own_columns_in_vertex_order()
+        if not self.columns:
+            return Zv[:, :self.d].cpu()
+        # column slices of every column group, padded to the widest one
+        mine = torch.zeros(self.V, self.ld_max, dtype=self.dtype, device=self.device)
+        mine[:, :self.ld] = Zv
+        del Zv
+        everyone = torch.empty(self.C * self.V, self.ld_max, dtype=self.dtype, device=self.device)
+        self.row_comm.all_gather_into(everyone, mine)
+        everyone = everyone.view(self.C, self.V, self.ld_max)
+        out = torch.empty(self.V, self.d_full, dtype=self.dtype, device=self.device)
+        for c in range(self.C):
+            c0, c1 = column_slice(self.d_full, self.dtype, self.C, c)
+            if c1 > c0:
+                out[:, c0:c1] = everyone[c][:, :c1 - c0]
+        return out.cpu()
 
     def stage_Z(self, pieces: bool = False) -> StagedZ:
         """Start copying the current embeddings to the host WITHOUT stalling the sweeps (``--save_history`` at
@@ -656,21 +709,22 @@ class SweepEngine:
         stream.  At most STAGE_SLOTS copies are in flight; with none free this call waits for ``result()`` of an
         earlier one (possibly on another thread).
         Several GPUs: ``pieces=True`` stages only what THIS rank holds -- its column slice of every row (column
-        split) or its own rows (row splits) -- the same way and with no collective: N PCIe links drain in parallel and
+        split), its own rows (row splits) or its columns of its rows (2-D division) -- the same way and with no collective: N PCIe links drain in parallel and
         whoever wants the whole matrix puts the ranks' pieces together on the host (``StagedZ.piece``,
         ``place_piece``; ``Embedder`` does, through files).  Without ``pieces`` a multi-GPU run gathers synchronously
         (``get_Z``: collective), as a host-memory engine does."""
         if self.world > 1 and not pieces:
             return StagedZ(ready=self.get_Z())
-        by_rows = self.world > 1 and not self.columns          # this rank's own rows; else all rows (of its columns)
+        by_rows = self.row_world > 1            # this rank's own rows; else all rows (of its columns)
+        cols = {"c0": self.col0, "c1": self.col1} if self.columns else {}
         if self.device.type != "cuda":          # host-memory engine (the CPU suite's test double): nothing to overlap
             if self.world == 1:
                 return StagedZ(ready=self.get_Z())
             if by_rows:
                 own = torch.cat([self._zrows(self.Zcur, b)[:, :self.d] for b in self.blocks]).clone()
-                return StagedZ(ready=own, where={"kind": "rows", "vertex": torch.from_numpy(self.local.vertex.astype(np.int64))})
-            return StagedZ(ready=self.Zcur[self.pos, :self.d].clone(),
-                           where={"kind": "columns", "c0": self.col0, "c1": self.col1})
+                return StagedZ(ready=own, where=dict(cols, kind="tile" if cols else "rows",
+                                                     vertex=torch.from_numpy(self.local.vertex.astype(np.int64))))
+            return StagedZ(ready=self.Zcur[self.pos, :self.d].clone(), where=dict(cols, kind="columns"))
         n_rows = self.part.n_local if by_rows else self.V
         with self._stage_cv:
             if self._stage_free is None:
@@ -692,11 +746,11 @@ class SweepEngine:
                 slot["dev"][self._rows(b)].copy_(self._zrows(self.Zcur, b))
             if self._own_vertex is None:
                 self._own_vertex = torch.from_numpy(self.local.vertex.astype(np.int64))
-            where = {"kind": "rows", "vertex": self._own_vertex}
+            where = dict(cols, kind="tile" if cols else "rows", vertex=self._own_vertex)
         else:
             torch.index_select(self.Zcur, 0, self.pos, out=slot["dev"])     # vertex order, on the sweep stream
             if self.world > 1:
-                where = {"kind": "columns", "c0": self.col0, "c1": self.col1}
+                where = dict(cols, kind="columns")
         copied = torch.cuda.Event()
         copied.record(main)
         self._copy_stream.wait_event(copied)
@@ -718,7 +772,7 @@ class SweepEngine:
             return
         begin, end, q = span
         mine = self.Zcur[begin + self.part.rank * q: begin + (self.part.rank + 1) * q]
-        self.comm.all_gather_into(self.Zcur[begin:end], mine)
+        self.col_comm.all_gather_into(self.Zcur[begin:end], mine)
         self.quiet_stale = False
 
     # ---- build_P (graph.py:118-128) -----------------------------------------------------
@@ -748,7 +802,7 @@ class SweepEngine:
             elif busy:
                 k.row_sqnorm(Z, self.d, self.sq_full)   # row split: every rank holds valid copies of all rows it reads
             if self.columns:
-                self._all_reduce(self.sq_full)
+                self._all_reduce(self.sq_full, self.row_comm)     # partial norms over the column groups' slices
             sq = self.sq_full
         if self.E_loc > 0 and not self.columns:
             for i, b in enumerate(self.blocks):
@@ -763,7 +817,8 @@ class SweepEngine:
                                        self.slabs[i % len(self.slabs)], fuse_softmax=True,
                                        n_slots=self.class_slots[i], row_parts=self.softmax_row_parts)
         elif self.E_loc > 0:
-            # column split: dot products of the owned columns, summed over the GPUs, then denominators + softmax
+            # several column groups: dot products of the owned columns, summed over the ranks that hold the same rows,
+            # then denominators + softmax
             if busy:
                 for i, b in enumerate(self.blocks):
                     k.edge_score(self.rowptr[b.local_start:], self.colidx, b.nrows, b.row0, Z, self.d,
@@ -775,7 +830,7 @@ class SweepEngine:
                                            _hip.SCORE_RAW_DOT, None, None, self.P)
             else:
                 self.P.zero_()
-            self._all_reduce(self.P)
+            self._all_reduce(self.P, self.row_comm)               # the ranks that hold the same rows, other columns
             for i, b in enumerate(self.blocks):
                 rp = self.rowptr[b.local_start:]
                 k.edge_score_finalize(rp, self.colidx, b.nrows, b.row0, mode, self.sums2, sq, self.P)
@@ -908,9 +963,9 @@ class SweepEngine:
                         if events is not None:
                             events[step[1]][step[2]].record()
                     elif kind == "allgather":
-                        works.append(self.comm.all_gather_into(step[1], step[2], async_op=True))
+                        works.append(self.col_comm.all_gather_into(step[1], step[2], async_op=True))
                     else:
-                        works.append(self.comm.all_to_all_rows(step[1], step[2], step[3], step[4], async_op=True))
+                        works.append(self.col_comm.all_to_all_rows(step[1], step[2], step[3], step[4], async_op=True))
         if side:
             for st in side:
                 done = torch.cuda.Event()
@@ -1033,15 +1088,16 @@ class SweepEngine:
                 "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
                 "class_affinity": self.class_affinity, "mega_segment_edges": self.mega_segment_edges,
                 "class_items_per_block": [c[6] for c in self.class_rows if c is not None][:1],
-                "hot_rows_first": self.hot_rows_first, "exchange": self.exchange}
+                "hot_rows_first": self.hot_rows_first, "exchange": self.exchange,
+                "grid": [self.R, self.C] if self.grid else None}
 
     def exchange_bytes_per_sweep(self) -> int:
         """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""
         s = self.Zcur.element_size()
-        if self.columns:
-            return 0
         if self.halo:
             return self.part.recv_rows_per_sweep() * self.ld * s
+        if self.columns:
+            return 0
         return sum((b.span[1] - b.span[0] - b.nrows) * self.ld * s for b in self.blocks if b.span is not None)
 
     # ---- outer-loop delta (embedder.py:58-60) -------------------------------------------
@@ -1066,6 +1122,7 @@ class SweepEngine:
         return self.l1_between(self.cur, self.hold)
 
     # ---- collectives ------------------------------------------------------------------
-    def _all_reduce(self, t: torch.Tensor) -> None:
+    def _all_reduce(self, t: torch.Tensor, comm=None) -> None:
+        """Sum over all ranks, or over the ranks of `comm` (row_comm: the ranks that hold the same rows)."""
         if self.world > 1 or self._forced:
-            self.comm.all_reduce_sum(t)
+            (comm if comm is not None else self.comm).all_reduce_sum(t)

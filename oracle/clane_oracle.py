@@ -209,7 +209,13 @@ class OracleEmbedder:
 
     def __init__(self, rowptr, colidx, X: torch.Tensor, gamma: float = 0.76,
                  tolerence: int = 10, mode: str = "reference", save_history: bool = False,
-                 max_sweeps: Optional[int] = None):
+                 max_sweeps: Optional[int] = None, plain_c: bool = False):
+        """``plain_c``: the same control flow with build_P / sweep done by the plain-C restatement
+        (oracle/clane_oracle.c: fp32, reference cosine mode only) -- the independent second oracle, and much the faster
+        one at d = 1433."""
+        if plain_c and (mode != "reference" or X.dtype != torch.float32):
+            raise ValueError("the plain-C oracle restates the fp32 reference-mode path only")
+        self.plain_c = plain_c
         self.rowptr, self.colidx = rowptr, colidx
         self.X = X
         self.Z = X.clone()
@@ -225,14 +231,20 @@ class OracleEmbedder:
         self.max_sweeps = max_sweeps
 
     def propagate(self):
-        P = build_P_values(self.rowptr, self.colidx, self.Z, self.mode)
-        P_sparse = as_sparse(self.rowptr, self.colidx, P)
+        if self.plain_c:
+            from . import clane_oracle_c as OC
+            P, _ = OC.build_P(self.rowptr, self.colidx, self.Z)
+            c_sweep = lambda: OC.sweep(self.rowptr, self.colidx, P, self.X, self.Z, self.gamma)  # noqa: E731
+        else:
+            P = build_P_values(self.rowptr, self.colidx, self.Z, self.mode)
+            P_sparse = as_sparse(self.rowptr, self.colidx, P)
         minimum = math.inf
         tol = self.tolerences["propagation"]
         tol.reset()
         hist, deltas = [], []
         while True:
-            Z_new, amount = sweep(self.rowptr, self.colidx, P, self.X, self.Z, self.gamma, P_sparse)
+            Z_new, amount = c_sweep() if self.plain_c else sweep(self.rowptr, self.colidx, P, self.X, self.Z, self.gamma,
+                                                                   P_sparse)
             self.Z = Z_new
             deltas.append(float(amount))
             if self.save_history:

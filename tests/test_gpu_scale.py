@@ -515,7 +515,7 @@ def test_corashape_symmetrised_to_convergence(tmp_path):
     assert np.array_equal(graph.csr.indeg(), np.diff(graph.csr.rowptr))    # symmetric
     emb = Embedder(graph, CosineSimilarity(), torch.device("cuda"), gamma=0.76, tolerence=10, verbose=False)
     emb.iterate()
-    orc = O.OracleEmbedder(graph.csr.rowptr, graph.csr.colidx, X, gamma=0.76, tolerence=10)
+    orc = O.OracleEmbedder(graph.csr.rowptr, graph.csr.colidx, X, gamma=0.76, tolerence=10, plain_c=True)
     Z_or = orc.iterate()
     assert O.rel_l2(graph.Z, Z_or) < 1e-5
     # the first propagate runs ~100 sweeps down to the fp32 noise floor of the delta, where WHICH sweep stops improving
@@ -687,7 +687,8 @@ def test_bench_main_record_survives_a_stuck_literal_block():
     """The `north_star_literal` block runs after the main measurement and must never cost it: past its deadline every
     rank prints / leaves on its own (a rank stuck in a collective cannot be talked to).  A deadline of a millisecond
     stands in for a hung all-gather: ONE JSON line still comes out, with the main division's numbers, its parity and
-    `comm` block, and an `error` in place of the literal block; the launcher sees a clean exit."""
+    `comm` block, and an `error` in place of the literal block -- and the launcher sees a NON-ZERO exit: a division that
+    hung is a failure the driver must be able to key on, the record says which."""
     import json
     import os
     import subprocess
@@ -697,7 +698,7 @@ def test_bench_main_record_survives_a_stuck_literal_block():
     run = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
                           "--workload", "tiny", "--steps", "3", "--warmup", "1", "--blocks", "2"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert run.returncode == 0, run.stderr[-3000:]
+    assert run.returncode != 0, run.stderr[-3000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     r = json.loads(lines[0])

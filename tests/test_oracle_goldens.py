@@ -79,6 +79,9 @@ def test_first_sweep_and_final_Z(name):
     emb = O.OracleEmbedder(rowptr, colidx, X, gamma=float(g["gamma"]), tolerence=int(g["tolerence"]))
     Z = emb.iterate()
     assert O.rel_l2(Z, torch.from_numpy(g["Z_final"])) < tol
+    if X.dtype == torch.float32:                     # the plain-C oracle under the same control flow: the same answer
+        emb_c = O.OracleEmbedder(rowptr, colidx, X, gamma=float(g["gamma"]), tolerence=int(g["tolerence"]), plain_c=True)
+        assert O.rel_l2(emb_c.iterate(), torch.from_numpy(g["Z_final"])) < tol
     # sinks never move (embedder.py:88-89)
     sink = np.diff(rowptr) == 0
     np.testing.assert_array_equal(Z.numpy()[sink], g["X"][sink])

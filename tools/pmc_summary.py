@@ -98,9 +98,11 @@ def main():
         if bench_name(k):
             entry[bench_name(k)] = {"bytes_per_launch": v["fetch_bytes"] + v["write_bytes"], "rocprof_name": k}
     for k, v in summary.items():        # the combine launch belongs to the same bench entry as its chunk / segment pass
+        # (spmm_class_combine_kernel also closes the split-segment pass when the class pass is off)
         for part, whole in (("spmm_class_combine_kernel", "spmm_class_chunk_kernel+combine"),
-                            ("spmm_split_combine_kernel", "spmm_split_segment_kernel+combine")):
-            if part in k and whole in entry:
+                            ("spmm_class_combine_kernel", "spmm_split_segment_kernel+combine")):
+            if part in k and whole in entry and not (whole.startswith("spmm_split") and
+                                                     "spmm_class_chunk_kernel+combine" in entry):
                 entry[whole]["bytes_per_launch"] += v["fetch_bytes"] + v["write_bytes"]
     data[args.workload] = entry
     tfile.write_text(json.dumps(data, indent=1) + "\n")
