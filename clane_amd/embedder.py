@@ -115,7 +115,9 @@ class Embedder(object):
         sim = self.similarity_measure
         if isinstance(sim, CosineSimilarity):
             return self.graph.engine(self.device, cosine_mode=sim.mode)
-        return self.graph.engine(self.device)
+        # a plug-in similarity needs whole rows: should this call be the one that creates the engine of a multi-GPU
+        # run, it divides the rows (an engine that exists already keeps its division)
+        return self.graph.engine(self.device, exchange=self.graph.PLUGIN_EXCHANGE)
 
     def _build_P(self, engine) -> None:
         if isinstance(self.similarity_measure, CosineSimilarity):
@@ -163,6 +165,7 @@ class Embedder(object):
             run = engine.comm.all_gather_object(f"run-{os.getpid()}-{time.time_ns()}")[0]
             self._writer.assembler = _PartsAssembler(self._parts_dir / run, engine.comm.rank, world,
                                                      (engine.V, engine.d_full), engine.dtype)
+            self._writer.assembler.check_shared(engine.comm)
         return engine.stage_Z(pieces=True) if pieces else engine.stage_Z()
 
     @torch.no_grad()
@@ -253,21 +256,49 @@ class _PartsAssembler:
     """Several GPUs, one box: every rank's writer thread saves the part of Z it staged as a file in a directory
     they all see; rank 0's writer thread waits for the N parts of a sweep, puts them together (``place_piece``) and
     removes them.  No collective runs on a side thread, nothing runs on the sweep's stream."""
-    PATIENCE_S = 600.0
+    # how long rank 0 waits for another rank's part of one sweep (a rank that FAILS says so at once, see `fail`; this
+    # only bounds the wait for a rank that died without a word); CLANE_HISTORY_PATIENCE_S overrides
+    PATIENCE_S = float(os.environ.get("CLANE_HISTORY_PATIENCE_S", "120"))
 
     def __init__(self, parts_dir: Path, rank: int, world: int, shape, dtype: torch.dtype):
         self.dir, self.rank, self.world, self.shape, self.dtype = Path(parts_dir), rank, world, tuple(shape), dtype
         self.dir.mkdir(parents=True, exist_ok=True)
 
+    def check_shared(self, comm) -> None:
+        """All ranks must see ONE directory (one box, one file system): rank 0 drops a token, everybody looks for it.
+        Collective -- called once, on the sweep's thread, where the ranks are in step."""
+        token = self.dir / "shared.token"
+        if self.rank == 0:
+            token.write_text("clane")
+        comm.all_gather_object(self.rank)                   # rank 0 has written before anyone looks
+        seen = comm.all_gather_object(token.exists())
+        if self.rank == 0:
+            token.unlink()
+        if not all(seen):
+            raise RuntimeError(f"--save_history on several GPUs hands the ranks' parts of Z over through {self.dir}, which "
+                               f"ranks {[q for q, ok in enumerate(seen) if not ok]} do not see: the ranks must share a file "
+                               f"system (one box)")
+
     def _path(self, outer: int, sweep: int, rank: int) -> Path:
         return self.dir / f"o{outer}_s{sweep}.r{rank}.pt"
+
+    def fail(self, outer: int, sweep: int, exc: BaseException) -> None:
+        """This rank cannot deliver its part: leave a marker rank 0 finds at once instead of waiting out its patience."""
+        try:
+            self._path(outer, sweep, self.rank).with_suffix(".err").write_text(f"{type(exc).__name__}: {exc}")
+        except OSError:
+            pass
 
     def collect(self, outer: int, sweep: int, staged):
         """Save this rank's part; rank 0: the whole [V, d] matrix of that sweep, the other ranks: None."""
         mine = self._path(outer, sweep, self.rank)
         tmp = mine.with_suffix(".tmp")
-        torch.save(staged.piece(), tmp)
-        tmp.rename(mine)                        # a part is either absent or complete
+        try:
+            torch.save(staged.piece(), tmp)
+            tmp.rename(mine)                    # a part is either absent or complete
+        except BaseException as exc:
+            self.fail(outer, sweep, exc)
+            raise
         if self.rank != 0:
             return None
         from .engine import place_piece
@@ -276,8 +307,13 @@ class _PartsAssembler:
         for q in range(self.world):
             path = self._path(outer, sweep, q)
             while not path.exists():
+                marker = path.with_suffix(".err")
+                if marker.exists():
+                    raise RuntimeError(f"history: rank {q} could not deliver its part of round {outer} sweep {sweep}: "
+                                       f"{marker.read_text()}")
                 if time.monotonic() > deadline:
-                    raise TimeoutError(f"history: rank {q}'s part of round {outer} sweep {sweep} never arrived in {self.dir}")
+                    raise TimeoutError(f"history: rank {q}'s part of round {outer} sweep {sweep} never arrived in "
+                                       f"{self.dir} within {self.PATIENCE_S:.0f} s")
                 time.sleep(0.002)
             place_piece(Z, torch.load(path))
             path.unlink()

@@ -245,6 +245,7 @@ class Graph(torch.utils.data.Dataset):
     # free HBM at the time of the call)
     PLUGIN_CHUNK_BYTES = 1 << 30
     PLUGIN_SINGLE_CALL_MAX_BYTES = None
+    PLUGIN_EXCHANGE = "halo"        # division of an engine first created for a plug-in similarity (needs whole rows)
 
     def __init__(self, data_root: Path, embedding_dim: int = 128, dtype=None, cache: bool = False) -> None:
         """``dtype`` (extension, default None = keep what the files hold, as upstream): storage type of the
@@ -409,13 +410,30 @@ class Graph(torch.utils.data.Dataset):
             eng = self.engine(cosine_mode=similarity.mode)
             eng.build_P()
         else:
-            eng = self.engine()
-            if eng.world > 1:
-                raise NotImplementedError("custom similarity callables are supported on a single GPU only")
+            # Several GPUs: a plug-in needs WHOLE rows (all d columns of z_src and z_dst), so the rows are divided
+            # (halo tables: every row a rank's edges read is in its table) and each rank scores the edges of its own
+            # rows.  That is only the reference's single batched call (graph.py:120-121) when a pair's score does not
+            # depend on the other pairs of the batch -- the callable says so with `batchwise = True`; a batch-global
+            # measure would see 1/N of its batch on every rank and is refused.
+            eng = self.engine(exchange=self.PLUGIN_EXCHANGE) if self._engine is None else self.engine()
+            if eng.world > 1 and eng.columns:
+                raise NotImplementedError(
+                    f"custom similarity callables need whole rows of Z; this engine divides the COLUMNS over the GPUs "
+                    f"(exchange={eng.exchange!r}). Build the graph's engine with a row division first: "
+                    f"graph.engine(exchange='halo') (or 'allgather' / 'allgather_all'), CLI --exchange halo")
+            if eng.world > 1 and not getattr(similarity, "batchwise", False):
+                raise NotImplementedError(
+                    "on several GPUs every rank scores the edges of its own rows, so a custom similarity callable must "
+                    "score each pair independently of the rest of the batch and say so with `batchwise = True`; a "
+                    "batch-global measure (like the reference's CosineSimilarity, similarity.py:37) is supported on a "
+                    "single GPU only")
             rows = torch.repeat_interleave(torch.arange(eng.part.n_local, device=eng.device),
                                            eng.rowptr[1:] - eng.rowptr[:-1])
             Zd = eng.Zcur[:, :eng.d]
-            src_pos = torch.from_numpy(eng.part.local_positions()).to(eng.device)[rows]   # single GPU: RowPartition
+            # table row of every own row: a halo table starts with the own rows; a RowPartition places them
+            own_pos = (torch.arange(eng.part.n_local, device=eng.device) if eng.halo
+                       else torch.from_numpy(eng.part.local_positions()).to(eng.device))
+            src_pos = own_pos[rows]
             dst_pos = eng.colidx[:eng.E_loc].long()
             pair_bytes = 2 * eng.E_loc * eng.d * Zd.element_size()          # the two gathered [E, d] batches
             if getattr(similarity, "batchwise", False):

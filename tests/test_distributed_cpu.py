@@ -275,3 +275,70 @@ def test_column_ranks_of_different_width_share_one_edge_order(tmp_path):
     build_P all-reduces the partial dot products element by element."""
     mp.spawn(_uneven_columns_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
+
+
+class _ScaledDot:
+    """A plug-in similarity in the reference's protocol (similarity.py:5-7: a callable on [B, d] batches) whose score
+    for a pair does not depend on the rest of the batch."""
+    batchwise = True
+
+    def is_trainable(self):
+        return False
+
+    def __call__(self, v1, v2):
+        return (v1 * v2).sum(-1) / (1.0 + v1.pow(2).sum(-1).sqrt() * v2.pow(2).sum(-1).sqrt())
+
+
+def _plugin_worker(rank: int, world: int, port: int, out_dir: str, exchange: str):
+    sys.path.insert(0, str(ROOT))
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from clane_amd.embedder import Embedder
+        from clane_amd.engine import SweepEngine
+        from clane_amd.graph import Graph
+        from clane_amd.similarity import CosineSimilarity
+        from oracle import clane_oracle as O
+        from tests.conftest import load_golden, write_data_root
+        from tests.oracle_kernels import OracleKernels
+        gold, k = load_golden("g5_symkarate_d16_g0.76.npz"), load_golden("g2_karate_csr.npz")
+        root = write_data_root(Path(out_dir) / f"r{rank}", k["vertex_ids"], gold["edge_src"], gold["edge_dst"], gold["X"])
+        g = Graph(root)
+        g._attach_engine(SweepEngine(g.csr, g.X, "cpu", OracleKernels(), process_group=dist.group.WORLD, chunks=2, seed=3,
+                                     exchange=exchange))
+        sim = _ScaledDot()
+        if exchange == "columns":           # a plug-in needs whole rows
+            with pytest.raises(NotImplementedError, match="whole rows"):
+                g.build_P(sim)
+        else:
+            X = torch.from_numpy(gold["X"])
+            rowptr, colidx = g.csr.rowptr, g.csr.colidx
+            rows = torch.from_numpy(np.repeat(np.arange(len(g)), np.diff(rowptr)))
+            want = O.segment_softmax(rowptr, sim(X[rows], X[torch.from_numpy(colidx).long()]))
+            P = g.build_P(sim)              # every rank scores its own rows' edges; the result is the whole P everywhere
+            np.testing.assert_allclose(P.values().numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
+            with pytest.raises(NotImplementedError, match="batchwise"):      # a batch-global measure: one GPU only
+                g.build_P(lambda a, b: (a * b).sum(-1) / a.norm())
+            # and the whole loop on top of it: same embeddings as one process with the same plug-in
+            emb = Embedder(g, sim, torch.device("cpu"), gamma=0.5, tolerence=3, verbose=False)
+            emb.iterate()
+            Z = g.Z
+            if rank == 0:
+                g1 = Graph(root)
+                g1._attach_engine(SweepEngine(g1.csr, g1.X, "cpu", OracleKernels()))
+                Embedder(g1, sim, torch.device("cpu"), gamma=0.5, tolerence=3, verbose=False).iterate()
+                assert O.rel_l2(Z, g1.Z) < 1e-6
+        (Path(out_dir) / f"ok{rank}").write_text("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["halo", "allgather_all", "allgather", "columns"])
+def test_plugin_similarity_on_two_ranks(tmp_path, exchange):
+    """The reference's plug-in surface (__main__.py:39-48, graph.py:120-121) on several GPUs: with the rows divided,
+    every rank calls a `batchwise` plug-in on the edges of its own rows; batch-global callables and column-divided
+    engines are refused with a message that says what to do."""
+    mp.spawn(_plugin_worker, args=(2, _free_port(), str(tmp_path), exchange), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))

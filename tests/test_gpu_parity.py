@@ -1170,30 +1170,28 @@ def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
 
 def test_bench_north_star_row_partition_two_processes(tmp_path):
     """`bench.py --gpus 2 --exchange allgather_all`: north_star's literal plan -- node rows of Z divided over the
-    ranks, every rank holds the full Z, one in-place all-gather of the updated rows per sweep -- with two real
-    processes on this box's GPU (gloo standing in for RCCL): the first sweep matches the C oracle, the last delta
-    the one-process run's."""
+    ranks, every rank holds the full Z, one in-place all-gather of the updated rows per sweep -- as the MAIN division,
+    with two real processes on this box's GPU (gloo standing in for RCCL), and the live-rows form measured behind it
+    in the same run: the first sweep of each matches the C oracle, their last deltas each other's.  (The one-process
+    figures and the default flow are test_bench_two_processes_on_one_gpu_match_one_process's.)"""
     import json
     import subprocess
     import sys
     root = Path(__file__).resolve().parent.parent
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    # the division under test IS the main one: no further divisions behind it (--also-exchange none), two timed blocks
-    common = ["--workload", "tiny", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--host-sync", "every-sweep",
-              "--also-exchange", "none", "--blocks", "2", "--no-delta-stream-ab"]
-    one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"] + common, capture_output=True,
-                         text=True, timeout=600, cwd=root, env=env)
-    assert one.returncode == 0, one.stderr[-2000:]
-    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
-    for exchange in ("allgather_all", "allgather"):
-        two = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-                              "--exchange", exchange] + common, capture_output=True, text=True, timeout=600, cwd=root,
-                             env=env)
-        assert two.returncode == 0, two.stderr[-2000:]
-        r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
-        assert f"exchange={exchange} over RCCL per chunk" in r2["config"]["parallelism"] and r2["n_gpus"] == 2
-        assert r2["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
-        assert r2["last_delta"] == pytest.approx(r1["last_delta"], rel=5e-5)
+    two = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                          "--exchange", "allgather_all", "--also-exchange", "allgather", "--workload", "tiny", "--steps", "4",
+                          "--warmup", "2", "--blocks", "2", "--no-cpu-baseline", "--host-sync", "every-sweep",
+                          "--no-delta-stream-ab"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "exchange=allgather_all over RCCL per chunk" in r2["config"]["parallelism"] and r2["n_gpus"] == 2
+    assert r2["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and r2["comm"]["exchange_bytes_per_sweep"] > 0
+    live = r2["other_divisions"]["allgather"]
+    assert "exchange=allgather over RCCL per chunk" in live["parallelism"] and "error" not in live
+    assert live["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5
+    assert 0 < live["comm"]["exchange_bytes_per_sweep"] < r2["comm"]["exchange_bytes_per_sweep"]     # live rows only
+    assert live["last_delta"] == pytest.approx(r2["last_delta"], rel=5e-5)
 
 
 def test_bench_halo_p2p_two_processes_share_tables_through_ipc(tmp_path):
