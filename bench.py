@@ -237,7 +237,7 @@ def make_parser():
     ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
     ap.add_argument("--exchange", default="auto",
                     choices=["auto", "columns", "grid", "halo", "halo_p2p", "allgather", "allgather_all"],
-                    help="N > 1: auto = columns while a rank's row slice is >= 64 bytes, else grid / halo; columns = every GPU "
+                    help="N > 1: auto = columns while a rank's row slice is >= 64 bytes, else halo; columns = every GPU "
                          "holds d/N columns of every row, no exchange per sweep; grid = R row groups x C column groups "
                          "(--grid-cols C): row SLICES exchanged inside a column group; allgather_all = north_star's literal "
                          "plan: rows divided, one in-place RCCL all-gather of the updated rows per sweep; allgather = "
@@ -375,6 +375,63 @@ def generate_input(args, ranks: Ranks):
     return csr, X
 
 
+def run_sweeps(eng, args, pipelined: bool) -> float:
+    """Exactly args.steps sweeps the way the host loop runs them; returns the last delta."""
+    delta = float("nan")
+    if pipelined:
+        ticket = eng.sweep_launch(args.gamma)
+        for _ in range(args.steps - 1):
+            following = eng.sweep_launch(args.gamma)
+            delta = eng.sweep_wait(ticket)
+            ticket = following
+        return eng.sweep_wait(ticket)
+    for _ in range(args.steps):
+        delta = eng.sweep(args.gamma)
+    return delta
+
+
+def timed_blocks(eng, args, ranks: Ranks, pipelined: bool, n_blocks: int):
+    """`n_blocks` blocks of exactly args.steps sweeps, each bracketed by barrier + torch.cuda.synchronize() on both
+    sides (host clock, MAX over ranks) and by a HIP event pair on the sweep's stream.  Returns (wall seconds per block,
+    this rank's own seconds per block, HIP-event ms per block, last delta)."""
+    wall, local_wall, hip_ms = [], [], []
+    delta = float("nan")
+    for _ in range(n_blocks):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        delta = run_sweeps(eng, args, pipelined)
+        ev1.record()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        ranks.barrier()
+        elapsed = time.perf_counter() - t0
+        wall.append(ranks.max_over_ranks([elapsed])[0])
+        local_wall.append(mine)
+        hip_ms.append(ev0.elapsed_time(ev1))
+    return wall, local_wall, hip_ms, delta
+
+
+def delta_stream_ab(eng, args, ranks: Ranks, pipelined: bool, off_wall) -> dict:
+    """The same protocol once more with the delta's all-reduce on a stream of its own (SweepEngine(delta_stream=True)):
+    off by default because one rank cannot show whether it pays (profiles/r02_delta_stream_ab.md) -- a run between
+    real GPUs can, and this is where it says so.  `value` stays the default's."""
+    try:
+        eng.use_delta_stream(True)
+        for _ in range(3):
+            eng.sweep(args.gamma)
+        on, _, _, _ = timed_blocks(eng, args, ranks, pipelined, min(3, max(1, args.blocks)))
+        return {"off_ms_per_step": statistics.median(off_wall) / args.steps * 1e3,
+                "on_ms_per_step": statistics.median(on) / args.steps * 1e3,
+                "note": "on = the all-reduce of the delta and its copy to the host on a stream of their own "
+                        "(SweepEngine(delta_stream=True)); the record's value is the default (off)"}
+    except Exception as exc:            # noqa: BLE001 -- an extra; the measurement above stands
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    finally:
+        eng.use_delta_stream(False)
+
+
 def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bool):
     """Engine for `exchange`, build_P (timed on its second call), the parity sweep, warm-up, and the timed blocks.
     Returns a dict of everything measured (every rank gets the same numbers where they are reduced)."""
@@ -427,66 +484,9 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
     eng.kernel_events = []
     eng.time_collectives = ranks.grouped
     eng.collective_events = []
-    wall, local_wall, hip_ms = [], [], []
-    delta = float("nan")
-    for _ in range(max(1, args.blocks)):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ranks.barrier()
-        t0 = time.perf_counter()
-        ev0.record()
-        if pipelined:
-            ticket = eng.sweep_launch(args.gamma)
-            for _ in range(args.steps - 1):
-                following = eng.sweep_launch(args.gamma)
-                delta = eng.sweep_wait(ticket)
-                ticket = following
-            delta = eng.sweep_wait(ticket)
-        else:
-            for _ in range(args.steps):
-                delta = eng.sweep(args.gamma)
-        ev1.record()
-        torch.cuda.synchronize()
-        mine = time.perf_counter() - t0
-        ranks.barrier()
-        elapsed = time.perf_counter() - t0
-        wall.append(ranks.max_over_ranks([elapsed])[0])
-        local_wall.append(mine)
-        hip_ms.append(ev0.elapsed_time(ev1))
+    wall, local_wall, hip_ms, delta = timed_blocks(eng, args, ranks, pipelined, max(1, args.blocks))
     eng.time_kernels = eng.time_collectives = False
-    # The same protocol once more with the delta's all-reduce on a stream of its own (SweepEngine(delta_stream=True)):
-    # off by default because one rank cannot show whether it pays (profiles/r02_delta_stream_ab.md) -- a run between
-    # real GPUs can, and this is where it says so.  `value` stays the default's.
-    ab = None
-    if ranks.grouped and not args.no_delta_stream_ab:
-        try:
-            eng.use_delta_stream(True)
-            for _ in range(3):
-                eng.sweep(args.gamma)
-            on = []
-            for _ in range(min(3, max(1, args.blocks))):
-                ranks.barrier()
-                t0 = time.perf_counter()
-                if pipelined:
-                    ticket = eng.sweep_launch(args.gamma)
-                    for _ in range(args.steps - 1):
-                        following = eng.sweep_launch(args.gamma)
-                        eng.sweep_wait(ticket)
-                        ticket = following
-                    eng.sweep_wait(ticket)
-                else:
-                    for _ in range(args.steps):
-                        eng.sweep(args.gamma)
-                torch.cuda.synchronize()
-                ranks.barrier()
-                on.append(ranks.max_over_ranks([time.perf_counter() - t0])[0])
-            ab = {"off_ms_per_step": statistics.median(wall) / args.steps * 1e3,
-                  "on_ms_per_step": statistics.median(on) / args.steps * 1e3,
-                  "note": "on = the all-reduce of the delta and its copy to the host on a stream of their own "
-                          "(SweepEngine(delta_stream=True)); the record's value is the default (off)"}
-        except Exception as exc:            # noqa: BLE001 -- an extra; the measurement above stands
-            ab = {"error": f"{type(exc).__name__}: {exc}"}
-        finally:
-            eng.use_delta_stream(False)
+    ab = delta_stream_ab(eng, args, ranks, pipelined, wall) if (ranks.grouped and not args.no_delta_stream_ab) else None
     med = statistics.median(wall)
     out.update({
         "delta": delta, "elapsed": med, "value": args.steps / med, "ms_per_step": med / args.steps * 1e3,
@@ -610,21 +610,10 @@ def roofline_block(args, world, m) -> dict:
             "kernel_config": eng.kernel_config()}
 
 
-def main():
-    args = make_parser().parse_args()
-    unknown = [x for x in args.also_exchange.split(",") if x not in ("", "none", "columns", "grid", "halo", "halo_p2p",
-                                                                     "allgather", "allgather_all")]
-    if unknown:
-        raise SystemExit(f"--also-exchange: unknown division(s) {unknown}")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher: be the launcher
-        raise SystemExit(launch_ranks(args.gpus))
-    if os.environ.get("CLANE_BENCH_WATCHDOG_S"):                # debugging aid: every rank dumps its stack every S seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["CLANE_BENCH_WATCHDOG_S"]), repeat=True, file=sys.stderr)
-
+def start_ranks(args) -> Ranks:
+    """This process as one rank: device, process group (RCCL, or gloo for rehearsals), host threads."""
     import torch.distributed as dist
     from clane_amd import _hip
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -665,17 +654,13 @@ def main():
         else:
             dist.init_process_group("gloo", timeout=patience)
         pg = dist.group.WORLD
-    ranks = Ranks(world, rank, dev, pg, rehearsal=args.rehearse_rccl)
+    return Ranks(world, rank, dev, pg, rehearsal=args.rehearse_rccl)
 
+
+def main_record(args, ranks: Ranks, m, X, E) -> dict:
+    """The JSON line of the main division (the driver's contract + roofline; parity and baselines are added later)."""
     gen, V, _, d, dname, gseed, xseed = WORKLOADS[args.workload]
-    t0 = time.perf_counter()
-    csr, X = generate_input(args, ranks)
-    E = csr.num_edges
-    log(f"{args.workload}: |V|={V} |E|={E} d={d} max outdeg={int(np.diff(csr.rowptr).max())} "
-        f"generated in {time.perf_counter() - t0:.1f}s")
-
-    m = measure_division(args, ranks, csr, X, args.exchange, time_kernels=True)
-    eng = m["eng"]
+    eng, world = m["eng"], ranks.world
     result = {
         "metric": "embedding-update iters/sec (Jacobi sweeps of Z <- X + gamma*P*Z, P frozen)",
         "value": m["value"], "unit": "sweeps/s", "n_gpus": world, "steps": args.steps,
@@ -702,31 +687,138 @@ def main():
     if ranks.rehearsal:
         result["rehearsal"] = ("ONE rank in a real RCCL group with every collective issued (--rehearse-rccl): the N > 1 "
                                "flow through the real library; not a headline number")
+    return result
 
-    # ---- parity: the first GPU sweep (and P itself) against the C oracle, which builds its OWN P -------------
-    Z1_oracle = None
+
+def check_parity(args, ranks: Ranks, eng, m, csr, X, result):
+    """The first GPU sweep (and P itself) against the C oracle, which builds its OWN P; at N = 1 also the CPU
+    baselines (the oracle timed on this box's host cores).  Returns (the oracle's first sweep on rank 0, failed) -- the
+    verdict is all-reduced, so every rank leaves together."""
+    dname = WORKLOADS[args.workload][4]
+    Z1_oracle, failed = None, False
+    P_gpu = eng.P_global() if eng.row_world == 1 else None      # row splits: each rank holds its rows of P
+    if ranks.rank == 0:
+        from oracle import clane_oracle as O
+        from oracle import clane_oracle_c as OC
+        if ranks.world > 1:     # torchrun gives every rank OMP_NUM_THREADS=1; the others are idle in the collective below
+            OC.set_threads(os.cpu_count() or 1)
+        Z1_oracle, first, _, P_oracle, Xf = oracle_first_sweep(csr, X, None, args.gamma)
+        parity = O.rel_l2(m["Z1"].float(), Z1_oracle)
+        result["parity_rel_l2_vs_oracle_after_1_sweep"] = parity
+        result["parity_note"] = ("first sweep from Z = X on the GPU(s), P from the GPU build_P, against "
+                                 "oracle/clane_oracle.c running its own build_P and sweep")
+        failed = not parity < PARITY_TOL[dname]
+        if P_gpu is not None:
+            parity_p = O.rel_l2(P_gpu.float(), P_oracle)
+            result["parity_P_rel_l2_vs_oracle"] = parity_p
+            failed = failed or not parity_p < PARITY_P_TOL[dname]
+        if ranks.world == 1 and not ranks.rehearsal and not args.no_cpu_baseline and not failed:
+            result["cpu_baseline"] = cpu_baseline(csr, Xf, P_oracle, args.gamma, Z1_oracle, first)
+            result["cpu_baseline_torch"] = cpu_baseline_torch(csr, Xf, P_oracle, args.gamma)
+    return Z1_oracle, ranks.agree_to_fail(failed)
+
+
+def run_iterate(args, ranks: Ranks, eng, csr, X) -> dict:
+    """The WHOLE algorithm from Z = X on the engine just measured: Embedder.iterate() to tolerance."""
+    from clane_amd.embedder import Embedder
+    from clane_amd.graph import Graph
+    from clane_amd.similarity import CosineSimilarity
+    g = Graph.from_csr(csr, X)
+    eng.set_Z(X)
+    g._attach_engine(eng)
+    emb = Embedder(g, CosineSimilarity(), ranks.dev, gamma=args.gamma, tolerence=args.tolerence, verbose=False,
+                   max_sweeps=2000)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    emb.iterate()
+    ranks.barrier()
+    wall = time.perf_counter() - t0
+    return {"wall_s": wall, "outer_rounds": len(emb.sweep_counts), "sweeps": sum(emb.sweep_counts),
+            "sweeps_launched": emb.sweeps_launched,
+            "sweeps_per_round": emb.sweep_counts, "tolerence": args.tolerence,
+            "last_outer_delta": emb.outer_deltas[-1],
+            "note": "Embedder.iterate() from Z = X: build_P + propagate per round, reference "
+                    "stopping rule (embedder.py:56-108); sweeps whose delta is provably 0 (after an "
+                    "exactly-zero delta with P frozen) are counted, not launched; not part of the "
+                    "headline value"}
+
+
+DIVISION_NOTES = {
+    "allgather_all": "north_star's division: node rows of Z partitioned across the GPUs, every GPU holds the full Z, ONE "
+                     "in-place RCCL all-gather of the owned rows per sweep (per launch chunk, overlapped with the next "
+                     "chunk's kernels)",
+    "allgather": "the same row partition and in-place all-gather, of the rows that CAN change and ARE read only "
+                 "(outdeg > 0 and indeg > 0): rows without out-edges are never updated (embedder.py:88-89), rows nobody "
+                 "reads are synchronised once at the end",
+    "halo": "rows partitioned, each updated row sent only to the ranks that read it: one all_to_all_single per launch "
+            "chunk into a compact per-rank table",
+    "grid": "R row groups x C column groups: row slices exchanged (halo) among the ranks that hold the same columns, "
+            "partial dot products summed among the ranks that hold the same rows",
+}
+
+
+def division_block(args, ranks: Ranks, csr, X, E, exchange: str, main_division: str, main_value: float, Z1_oracle):
+    """One division measured AFTER the main one, as a block of the same record.  Returns (block, parity failed)."""
+    dname = WORKLOADS[args.workload][4]
+    block = {"exchange": exchange}
     failed = False
-    if not args.no_parity:
-        P_gpu = eng.P_global() if eng.row_world == 1 else None      # row splits: each rank holds its rows of P
-        if rank == 0:
+    try:
+        torch.cuda.empty_cache()
+        m2 = measure_division(args, ranks, csr, X, exchange, time_kernels=False)
+        e2 = m2.pop("eng")
+        block.update({
+            "what": DIVISION_NOTES.get(exchange, f"the same graph divided with exchange={exchange}"),
+            "value": m2["value"], "unit": "sweeps/s", "ms_per_step": m2["ms_per_step"],
+            "ms_per_step_min": m2["ms_per_step_min"], "ms_per_step_max": m2["ms_per_step_max"],
+            "ms_per_step_hip_events": m2["ms_per_step_hip_events"], "steps": args.steps,
+            "blocks": max(1, args.blocks), "build_P_ms": m2["build_P_ms"], "last_delta": m2["delta"],
+            "parallelism": describe_parallelism(args, ranks.world, e2, X, E),
+            "host_sync": "pipelined" if m2["pipelined"] else "after every sweep",
+            "vs_main_division": m2["value"] / main_value, "main_division": main_division,
+            "comm": comm_block(args, ranks, dict(m2, eng=e2))})
+        bad = False
+        if ranks.rank == 0 and Z1_oracle is not None and m2["Z1"] is not None:
             from oracle import clane_oracle as O
-            from oracle import clane_oracle_c as OC
-            if world > 1:           # torchrun gives every rank OMP_NUM_THREADS=1; the others are idle in the collective below
-                OC.set_threads(os.cpu_count() or 1)
-            Z1_oracle, first, _, P_oracle, Xf = oracle_first_sweep(csr, X, None, args.gamma)
-            parity = O.rel_l2(m["Z1"].float(), Z1_oracle)
-            result["parity_rel_l2_vs_oracle_after_1_sweep"] = parity
-            result["parity_note"] = ("first sweep from Z = X on the GPU(s), P from the GPU build_P, against "
-                                     "oracle/clane_oracle.c running its own build_P and sweep")
-            failed = not parity < PARITY_TOL[dname]
-            if P_gpu is not None:
-                parity_p = O.rel_l2(P_gpu.float(), P_oracle)
-                result["parity_P_rel_l2_vs_oracle"] = parity_p
-                failed = failed or not parity_p < PARITY_P_TOL[dname]
-            if world == 1 and not ranks.rehearsal and not args.no_cpu_baseline and not failed:
-                result["cpu_baseline"] = cpu_baseline(csr, Xf, P_oracle, args.gamma, Z1_oracle, first)
-                result["cpu_baseline_torch"] = cpu_baseline_torch(csr, Xf, P_oracle, args.gamma)
-        failed = ranks.agree_to_fail(failed)
+            block["parity_rel_l2_vs_oracle_after_1_sweep"] = O.rel_l2(m2["Z1"].float(), Z1_oracle)
+            bad = not block["parity_rel_l2_vs_oracle_after_1_sweep"] < PARITY_TOL[dname]
+        del e2, m2
+        if ranks.agree_to_fail(bad):
+            block["error"] = "parity check failed"
+            failed = True
+    except Exception as exc:        # noqa: BLE001 -- reported in the record; the main measurement stands
+        block["error"] = f"{type(exc).__name__}: {exc}"
+    return block, failed
+
+
+def main():
+    args = make_parser().parse_args()
+    unknown = [x for x in args.also_exchange.split(",") if x not in ("", "none", "columns", "grid", "halo", "halo_p2p",
+                                                                     "allgather", "allgather_all")]
+    if unknown:
+        raise SystemExit(f"--also-exchange: unknown division(s) {unknown}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # no launcher: be the launcher
+        raise SystemExit(launch_ranks(args.gpus))
+    if os.environ.get("CLANE_BENCH_WATCHDOG_S"):                # debugging aid: every rank dumps its stack every S seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CLANE_BENCH_WATCHDOG_S"]), repeat=True, file=sys.stderr)
+
+    import torch.distributed as dist
+    ranks = start_ranks(args)
+    rank = ranks.rank
+    V, d = WORKLOADS[args.workload][1], WORKLOADS[args.workload][3]
+    t0 = time.perf_counter()
+    csr, X = generate_input(args, ranks)
+    E = csr.num_edges
+    log(f"{args.workload}: |V|={V} |E|={E} d={d} max outdeg={int(np.diff(csr.rowptr).max())} "
+        f"generated in {time.perf_counter() - t0:.1f}s")
+
+    m = measure_division(args, ranks, csr, X, args.exchange, time_kernels=True)
+    eng = m["eng"]
+    result = main_record(args, ranks, m, X, E)
+
+    Z1_oracle, failed = None, False
+    if not args.no_parity:
+        Z1_oracle, failed = check_parity(args, ranks, eng, m, csr, X, result)
         if failed:                  # every rank leaves, non-zero, together
             if rank == 0:
                 print(json.dumps(result), flush=True)
@@ -734,33 +826,13 @@ def main():
                 dist.destroy_process_group()
             raise SystemExit(f"parity check failed: {result.get('parity_rel_l2_vs_oracle_after_1_sweep')} "
                              f"(P: {result.get('parity_P_rel_l2_vs_oracle')})")
-
     if args.iterate:
-        from clane_amd.embedder import Embedder
-        from clane_amd.graph import Graph
-        from clane_amd.similarity import CosineSimilarity
-        g = Graph.from_csr(csr, X)
-        eng.set_Z(X)
-        g._attach_engine(eng)
-        emb = Embedder(g, CosineSimilarity(), dev, gamma=args.gamma, tolerence=args.tolerence, verbose=False,
-                       max_sweeps=2000)
-        ranks.barrier()
-        t0 = time.perf_counter()
-        emb.iterate()
-        ranks.barrier()
-        wall = time.perf_counter() - t0
-        result["iterate"] = {"wall_s": wall, "outer_rounds": len(emb.sweep_counts), "sweeps": sum(emb.sweep_counts),
-                             "sweeps_launched": emb.sweeps_launched,
-                             "sweeps_per_round": emb.sweep_counts, "tolerence": args.tolerence,
-                             "last_outer_delta": emb.outer_deltas[-1],
-                             "note": "Embedder.iterate() from Z = X: build_P + propagate per round, reference "
-                                     "stopping rule (embedder.py:56-108); sweeps whose delta is provably 0 (after an "
-                                     "exactly-zero delta with P frozen) are counted, not launched; not part of the "
-                                     "headline value"}
+        result["iterate"] = run_iterate(args, ranks, eng, csr, X)
 
     # ---- north_star's literal division beside the default one, in the same record -----------------------------
     printed = threading.Event()
     lock = threading.Lock()
+    state = {"failed": False}
 
     def emit(extra=None):
         """Print the record once (rank 0).  `result` is only ever written under `lock`, so the copy that is dumped --
@@ -774,7 +846,6 @@ def main():
     also = [] if (args.also_exchange == "none" or not ranks.grouped or args.column_slice_of) else \
         [x for x in args.also_exchange.split(",") if x and x != eng.exchange
          and not (ranks.rehearsal and x not in ("columns", "allgather", "allgather_all"))]   # what ONE rank can be made to issue
-    timer = None
     if also:
         # Whatever happens in here, the main record above must come out: past the deadline (per division) every rank
         # prints / leaves on its own (a rank stuck in a collective cannot be talked to).
@@ -786,7 +857,7 @@ def main():
             if "north_star_literal" not in result:
                 extra["north_star_literal"] = {"exchange": "allgather_all"}
             emit(extra)
-            os._exit(1 if failed else 3)
+            os._exit(1 if state["failed"] else 3)
         # a safety copy for the logs: should a later division take the process down (a fault, an abort inside the
         # library), the measurement of the main division has been seen
         log("main division measured; the record so far (the ONE stdout line follows after the other divisions): "
@@ -794,46 +865,15 @@ def main():
         main_division, main_value = eng.exchange, m["value"]
         del m["eng"]
         eng = None                          # the first engine's tables go back to the allocator before the next is built
+        timer = None
         for exchange in also:
             if timer is not None:
                 timer.cancel()
             timer = threading.Timer(LITERAL_DEADLINE_S, give_up)
             timer.daemon = True
             timer.start()
-            block = {"exchange": exchange}
-            try:
-                torch.cuda.empty_cache()
-                m2 = measure_division(args, ranks, csr, X, exchange, time_kernels=False)
-                e2 = m2.pop("eng")
-                block.update({
-                    "what": {"allgather_all": "north_star's division: node rows of Z partitioned across the GPUs, every GPU "
-                                              "holds the full Z, ONE in-place RCCL all-gather of the owned rows per sweep (per "
-                                              "launch chunk, overlapped with the next chunk's kernels)",
-                             "allgather": "the same row partition and in-place all-gather, of the rows that CAN change and "
-                                          "ARE read only (outdeg > 0 and indeg > 0): rows without out-edges are never "
-                                          "updated (embedder.py:88-89), rows nobody reads are synchronised once at the end",
-                             "halo": "rows partitioned, each updated row sent only to the ranks that read it: one "
-                                     "all_to_all_single per launch chunk into a compact per-rank table"}.get(
-                                         exchange, f"the same graph divided with exchange={exchange}"),
-                    "value": m2["value"], "unit": "sweeps/s", "ms_per_step": m2["ms_per_step"],
-                    "ms_per_step_min": m2["ms_per_step_min"], "ms_per_step_max": m2["ms_per_step_max"],
-                    "ms_per_step_hip_events": m2["ms_per_step_hip_events"], "steps": args.steps,
-                    "blocks": max(1, args.blocks), "build_P_ms": m2["build_P_ms"], "last_delta": m2["delta"],
-                    "parallelism": describe_parallelism(args, world, e2, X, E),
-                    "host_sync": "pipelined" if m2["pipelined"] else "after every sweep",
-                    "vs_main_division": m2["value"] / main_value, "main_division": main_division,
-                    "comm": comm_block(args, ranks, dict(m2, eng=e2))})
-                bad = False
-                if rank == 0 and Z1_oracle is not None and m2["Z1"] is not None:
-                    from oracle import clane_oracle as O
-                    block["parity_rel_l2_vs_oracle_after_1_sweep"] = O.rel_l2(m2["Z1"].float(), Z1_oracle)
-                    bad = not block["parity_rel_l2_vs_oracle_after_1_sweep"] < PARITY_TOL[dname]
-                del e2, m2
-                if ranks.agree_to_fail(bad):
-                    block["error"] = "parity check failed"
-                    failed = True
-            except Exception as exc:        # noqa: BLE001 -- reported in the record; the main measurement stands
-                block["error"] = f"{type(exc).__name__}: {exc}"
+            block, bad = division_block(args, ranks, csr, X, E, exchange, main_division, main_value, Z1_oracle)
+            state["failed"] = state["failed"] or bad
             with lock:
                 if exchange == "allgather_all":
                     result["north_star_literal"] = block
@@ -846,13 +886,13 @@ def main():
         # leave together.  A rank that fell out of a block above on its own (an exception the others did not have)
         # must not wait for ever for ranks stuck in a collective: the record is out, so past this deadline just leave,
         # non-zero.
-        last = threading.Timer(LITERAL_DEADLINE_S, lambda: os._exit(1 if failed else 3))
+        last = threading.Timer(LITERAL_DEADLINE_S, lambda: os._exit(1 if state["failed"] else 3))
         last.daemon = True
         last.start()
         dist.barrier()
         last.cancel()
         dist.destroy_process_group()
-    if failed:
+    if state["failed"]:
         raise SystemExit("a division measured after the main one failed its parity check")
 
 

@@ -101,18 +101,25 @@ GRID_SLICE_ROW_BYTES = 128
 def pick_division(d: int, dtype: torch.dtype, world: int):
     """(exchange, column groups) for ``exchange="auto"``.  Column split while a rank's slice of a row is at least
     MIN_SLICE_ROW_BYTES (HBM is fetched in 64/128-byte lines: below that every gather drags in bytes of columns the rank
-    does not own -- measured on the 10M-vertex bf16 graph).  Narrower rows: the 2-D division -- the most
-    column groups C (a divisor of the world size) whose slices are still GRID_SLICE_ROW_BYTES wide, rows divided over
-    the world / C ranks of a column group with a halo exchange of row SLICES inside it; plain halo when even two
-    column groups are too many."""
+    does not own -- measured on the 10M-vertex bf16 graph); else divide the rows and exchange halo rows.
+    The 2-D division ("grid") is never picked here: on a fully connected fabric it loses to the halo division, because
+    the row exchange of a column group runs over R - 1 of a GPU's 7 links instead of all of them (config 4's shape at
+    N = 8, one rank's kernels and bytes measured, profiles/r04_rank_compute_grid_powerlaw10m.jsonl: halo 1.95 ms of
+    kernels + 175 MB per link; 4 x 2 grid 2.38 ms + 237 MB per link; 2 x 4 grid 3.51 ms + 290 MB on ONE link).  It stays
+    available by name for fabrics where links are shared (``grid_cols``; `grid_cols_for` suggests C)."""
     row_bytes = d * torch.empty(0, dtype=dtype).element_size()
     world = max(world, 1)
-    if row_bytes // world >= MIN_SLICE_ROW_BYTES:
-        return "columns", world
+    return ("columns", world) if row_bytes // world >= MIN_SLICE_ROW_BYTES else ("halo", 1)
+
+
+def grid_cols_for(d: int, dtype: torch.dtype, world: int) -> int:
+    """Column groups of ``exchange="grid"`` when the caller names none: the most (a proper divisor of the world size)
+    whose slices are still GRID_SLICE_ROW_BYTES wide; else the smallest proper divisor."""
+    row_bytes = d * torch.empty(0, dtype=dtype).element_size()
     for C in range(world - 1, 1, -1):
         if world % C == 0 and row_bytes // C >= GRID_SLICE_ROW_BYTES:
-            return "grid", C
-    return "halo", 1
+            return C
+    return next((c for c in range(2, world) if world % c == 0), world)
 
 
 def pick_exchange(d: int, dtype: torch.dtype, world: int) -> str:
@@ -192,7 +199,7 @@ class SweepEngine:
                  phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None,
                  grid_cols: Optional[int] = None):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
-        "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "grid" / "halo" (pick_division).
+        "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_division).
         "grid" -- both at once, for rows too narrow to cut N ways: the N ranks form R row groups x C column groups
         (``grid_cols`` = C; rank = r * C + c).  Rank (r, c) holds columns slice c of the rows of group r: the row
         exchange ("halo") runs among the R ranks that hold the same columns and moves SLICES of rows (1/C of the bytes),
@@ -253,9 +260,7 @@ class SweepEngine:
             grid_cols = grid_cols if grid_cols is not None else auto_cols
         if exchange == "grid" and divided:
             if grid_cols is None:
-                grid_cols = pick_division(int(X.shape[1]), X.dtype, self.world)[1]
-                grid_cols = grid_cols if 1 < grid_cols < self.world else next(
-                    (c for c in range(2, self.world) if self.world % c == 0), self.world)
+                grid_cols = grid_cols_for(int(X.shape[1]), X.dtype, self.world)
             if grid_cols < 1 or self.world % grid_cols:
                 raise ValueError(f"grid_cols={grid_cols} does not divide the {self.world} ranks")
             if grid_cols == self.world:         # one row group: that IS the column split
