@@ -71,6 +71,7 @@ SOFTMAX_EDGES_PER_WORKGROUP = 1 << 17     # build_P: edges of one class row that
 L2_BYTES_ALL_XCDS = 8 * 4 * 1024 * 1024
 MIN_HOT_READ_SHARE = 0.2
 HEAVY_ROW_EDGES = 4096
+UNSKEWED_LONG_THRESHOLD = 128
 
 
 def hot_read_share(csr: HostCSR, row_bytes: int) -> float:
@@ -365,6 +366,12 @@ class SweepEngine:
                 # with the class pass taking the rows above class_threshold, the 33..64-edge rows are better off with
                 # one wave each than with a 16-wave workgroup of which 15 waves leave at once (4.34 -> 4.30 ms)
                 long_threshold = max(long_threshold, self.class_threshold)
+            elif self.rows_per_wave == 1 and not self.class_affinity:
+                # evenly spread reads: no hubs for a lone wave to crawl along, and plenty of similar rows in flight --
+                # one wave per row up to UNSKEWED_LONG_THRESHOLD edges (near-regular 2M / 128M, rows of 48..80 edges:
+                # 23.4 ms with T = 32, 22.2 with 128 or 256; uniform and star-heavy graphs: no difference,
+                # profiles/r04_threshold_robustness.md)
+                long_threshold = max(long_threshold, UNSKEWED_LONG_THRESHOLD)
             if self.rows_per_wave > 1:
                 # A T-edge row walked by one sub-wave takes T/8 gather groups in sequence -- the tail of its launch.
                 # That is nothing next to a 40M-edge pass and a third of a 4M-edge one (R-MAT 200k/4M/d=128:

@@ -519,7 +519,7 @@ def test_class_pass_follows_the_read_skew():
     kern = OracleKernels()
     e_even = SweepEngine(even, X, "cpu", kernels=kern)
     assert not e_even.class_affinity and e_even.class_threshold == E.HEAVY_ROW_EDGES and e_even.class_rows[0] is None
-    assert e_even.long_threshold == E.LONG_THRESHOLD_BY_ROWS_PER_WAVE[1]        # 32: the row-split kernel takes 40..80
+    assert e_even.long_threshold == E.UNSKEWED_LONG_THRESHOLD                   # 128: no hubs, one wave per row (r04)
     e_skew = SweepEngine(skewed, X, "cpu", kernels=kern)
     assert e_skew.class_affinity and e_skew.class_threshold == 64 and e_skew.class_rows[0] is not None
     assert e_skew.long_threshold == 64

@@ -7,7 +7,7 @@
 # The raw traces stay in /tmp on the box (hundreds of MB); only the summaries and the bench lines come back.
 #   tools/profile_bench.sh <workload> <tag> [extra bench.py arguments]
 set -e
-W=${1:-rmat2m}; TAG=${2:-r03}; shift 2 || true
+W=${1:-rmat2m}; TAG=${2:-r04}; shift 2 || true
 KEY=${CLANE_PROFILE_KEY:-${W}_n1}        # name of the traffic.json entry (e.g. rmat2m_column_slice_of_8 with --column-slice-of 8)
 R="$(cd "$(dirname "$0")/.." && pwd)"
 RAW="/tmp/clane_prof_${TAG}_${W}"; rm -rf "$RAW"; mkdir -p "$RAW" "$R/gpurun_out/profiles"
