@@ -178,10 +178,18 @@ def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=12.0):
         probe, _, _, _ = timed(max(1, V // probe_rows), threads, 1)           # a small probe sizes the sample
         stride = 1 if probe * 2 <= budget_s else max(2, int(np.ceil(probe * 3 / budget_s)))
         per, share, n_rows, reps = timed(stride, threads, 10 if stride == 1 else 2)
-        what = (f"{reps} full sweeps (after 1 warm-up), best" if stride == 1 else
-                f"a random 1/{stride} of the rows ({n_rows} rows, {share:.1%} of the edges), best of {reps}, scaled to a "
-                f"whole sweep")
-        return per, what
+        if stride == 1:
+            return per, f"{reps} full sweeps (after 1 warm-up), best"
+        # A sample's time is not proportional to its edges alone (per-call costs that do not shrink with the sample --
+        # thread wake-ups, touching the whole of Z: seconds at 16M vertices -- would be multiplied by 1/share): time a
+        # second sample of half the size and take the line through the two, cost(E) = a + b * edges.
+        per2, share2, n_rows2, _ = timed(2 * stride, threads, 2)
+        t1, t2 = per * share, per2 * share2                     # the samples' own times
+        slope = max((t1 - t2) / max(share - share2, 1e-12), 0.0)
+        whole = max(t1 + slope * (1.0 - share), t1)
+        return whole, (f"two random row samples (1/{stride}: {n_rows} rows, {share:.1%} of the edges; 1/{2 * stride}: "
+                       f"{n_rows2} rows), best of {reps} each, extended linearly to a whole sweep (fixed per-call cost + "
+                       f"per-edge cost)")
 
     per_all, what_all = figure(all_threads, 20_000)
     per_1, what_1 = figure(1, 5_000)

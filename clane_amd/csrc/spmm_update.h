@@ -176,10 +176,9 @@ template <typename T, int VEC>
 __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC> &x, const Pack<T, VEC> &zo,
                                                                const typename Elem<T>::acc_t (&acc)[VEC],
                                                                typename Elem<T>::acc_t gamma, bool has_edges,
-                                                               T *__restrict__ dst, const Mirror<T> &mirror,
-                                                               int64_t row, int col, typename Elem<T>::acc_t &qsum) {
+                                                               T *__restrict__ dst, Pack<T, VEC> &out,
+                                                               typename Elem<T>::acc_t &qsum) {
     using A = typename Elem<T>::acc_t;
-    Pack<T, VEC> out;
     A rsum = A(0);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -191,11 +190,30 @@ __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC
         qsum = fma(stored, stored, qsum);
     }
     store_pack_stream<T, VEC>(dst, out);
-    if (mirror.row_ptr != nullptr) {
-        for (int64_t s = mirror.row_ptr[row]; s < mirror.row_ptr[row + 1]; ++s)
-            store_pack<T, VEC>(mirror.row(mirror.slot[s]) + col, out);
-    }
     return rsum;
+}
+
+// The further destinations of a finished row (Mirror above), stored by the GROUP lanes that cover the row TOGETHER: the
+// row's places are read with one coalesced load (lane j of the group takes place j) and handed round lane to lane, so
+// a row that goes to 7 readers costs one memory round trip before its stores, not a chain of 7 dependent ones (round
+// 4: every lane used to walk slot[row_ptr[r] ..] on its own, load after load).  EVERY lane of the group must call this
+// (`row` is uniform over the group); only `writer` lanes hold a pack and store it.  `base` = first lane of the group.
+template <typename T, int VEC, int GROUP>
+__device__ __forceinline__ void mirror_store(const Mirror<T> &mirror, int64_t row, int col, const Pack<T, VEC> &out,
+                                             bool writer, int group_lane, int base) {
+    if (mirror.row_ptr == nullptr) return;                       // kernel argument: uniform
+    const int64_t s0 = mirror.row_ptr[row], s1 = mirror.row_ptr[row + 1];
+    for (int64_t s = s0; s < s1; s += GROUP) {
+        const int n = s1 - s < GROUP ? int(s1 - s) : GROUP;
+        int32_t mine = 0;
+        if (group_lane < n) mine = mirror.slot[s + group_lane];
+        for (int j = 0; j < n; ++j) {
+            int32_t place;
+            if constexpr (GROUP == kWave) place = lane_get_uniform(mine, j);   // the whole wave works on one row
+            else place = lane_get(mine, base + j);
+            if (writer) store_pack<T, VEC>(mirror.row(place) + col, out);
+        }
+    }
 }
 
 #if CLANE_SPMM_MIN_WAVES > 0
@@ -279,7 +297,9 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
                 for (int k = 0; k < VEC; ++k) acc[k] = A(0);
                 gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
                 fold_subwaves<LPR>(acc);
-                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, mirror, r, c0, qsum);
+                Pack<T, VEC> out{};
+                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out, qsum);
+                mirror_store<T, VEC, kWave>(mirror, r, c0, out, writer, lane, 0);
             }
             rsum = group_sum<kWave>(rsum);
             if (lane == 0) s_rowsum[cur] = double(rsum);
@@ -378,7 +398,9 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
                 if (have) {
                     const int64_t r = row_begin + mine;
                     A rsum = A(0), qsum = A(0);
-                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0, qsum);
+                    Pack<T, VEC> out{};
+                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out, qsum);
+                    mirror_store<T, VEC, LPR>(mirror, r, c0, out, col_ok, sl, sub_base);   // the sub-wave's LPR lanes
                     rsum = group_sum<LPR>(rsum);
                     if (sl == 0) s_rowsum[mine] = double(rsum);
                     if (sq_out != nullptr) {
@@ -517,12 +539,16 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
             for (int k = 0; k < VEC; ++k) red[wave][lane][k] = acc[k];
         }
         __syncthreads();
-        if (writer) {
-            for (int w = 1; w < active; ++w) {
+        if (wave == 0) {
+            Pack<T, VEC> out{};
+            if (writer) {
+                for (int w = 1; w < active; ++w) {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
+                    for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
+                }
+                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out, qsum);
             }
-            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, mirror, r, c0, qsum);
+            mirror_store<T, VEC, kWave>(mirror, r, c0, out, writer, lane, 0);
         }
         if (t0 + LPR * VEC < d) __syncthreads();  // red[] is reused by the next column tile
     }
@@ -751,17 +777,21 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
             }
             __syncthreads();
         }
-        if (wave == 0 && ok) {
-            if constexpr (kCombineWaves > 1) {
+        if (wave == 0) {
+            Pack<T, VEC> out{};
+            if (ok) {
+                if constexpr (kCombineWaves > 1) {
 #pragma unroll
-                for (int w = 1; w < kCombineWaves; ++w) {
+                    for (int w = 1; w < kCombineWaves; ++w) {
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] += s_part[w - 1][lane][k];
+                        for (int k = 0; k < VEC; ++k) acc[k] += s_part[w - 1][lane][k];
+                    }
                 }
+                const Pack<T, VEC> x = load_pack_stream<T, VEC>(X + r * ldx + c0);
+                const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
+                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out, qsum);
             }
-            const Pack<T, VEC> x = load_pack_stream<T, VEC>(X + r * ldx + c0);
-            const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
-            rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, mirror, r, c0, qsum);
+            mirror_store<T, VEC, kWave>(mirror, r, c0, out, ok, lane, 0);
         }
     }
     if (wave == 0) {
