@@ -42,6 +42,7 @@ SIGNATURES = {
     "clane_spmm_split_slab_len": (_i64, [_i64, _i32]),
     "clane_spmm_class_slab_len": (_i64, [_i64, _i32]),
     "clane_device_alloc": (C.c_int, [_i64, C.POINTER(_p)]),
+    "clane_device_alloc_contiguous": (C.c_int, [_i64, C.POINTER(_p)]),
     "clane_device_free": (C.c_int, [_p]),
     "clane_ipc_export": (C.c_int, [_p, _p]),
     "clane_ipc_open": (C.c_int, [_p, C.POINTER(_p)]),
@@ -143,7 +144,10 @@ class DeviceBuffer:
     can map it (hipIpc works on allocation bases; torch sub-allocates) -- or such a mapping of another process's
     matrix (`DeviceBuffer.open`).  `.tensor` views it; torch neither owns nor frees it: this object does."""
 
-    def __init__(self, lib, shape, dtype: torch.dtype, device, _mapped_from: Optional[bytes] = None):
+    def __init__(self, lib, shape, dtype: torch.dtype, device, _mapped_from: Optional[bytes] = None,
+                 contiguous: bool = False):
+        """``contiguous``: physically contiguous backing (clane_device_alloc_contiguous); raises ClaneHipError when
+        the driver has no such range free -- the caller falls back to an ordinary allocation."""
         self.lib, self.shape, self.dtype = lib, tuple(int(x) for x in shape), dtype
         self.nbytes = max(16, int(torch.empty(0, dtype=dtype).element_size()) * int(torch.Size(self.shape).numel()))
         self.mapped = _mapped_from is not None
@@ -151,6 +155,8 @@ class DeviceBuffer:
         with torch.cuda.device(device):
             if self.mapped:
                 rc = lib.clane_ipc_open(_mapped_from, C.byref(ptr))
+            elif contiguous:
+                rc = lib.clane_device_alloc_contiguous(self.nbytes, C.byref(ptr))
             else:
                 rc = lib.clane_device_alloc(self.nbytes, C.byref(ptr))
         if rc != 0:
@@ -305,6 +311,8 @@ class KernelBackend(abc.ABC):
     @abc.abstractmethod
     def shareable_matrix(self, shape, dtype, device): ...
     @abc.abstractmethod
+    def contiguous_matrix(self, shape, dtype, device): ...
+    @abc.abstractmethod
     def open_shared_matrix(self, handle, shape, dtype, device): ...
 
     def bind(self, method: str, *args, **kwargs):
@@ -391,6 +399,10 @@ class HipKernels(KernelBackend):
 
     def reduce_ws_len(self) -> int:
         return int(self.lib.clane_reduce_ws_len())
+
+    def contiguous_matrix(self, shape, dtype: torch.dtype, device) -> DeviceBuffer:
+        """A zeroed matrix of its own, physically contiguous allocation (raises ClaneHipError when none is to be had)."""
+        return DeviceBuffer(self.lib, shape, dtype, device, contiguous=True)
 
     def shareable_matrix(self, shape, dtype: torch.dtype, device) -> DeviceBuffer:
         """Zero-filled device matrix that other processes can map (DeviceBuffer.export / .open)."""

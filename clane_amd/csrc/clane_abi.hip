@@ -500,6 +500,11 @@ int clane_device_alloc(int64_t bytes, void **ptr) {
     HIP_REQUIRE(hipMalloc(ptr, size_t(bytes)), "hipMalloc");
     return CLANE_OK;
 }
+int clane_device_alloc_contiguous(int64_t bytes, void **ptr) {
+    REQUIRE(bytes > 0 && ptr, "device_alloc_contiguous: bad arguments");
+    HIP_REQUIRE(hipExtMallocWithFlags(ptr, size_t(bytes), hipDeviceMallocContiguous), "hipExtMallocWithFlags(contiguous)");
+    return CLANE_OK;
+}
 int clane_device_free(void *ptr) {
     HIP_REQUIRE(hipFree(ptr), "hipFree");
     return CLANE_OK;

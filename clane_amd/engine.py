@@ -198,7 +198,7 @@ class SweepEngine:
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
                  phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None,
-                 grid_cols: Optional[int] = None):
+                 grid_cols: Optional[int] = None, table_alloc: str = "torch", fused_norms: bool = True):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_division).
         "grid" -- both at once, for rows too narrow to cut N ways: the N ranks form R row groups x C column groups
@@ -227,6 +227,12 @@ class SweepEngine:
         self.acc_dtype = _hip.acc_dtype(X.dtype)
         self.cosine_mode = cosine_mode
         self.table_skew = table_skew
+        if table_alloc not in ("torch", "contiguous"):
+            raise ValueError("table_alloc must be 'torch' or 'contiguous'")
+        self.table_alloc, self._own_tables, self.table_alloc_note = table_alloc, [], None
+        # K0 fused into K3 (the sweep's kernels leave every finished row's squared norm behind); False = the separate
+        # row_sqnorm pass of rounds 1-3 at every build_P (A/B: tools/fused_norms_ab.py)
+        self.fused_norms = bool(fused_norms)
         X = self._choose_division(csr, X, process_group, comm, exchange, grid_cols)
         self._choose_class_pass(csr, class_threshold, class_chunk, class_k1, class_phases, phase_threshold)
         self._build_layout(csr, chunks, shuffle, seed, hot_rows_first)
@@ -511,6 +517,13 @@ class SweepEngine:
         """One of the big [rows, ld] tables (Zbuf0 / Zbuf1 / X), zeroed.  ``table_skew`` = {tag: bytes} (experiments:
         tools/placement_probe.py) carves it out of a private allocation at that offset from a 2-MiB boundary."""
         skew = (self.table_skew or {}).get(tag)
+        if self.table_alloc == "contiguous":
+            try:        # physically contiguous backing: its own allocation, kept alive by this engine
+                buf = self.k.contiguous_matrix((rows, self.ld), self.dtype, self.device)
+                self._own_tables.append(buf)
+                return buf.tensor
+            except _hip.ClaneHipError as exc:               # no contiguous range free: an ordinary allocation will do
+                self.table_alloc_note = f"{tag}: {exc}"
         if skew is None or self.device.type != "cuda":
             return torch.zeros(rows, self.ld, dtype=self.dtype, device=self.device)
         es = torch.empty(0, dtype=self.dtype).element_size()
@@ -794,7 +807,7 @@ class SweepEngine:
         mode = _hip.SCORE_MODES[self.cosine_mode]
         busy = self.d > 0                   # a column-split rank without columns only joins the collectives
         sq = None
-        if not self.sq_valid:               # Z was loaded from outside (X, set_Z): K0 once, for every table's copy
+        if not self.sq_valid or not self.fused_norms:   # Z was loaded from outside (X, set_Z): K0 once, for every table's copy
             if busy:
                 for b in self.blocks:
                     k.row_sqnorm(self._zrows(Z, b), self.d, self.sq_pp[self.cur][self._rows(b)])
@@ -876,7 +889,7 @@ class SweepEngine:
                 rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
                 po = self.partial_off[i]
                 mir = self.mirrors_p2p[dst][i] if self.p2p else self.mirrors[i]
-                sq_new = self.sq_pp[dst][b.local_start:]           # the finished rows' norms go with Z_new
+                sq_new = self.sq_pp[dst][b.local_start:] if self.fused_norms else None   # the finished rows' norms go with Z_new
                 po_mid = po + k.spmm_partials_len(b.nrows, 0)
                 po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
                 po_split = po_hub + (0 if self.hub_rows[i] is None else self.hub_rows[i].numel())

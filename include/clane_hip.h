@@ -106,6 +106,11 @@ int64_t clane_reduce_ws_len(void);
  *   clane_ipc_open(handle, &ptr)   : map it (hipIpcMemLazyEnablePeerAccess); clane_ipc_close(ptr) unmaps. */
 #define CLANE_IPC_HANDLE_BYTES 64
 int clane_device_alloc(int64_t bytes, void **ptr);
+/* The same with PHYSICALLY CONTIGUOUS backing (hipExtMallocWithFlags, hipDeviceMallocContiguous): for the big gather
+ * tables -- a random row gather over a 2 GB table runs up to 7 % slower when the driver backs it with scattered pages
+ * (profiles/r04_placement_probe_*.jsonl).  Fails (CLANE_ERR_LAUNCH) when no contiguous range is free: fall back to
+ * clane_device_alloc.  Freed with clane_device_free. */
+int clane_device_alloc_contiguous(int64_t bytes, void **ptr);
 int clane_device_free(void *ptr);
 int clane_ipc_export(void *ptr, void *handle64);
 int clane_ipc_open(const void *handle64, void **ptr);

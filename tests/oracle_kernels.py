@@ -120,6 +120,9 @@ class OracleKernels(KernelBackend):
                 self.tensor, self.shape, self.dtype = torch.zeros(shape, dtype=dtype, device=device), tuple(shape), dtype
         return _Plain()
 
+    def contiguous_matrix(self, shape, dtype, device):
+        return self.shareable_matrix(shape, dtype, device)          # host memory: nothing to be contiguous about
+
     def _spmm_rows(self, rowptr, colidx, P, rows_sel, row0, Z_old, X, gamma, Z_new, d, mirror=None, sq_out=None):
         rp = _np(rowptr)
         acc = P.dtype

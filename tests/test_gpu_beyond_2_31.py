@@ -133,5 +133,5 @@ def test_more_than_2_31_edges():
             "delta": delta, "delta_oracle": delta_o, "oracle_threads": OC.threads(),
             **{k: round(v, 3) for k, v in clock.items()}}
     if LOG2_V >= 25:
-        (out / "r03_edges_beyond_2_31.json").write_text(json.dumps(line) + "\n")
+        (out / "r04_edges_beyond_2_31.json").write_text(json.dumps(line) + "\n")
     print(json.dumps(line), flush=True)

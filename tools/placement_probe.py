@@ -19,6 +19,8 @@ ap.add_argument("--graph", default="uniform", choices=["uniform", "star", "rmat"
 ap.add_argument("--steps", type=int, default=15)
 ap.add_argument("--blocks", type=int, default=5)
 ap.add_argument("--out", default=None)
+ap.add_argument("--contiguous", action="store_true",
+                help="also: the three big tables in physically contiguous allocations (SweepEngine(table_alloc='contiguous'))")
 args = ap.parse_args()
 dev = _hip.require_gpu("cuda:0")
 V = 2_000_000
@@ -67,7 +69,7 @@ def run(label, junk_mib=0, **kw):
     eng = SweepEngine(csr, X, dev, **kw)
     ptr = tables(eng)
     blocks = timed(eng)
-    rec = {"graph": args.graph, "label": label, "junk_mib": junk_mib, "skew": kw.get("table_skew"),
+    rec = {"graph": args.graph, "label": label, "table_alloc": eng.table_alloc, "table_alloc_note": eng.table_alloc_note, "junk_mib": junk_mib, "skew": kw.get("table_skew"),
            "ms_blocks": blocks, "ms_median": float(np.median(blocks)),
            "ptr": {k_: hex(v) for k_, v in ptr.items()},
            "mod_2MiB": {k_: v % (2 << 20) for k_, v in ptr.items()},
@@ -96,3 +98,7 @@ for name, skew in (("all aligned", {"Z0": 0, "Z1": 0, "X": 0}),
                    ("all aligned (again)", {"Z0": 0, "Z1": 0, "X": 0})):
     run(name, table_skew=skew)
 run("allocator (last)")
+if args.contiguous:
+    for i in range(6):
+        run(f"contiguous #{i}", table_alloc="contiguous")
+        run(f"torch again #{i}")
