@@ -67,7 +67,7 @@ for _s in ("f32", "f64", "bf16"):
     SIGNATURES[f"clane_edge_score_class_{_s}"] = (
         C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p])
     SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
-    SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p])
+    SIGNATURES[f"clane_l1_distance_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i64, _i32, _p, _p, _p, _p])
 for _s in ("f32", "f64"):
     SIGNATURES[f"clane_degree_weighted_sums_{_s}"] = (C.c_int, [_p, _p, _p, _i64, _p, _p, _p])
     SIGNATURES[f"clane_edge_score_finalize_{_s}"] = (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p])
@@ -302,7 +302,7 @@ class KernelBackend(abc.ABC):
     @abc.abstractmethod
     def reduce_partials(self, partials, n, ws, out): ...
     @abc.abstractmethod
-    def l1_distance(self, A, B, d, ws, out): ...
+    def l1_distance(self, A, B, d, ws, out, sq_a=None): ...
     @abc.abstractmethod
     def gather_rows(self, src, idx, d, dst): ...
     # further destinations of finished rows, tables other processes map
@@ -559,12 +559,13 @@ class HipKernels(KernelBackend):
                      _vec(partials, torch.float64, "partials"), n, _vec(ws, torch.float64, "ws"),
                      _vec(out, torch.float64, "out"), self._stream(out))
 
-    def l1_distance(self, A, B, d: int, ws, out):
+    def l1_distance(self, A, B, d: int, ws, out, sq_a: Optional[torch.Tensor] = None):
+        """out[0] = sum|A - B|; with `sq_a` also the squared norm of every row of A (bit for bit row_sqnorm's)."""
         ap, lda = _mat(A, "A")
         bp, ldb = _mat(B, "B")
         self._check(self._fn("clane_l1_distance", A.dtype)(
-            ap, lda, bp, ldb, A.shape[0], d, _vec(ws, torch.float64, "ws"), _vec(out, torch.float64, "out"),
-            self._stream(A)), "clane_l1_distance")
+            ap, lda, bp, ldb, A.shape[0], d, self._sq_arg(sq_a, A.dtype), _vec(ws, torch.float64, "ws"),
+            _vec(out, torch.float64, "out"), self._stream(A)), "clane_l1_distance")
 
     def gather_rows(self, src, idx, d: int, dst):
         """dst[i, :] = src[idx[i], :] (send-buffer packing of the halo exchange)."""

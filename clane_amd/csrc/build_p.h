@@ -174,10 +174,15 @@ __global__ __launch_bounds__(WAVES *kWave) void segment_softmax_long_kernel(cons
 }
 
 // ---- sum|A - B| (outer-loop delta, embedder.py:60) -------------------------------------------
+// sq_a != nullptr: also sq_a[r] = |A[r,:]|^2, accumulated exactly as row_sqnorm_kernel (K0) does -- lane l takes the
+// packs l, l + LPR, ..., one fma per element, the same butterfly -- so the pass that measures how far an outer round
+// moved Z also leaves the norms the NEXT build_P needs (similarity.py:37), bit for bit K0's, for no extra traffic: it
+// reads every row of A anyway.
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void l1_distance_kernel(const T *__restrict__ Am, int64_t lda,
                                                              const T *__restrict__ Bm, int64_t ldb, int64_t nrows,
-                                                             int d, double *__restrict__ ws) {
+                                                             int d, typename Elem<T>::acc_t *__restrict__ sq_a,
+                                                             double *__restrict__ ws) {
     using A = typename Elem<T>::acc_t;
     __shared__ double smem[kWavesPerBlock];
     constexpr int RPW = kWave / LPR;
@@ -188,15 +193,23 @@ __global__ __launch_bounds__(kBlock) void l1_distance_kernel(const T *__restrict
     double dsum = 0.0;
     for (int64_t base = wave * RPW; base < nrows; base += nwaves * RPW) {
         const int64_t r = base + sub;
-        if (r >= nrows) continue;
-        A s = A(0);
+        if (r >= nrows) continue;            // uniform over the LPR lanes of a row
+        A s = A(0), q = A(0);
         for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC) {
             const Pack<T, VEC> a = load_pack<T, VEC>(Am + r * lda + c0);
             const Pack<T, VEC> b = load_pack<T, VEC>(Bm + r * ldb + c0);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) s += fabs(Elem<T>::to_acc(a.v[k]) - Elem<T>::to_acc(b.v[k]));
+            for (int k = 0; k < VEC; ++k) {
+                const A av = Elem<T>::to_acc(a.v[k]);
+                s += fabs(av - Elem<T>::to_acc(b.v[k]));
+                q = fma(av, av, q);
+            }
         }
         dsum += double(s);
+        if (sq_a != nullptr) {               // kernel argument: uniform
+            q = group_sum<LPR>(q);
+            if (sl == 0) sq_a[r] = q;
+        }
     }
     const double t = block_sum_fixed(dsum, smem);
     if (threadIdx.x == 0) ws[blockIdx.x] = t;

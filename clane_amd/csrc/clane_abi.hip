@@ -397,17 +397,22 @@ int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0
 }
 
 template <typename T>
-int l1_distance(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows, int32_t d, double *ws, double *out,
-                void *stream) {
+int l1_distance(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows, int32_t d,
+                typename Elem<T>::acc_t *sq_a, double *ws, double *out, void *stream) {
     REQUIRE(nrows >= 0 && d > 0 && lda >= d && ldb >= d, "l1_distance: bad shape");
     REQUIRE(ws && out, "l1_distance: null workspace/output");
     REQUIRE(nrows == 0 || (A && B), "l1_distance: null pointer");
     const Layout L = pick_layout<T>(d, {A, B}, {lda, ldb});
+    if (sq_a != nullptr) {      // sq_a must be bit for bit row_sqnorm's, whose lane layout follows from A alone
+        const Layout LA = pick_layout<T>(d, {A}, {lda});
+        REQUIRE(LA.vec == L.vec && LA.lpr == L.lpr,
+                "l1_distance: sq_a needs B as aligned as A (the lane layout of row_sqnorm on A)");
+    }
     int grid = 1;
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         grid = grid_for_waves(ceil_div(nrows > 0 ? nrows : 1, kWave / LPR));
         if (grid > kReduceGrid) grid = kReduceGrid;
-        l1_distance_kernel<T, VEC, LPR><<<grid, kBlock, 0, (hipStream_t)stream>>>(A, lda, B, ldb, nrows, d, ws);
+        l1_distance_kernel<T, VEC, LPR><<<grid, kBlock, 0, (hipStream_t)stream>>>(A, lda, B, ldb, nrows, d, sq_a, ws);
     });
     reduce_fixed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ws, grid, grid, 1, out);
     return check_launch("l1_distance");
@@ -668,17 +673,17 @@ int clane_reduce_partials(const double *partials, int64_t n, double *ws, double 
 }
 
 int clane_l1_distance_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t nrows, int32_t d,
-                          double *ws, double *out, void *stream) {
-    return l1_distance<float>(A, lda, B, ldb, nrows, d, ws, out, stream);
+                          float *sq_a, double *ws, double *out, void *stream) {
+    return l1_distance<float>(A, lda, B, ldb, nrows, d, sq_a, ws, out, stream);
 }
 int clane_l1_distance_f64(const double *A, int64_t lda, const double *B, int64_t ldb, int64_t nrows, int32_t d,
-                          double *ws, double *out, void *stream) {
-    return l1_distance<double>(A, lda, B, ldb, nrows, d, ws, out, stream);
+                          double *sq_a, double *ws, double *out, void *stream) {
+    return l1_distance<double>(A, lda, B, ldb, nrows, d, sq_a, ws, out, stream);
 }
 int clane_l1_distance_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, int64_t nrows, int32_t d,
-                           double *ws, double *out, void *stream) {
+                           float *sq_a, double *ws, double *out, void *stream) {
     return l1_distance<bf16_t>(reinterpret_cast<const bf16_t *>(A), lda, reinterpret_cast<const bf16_t *>(B), ldb,
-                               nrows, d, ws, out, stream);
+                               nrows, d, sq_a, ws, out, stream);
 }
 
 int clane_gather_rows_f32(const float *src, int64_t lds, const int32_t *idx, int64_t n, int32_t d, float *dst,

@@ -198,7 +198,7 @@ class SweepEngine:
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
                  phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None,
-                 grid_cols: Optional[int] = None, table_alloc: str = "torch", fused_norms: bool = True):
+                 grid_cols: Optional[int] = None, table_alloc: str = "torch", fused_norms: bool = False):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_division).
         "grid" -- both at once, for rows too narrow to cut N ways: the N ranks form R row groups x C column groups
@@ -230,8 +230,13 @@ class SweepEngine:
         if table_alloc not in ("torch", "contiguous"):
             raise ValueError("table_alloc must be 'torch' or 'contiguous'")
         self.table_alloc, self._own_tables, self.table_alloc_note = table_alloc, [], None
-        # K0 fused into K3 (the sweep's kernels leave every finished row's squared norm behind); False = the separate
-        # row_sqnorm pass of rounds 1-3 at every build_P (A/B: tools/fused_norms_ab.py)
+        # Where build_P's row norms come from (similarity.py:37).  Always available: row_sqnorm (K0), a 2 GB pass over Z.
+        # In the outer loop (embedder.py:58-60) the pass that measures how far a round moved Z reads every row of the
+        # new Z anyway and leaves the norms behind (l1_between) -- free, and what Embedder.iterate() lives on.
+        # fused_norms=True: the K3 kernels leave them behind too (every sweep): build_P never runs K0 after the first,
+        # but every sweep pays ~1.2 % (measured on one box, interleaved: config 3 3.946 -> 3.991 ms per sweep for
+        # 0.34 ms per build_P, and a propagate runs >= 11 sweeps per build_P: a net loss, profiles/r04_fused_norms_ab.jsonl)
+        # -- hence off.
         self.fused_norms = bool(fused_norms)
         X = self._choose_division(csr, X, process_group, comm, exchange, grid_cols)
         self._choose_class_pass(csr, class_threshold, class_chunk, class_k1, class_phases, phase_threshold)
@@ -583,11 +588,10 @@ class SweepEngine:
         if self.device.type == "cuda" and (self.world > 1 or self._forced) and delta_stream:
             self._delta_stream = torch.cuda.Stream(self.device)
         self.block_out = torch.zeros(len(self.blocks), dtype=torch.float64, device=dev)
-        # |z_v|^2 of the owned rows, one copy per Z table: the K3 kernel that writes a row of Zbuf[p] also
-        # writes its norm to sq_pp[p] (K0 fused into K3's epilogue); rows without out-edges keep the value K0 gave them
-        # when Z was loaded (`sq_valid`).  build_P reads sq_pp[cur]: no pass over Z (similarity.py:37's two norms).
+        # |z_v|^2 of the owned rows, one copy per Z table, and whether it matches the table (`sq_ok`): written by K0 in
+        # build_P, by the outer-delta pass (l1_between) or -- fused_norms -- by the K3 kernels that write the table.
         self.sq_pp = [torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev) for _ in range(self.N_TABLES)]
-        self.sq_valid = False
+        self.sq_ok = [False] * self.N_TABLES
         self.sq_full: Optional[torch.Tensor] = None
         self.sweeps_done = 0
         # optional per-kernel timing with HIP events on the launch stream (bench.py)
@@ -691,7 +695,7 @@ class SweepEngine:
         for other in self.Zbuf[1:]:
             other.copy_(first)
         self.cur, self.hold, self._prev_cur = 0, None, 0
-        self.sq_valid = False
+        self.sq_ok = [False] * self.N_TABLES
         self.P_valid = False
         self.quiet_stale = False
         if self.p2p:        # nobody may store into a table that its owner is still loading
@@ -807,15 +811,18 @@ class SweepEngine:
         mode = _hip.SCORE_MODES[self.cosine_mode]
         busy = self.d > 0                   # a column-split rank without columns only joins the collectives
         sq = None
-        if not self.sq_valid or not self.fused_norms:   # Z was loaded from outside (X, set_Z): K0 once, for every table's copy
+        if not self.sq_ok[self.cur]:        # nobody has left this table's norms behind: K0
             if busy:
                 for b in self.blocks:
                     k.row_sqnorm(self._zrows(Z, b), self.d, self.sq_pp[self.cur][self._rows(b)])
-            for i in range(self.N_TABLES):
-                if i != self.cur:
-                    self.sq_pp[i].copy_(self.sq_pp[self.cur])
-            self.sq_valid = True
-        sq_own = self.sq_pp[self.cur]       # after a sweep: written by the K3 kernels, bit for bit what K0 would give
+            if self.fused_norms and not any(self.sq_ok):
+                # fresh from set_Z: all tables are alike, and the K3 kernels will only write the rows WITH out-edges
+                for i in range(self.N_TABLES):
+                    if i != self.cur:
+                        self.sq_pp[i].copy_(self.sq_pp[self.cur])
+                self.sq_ok = [True] * self.N_TABLES
+            self.sq_ok[self.cur] = True
+        sq_own = self.sq_pp[self.cur]       # K0's bits, whoever wrote them (tests: test_row_norms_are_bitwise_k0)
         if self.cosine_mode == "reference":
             k.degree_weighted_sums(sq_own, self.rowptr, self.indeg, part.n_local, self.ws, self.sums2)
             self._all_reduce(self.sums2)    # partial over the owned rows, or over the owned columns: a sum either way
@@ -1027,6 +1034,7 @@ class SweepEngine:
             if self._delta_ev is not None:
                 self._delta_ev[parity].record()
         self._prev_cur, self.cur = src, dst
+        self.sq_ok[dst] = self.fused_norms and self.sq_ok[src]   # the K3 kernels wrote its norms, or nobody did
         self.sweeps_done += 1
         self.quiet_stale = True
         return parity
@@ -1132,11 +1140,14 @@ class SweepEngine:
         self.hold = self.cur
 
     def l1_between(self, i: int, j: int) -> float:
-        """sum |Zbuf[i] - Zbuf[j]| over the owned rows, all ranks (embedder.py:60's reduction)."""
+        """sum |Zbuf[i] - Zbuf[j]| over the owned rows, all ranks (embedder.py:60's reduction).  The pass reads every
+        row of table i anyway, so it also leaves that table's row norms behind (sq_pp[i]: bit for bit K0's) -- the next
+        build_P of the outer loop starts without a pass over Z."""
         for n, b in enumerate(self.blocks):
             if self.d > 0:
                 self.k.l1_distance(self._zrows(self.Zbuf[i], b), self._zrows(self.Zbuf[j], b), self.d, self.ws,
-                                   self.block_out[n:n + 1])
+                                   self.block_out[n:n + 1], sq_a=self.sq_pp[i][self._rows(b)])
+        self.sq_ok[i] = True
         self.k.reduce_partials(self.block_out, len(self.blocks), self.ws, self.delta)
         self._all_reduce(self.delta)
         return float(self.delta.item())

@@ -39,7 +39,8 @@ extern "C" {
 #endif
 
 #define CLANE_ABI_VERSION 3 /* 2: + clane_build_info, clane_xcc_ids, clane_check_csr, clane_spmm_update_class_*, clane_edge_score_class_*
-                             * 3: every clane_spmm_update* takes `sq_out` (the finished rows' squared norms, K0 fused into K3) */
+                             * 3: every clane_spmm_update* takes `sq_out` (the finished rows' squared norms, K0 fused into K3),
+                             *    clane_l1_distance_* takes `sq_a` (the same from the outer-delta pass), clane_device_alloc_contiguous */
 
 #define CLANE_OK 0
 #define CLANE_ERR_INVALID_ARGUMENT (-1)
@@ -317,13 +318,16 @@ int clane_spmm_update_class_bf16(const int32_t *colidx, const float *P, const in
 int clane_reduce_partials(const double *partials, int64_t n, double *ws, double *out, void *stream);
 
 /* sum|A - B| over an [nrows, d] matrix pair -> out[0] (outer-loop delta, embedder.py:60).
+ * sq_a (accumulate type, [nrows]; NULL: not wanted): also |A[i,:]|^2 for every row, bit for bit what clane_row_sqnorm_*
+ * gives on A -- the pass reads every row of A anyway, so with A = the new embeddings the next build_P of the outer loop
+ * (embedder.py:59 after :60) gets its norms (similarity.py:37) for no extra traffic.
  * ws: clane_reduce_ws_len() doubles. */
 int clane_l1_distance_f32(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t nrows, int32_t d,
-                          double *ws, double *out, void *stream);
+                          float *sq_a, double *ws, double *out, void *stream);
 int clane_l1_distance_f64(const double *A, int64_t lda, const double *B, int64_t ldb, int64_t nrows, int32_t d,
-                          double *ws, double *out, void *stream);
+                          double *sq_a, double *ws, double *out, void *stream);
 int clane_l1_distance_bf16(const uint16_t *A, int64_t lda, const uint16_t *B, int64_t ldb, int64_t nrows, int32_t d,
-                           double *ws, double *out, void *stream);
+                           float *sq_a, double *ws, double *out, void *stream);
 
 /* dst[i,:] = src[idx[i],:] for i < n: packs the rows other ranks read into the send buffer of the
  * multi-GPU halo exchange (no counterpart in the single-process reference). */

@@ -210,9 +210,11 @@ class OracleKernels(KernelBackend):
     def reduce_partials(self, partials, n, ws, out):
         out[0] = partials[:n].sum()
 
-    def l1_distance(self, A, B, d, ws, out):
+    def l1_distance(self, A, B, d, ws, out, sq_a=None):
         acc = torch.float64 if A.dtype == torch.float64 else torch.float32
         out[0] = (A[:, :d].to(acc) - B[:, :d].to(acc)).abs().sum().double()
+        if sq_a is not None:
+            sq_a[:A.shape[0]] = A[:, :d].to(acc).pow(2).sum(1)
 
     def gather_rows(self, src, idx, d, dst):
         dst[:idx.numel(), :d] = src[idx.long(), :d]

@@ -318,7 +318,8 @@ def test_class_pass_random_engines(dev, case):
         mode = "per_edge" if case % 2 else "reference"
         phases, pt = int(rng.choice([1, 2, 4, 8])), int(rng.choice([2, 6, 20]))     # heavy rows phased in time as well
         eng = SweepEngine(csr, X, dev, chunks=1 if case % 4 else 3, hot_rows_first=bool(case % 3), cosine_mode=mode,
-                          class_threshold=ct, class_chunk=chunk, class_phases=phases, phase_threshold=pt)
+                          class_threshold=ct, class_chunk=chunk, class_phases=phases, phase_threshold=pt,
+                          fused_norms=bool(case % 2))
         tag = (f"case {case}: V={V} d={d} {dtype} class_threshold={ct} chunk={chunk} phases={phases}>{pt} "
                f"E={csr.num_edges} {mode}")
         assert sum(0 if c is None else c[0].numel() for c in eng.class_rows) == int((deg > ct).sum()), tag
@@ -338,7 +339,9 @@ def test_class_pass_random_engines(dev, case):
             assert delta == pytest.approx(float((got - Z).abs().sum()), rel=1e-5 if dtype != torch.bfloat16 else 2e-2,
                                           abs=1e-9), tag
             Z = got                                  # follow the GPU's (bf16-rounded) trajectory
-            assert_norms_are_k0s(eng, tag)
+            assert eng.sq_ok[eng.cur] == eng.fused_norms
+            if eng.fused_norms:                      # the K3 kernels left the new rows' norms behind
+                assert_norms_are_k0s(eng, tag)
         del eng
 
 
@@ -357,13 +360,15 @@ def assert_norms_are_k0s(eng, tag=""):
 @pytest.mark.parametrize("kw", [dict(), dict(class_threshold=0), dict(class_threshold=0, split_hubs=False, chunks=3),
                                 dict(class_threshold=16, class_chunk=64, chunks=2), dict(long_threshold=8, hub_threshold=40,
                                                                                          class_threshold=0)])
-def test_k3_row_norms_are_bitwise_k0(dev, dtype, d, kw):
-    """K0 fused into K3: after sweeps through every K3 kernel -- one (sub-)wave per row, 4- and 16-wave
-    rows, split hub rows + combine, class chunks + combine -- build_P's norms come from the sweep, not from a pass over Z,
-    and they are the same bits.  Also after set_Z (K0 itself runs once) and after a discarded launch."""
+def test_row_norms_are_bitwise_k0(dev, dtype, d, kw):
+    """build_P's row norms (similarity.py:37) come from K0 only when nobody has left them behind: the outer-delta pass
+    (l1_between: it reads every row of the new Z anyway) and -- fused_norms=True -- every K3 kernel (one (sub-)wave per
+    row, 4- and 16-wave rows, split hub rows + combine, class chunks + combine) leave norms that are the SAME BITS as
+    K0's on the table they belong to.  Also after set_Z (K0 itself runs once) and after a discarded launch."""
     csr = ragged_csr(5000, seed=11, max_deg=30, hubs=(4500, 700, 129, 65, 64, 5000, 300, 33))
     X = synth.gaussian_X(5000, d, seed=3).to(dtype)
-    eng = SweepEngine(csr, X, dev, **kw)
+    # ---- the K3 kernels' norms
+    eng = SweepEngine(csr, X, dev, fused_norms=True, **kw)
     eng.build_P()
     assert_norms_are_k0s(eng, "after load")
     for i in range(3):
@@ -379,13 +384,30 @@ def test_k3_row_norms_are_bitwise_k0(dev, dtype, d, kw):
     P_before = eng.P.clone()
     eng.build_P()                           # from the fused norms ...
     P_fused = eng.P.clone()
-    eng.sq_valid = False
+    eng.sq_ok[eng.cur] = False
     eng.build_P()                           # ... and from K0 over the same table: the same P, bit for bit
     assert torch.equal(P_fused, eng.P) and not torch.equal(P_before, P_fused)
     assert eng.distance_from_snapshot() > 0
     eng.set_Z(X.float() * 2)
     eng.build_P()
     assert_norms_are_k0s(eng, "after set_Z")
+    # ---- the default: the sweeps leave nothing behind, the outer-delta pass does (what Embedder.iterate() lives on)
+    eng = SweepEngine(csr, X, dev, **kw)
+    assert not eng.fused_norms
+    eng.build_P()
+    assert eng.sq_ok[eng.cur]
+    eng.snapshot()
+    for _ in range(2):
+        eng.sweep(0.7)
+    assert not eng.sq_ok[eng.cur]           # a sweep's destination starts without norms ...
+    moved = eng.distance_from_snapshot()
+    assert moved > 0 and eng.sq_ok[eng.cur]  # ... the outer-delta pass leaves them
+    assert_norms_are_k0s(eng, "after the outer-delta pass")
+    eng.build_P()
+    P_l1 = eng.P.clone()
+    eng.sq_ok[eng.cur] = False
+    eng.build_P()                           # K0 again: the same P, bit for bit
+    assert torch.equal(P_l1, eng.P)
 
 
 def test_spmm_row_block_with_row0_offset(dev, k):
@@ -643,7 +665,7 @@ def test_bf16_storage_end_to_end(tmp_path):
 def test_powerlaw_generator_and_bf16_sweep(dev):
     csr = synth.powerlaw_csr(100_000, 2_000_000, seed=5)
     deg = np.diff(csr.rowptr)
-    assert 1_800_000 < csr.num_edges <= 2_000_000 and deg.max() > 1000 and (np.diff(csr.colidx.astype(np.int64))[
+    assert csr.num_edges == 2_000_000 and deg.max() > 1000 and (np.diff(csr.colidx.astype(np.int64))[
         np.diff(np.repeat(np.arange(100_000), deg)) == 0] > 0).all()          # sorted, unique within rows
     X = synth.gaussian_X(100_000, 128, seed=6).to(torch.bfloat16)
     eng = SweepEngine(csr, X, dev)

@@ -21,7 +21,7 @@ CASES = [
     ("uniform 2M/40M d=256 fp32", lambda: synth.uniform_random_csr(2_000_000, 40_000_000, device=str(dev)), 256, torch.float32),
     ("uniform 8M/400M d=32 fp32 (128-byte rows, the shape of the 2^31-edge test)",
      lambda: synth.uniform_random_csr(8_000_000, 400_000_000, device=str(dev)), 32, torch.float32),
-    ("power-law 10M/198M d=128 bf16 (config 4's shape)", lambda: synth.powerlaw_csr(10_000_000, 200_000_000, seed=5, device=str(dev)), 128,
+    ("power-law 10M/200M d=128 bf16 (config 4's shape)", lambda: synth.powerlaw_csr(10_000_000, 200_000_000, seed=5, device=str(dev)), 128,
      torch.bfloat16),
 ]
 
