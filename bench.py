@@ -126,8 +126,8 @@ def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=12.0):
     """The PyTorch-CPU restatement SURVEY 8d names --  Z = X + gamma * (P @ Z)  plus the L1 delta, as in
     oracle/clane_oracle.py:sweep -- with P as a torch.sparse_csr_tensor (its CPU kernel is parallel over rows; the COO
     form of torch.sparse.mm is not: 0.127 sweeps/s on 128 threads against 0.130 on one in round 2), on all host
-    threads and on ONE thread.  FULL sweeps (1 warm-up + up to 10 timed, at least one) whenever a warm-up and one timed
-    sweep fit the budget (config 3 on all threads: ~4 s a sweep -- it does; SURVEY 8d asks for full sweeps); else a bounded
+    threads and on ONE thread.  FULL sweeps (1 warm-up + up to 10 timed, at least one) whenever the estimate of one sweep
+    fits the budget (config 3 on all threads: ~4 s a sweep -- it does; SURVEY 8d asks for full sweeps); else a bounded
     SAMPLE of the workload, a seeded random 1/m of the rows (same degree mix; every m-th row would not do: R-MAT's hubs
     sit on the ids with trailing zero bits), scaled by the share of the edges the sample holds -- `sample` says which."""
     import warnings
@@ -176,7 +176,9 @@ def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=12.0):
 
     def figure(threads, probe_rows):
         probe, _, _, _ = timed(max(1, V // probe_rows), threads, 1)           # a small probe sizes the sample
-        stride = 1 if probe * 2 <= budget_s else max(2, int(np.ceil(probe * 3 / budget_s)))
+        # the probe (a small sample, scaled) over-estimates: its per-call costs are scaled too.  Full sweeps whenever
+        # the ESTIMATE of one fits the budget (config 3, all threads: estimated 4-7 s, really 3.5 s)
+        stride = 1 if probe <= budget_s else max(2, int(np.ceil(probe * 3 / budget_s)))
         per, share, n_rows, reps = timed(stride, threads, 10 if stride == 1 else 2)
         if stride == 1:
             return per, f"{reps} full sweeps (after 1 warm-up), best"

@@ -1122,7 +1122,7 @@ class SweepEngine:
                 "class_affinity": self.class_affinity, "mega_segment_edges": self.mega_segment_edges,
                 "class_items_per_block": [c[6] for c in self.class_rows if c is not None][:1],
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange,
-                "grid": [self.R, self.C] if self.grid else None}
+                "grid": [self.R, self.C] if self.grid else None, "fused_norms": self.fused_norms}
 
     def exchange_bytes_per_sweep(self) -> int:
         """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""
