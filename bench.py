@@ -183,17 +183,24 @@ def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=12.0):
         if stride == 1:
             return per, f"{reps} full sweeps (after 1 warm-up), best"
         # A sample's time is not proportional to its edges alone (per-call costs that do not shrink with the sample --
-        # thread wake-ups, touching the whole of Z: seconds at 16M vertices -- would be multiplied by 1/share): time a
-        # second sample of half the size and take the line through the two, cost(E) = a + b * edges.
-        per2, share2, n_rows2, _ = timed(2 * stride, threads, 2)
-        t1, t2 = per * share, per2 * share2                     # the samples' own times
-        if t1 > t2 and share > share2:
-            whole = t1 + (t1 - t2) / (share - share2) * (1.0 - share)
-        else:                                                   # noise beats the difference: plain proportional scaling
-            whole = per
-        return whole, (f"two random row samples (1/{stride}: {n_rows} rows, {share:.1%} of the edges; 1/{2 * stride}: "
-                       f"{n_rows2} rows), best of {reps} each, extended linearly to a whole sweep (fixed per-call cost + "
-                       f"per-edge cost)")
+        # thread wake-ups, touching the whole of Z: seconds at 16M vertices -- would be multiplied by 1/share): grow the
+        # sample until it takes a real share of the budget, then take the line through the two largest samples,
+        # cost(E) = a + b * edges.
+        samples = [(share, per * share, n_rows, stride)]
+        while samples[-1][1] < budget_s / 6 and stride > 2 and len(samples) < 4:
+            stride = max(2, stride // 4)
+            per_n, share_n, rows_n, _ = timed(stride, threads, 2)
+            samples.append((share_n, per_n * share_n, rows_n, stride))
+        (s1, t1, r1, st1) = samples[-1]
+        if len(samples) > 1 and t1 > samples[-2][1] and s1 > samples[-2][0]:
+            s0, t0 = samples[-2][0], samples[-2][1]
+            whole = t1 + (t1 - t0) / (s1 - s0) * (1.0 - s1)
+            how = "the line through the two largest samples (fixed per-call cost + per-edge cost)"
+        else:
+            whole = t1 / s1
+            how = "scaled by the share of the edges it holds"
+        return whole, (f"random row samples, the largest 1/{st1} of the rows ({r1} rows, {s1:.1%} of the edges), best of 2 "
+                       f"each, extended to a whole sweep by {how}")
 
     per_all, what_all = figure(all_threads, 20_000)
     per_1, what_1 = figure(1, 5_000)

@@ -78,7 +78,7 @@ def test_torch_baseline_sampled_and_full(monkeypatch):
     P = O.build_P_values(csr.rowptr, csr.colidx, X)
     out = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=0.001)     # tiny budget: forces row sampling
     assert out["kind"] == "port" and out["cores"] == torch.get_num_threads() and out["one_thread"]["cores"] == 1
-    assert "sparse_csr_tensor" in out["sample"] and "random row samples (1/" in out["sample"]
+    assert "sparse_csr_tensor" in out["sample"] and "random row samples, the largest 1/" in out["sample"]
     full_run = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=20.0)
     assert "full sweeps" in full_run["sample"] and "full sweeps" in full_run["one_thread"]["sample"]
     with warnings.catch_warnings():
