@@ -1408,3 +1408,20 @@ def test_lane_xor_exchanges_on_the_card(tmp_path):
                     "-o", str(exe), str(src)], check=True, timeout=300)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "lane_xor check: 0 mismatches" in out.stdout, out.stdout + out.stderr
+
+
+def test_tables_in_contiguous_allocations(dev):
+    """SweepEngine(table_alloc="contiguous"): the Z tables and X in physically contiguous allocations of their own
+    (clane_device_alloc_contiguous) -- an experiment's knob (profiles/r04_placement_probe_box4_contiguous.jsonl), but a
+    product option: same results bit for bit, the allocations live as long as the engine, an unknown choice is refused."""
+    csr = synth.rmat_csr(20_000, 200_000, seed=7)
+    X = synth.gaussian_X(20_000, 64, seed=8)
+    a, b = SweepEngine(csr, X, dev), SweepEngine(csr, X, dev, table_alloc="contiguous")
+    assert len(b._own_tables) == SweepEngine.N_TABLES + 1 or b.table_alloc_note is not None   # or the driver had no such range
+    for eng in (a, b):
+        eng.build_P()
+        for _ in range(3):
+            eng.sweep(0.76)
+    assert torch.equal(a.get_Z(), b.get_Z()) and torch.equal(a.P, b.P)
+    with pytest.raises(ValueError, match="table_alloc"):
+        SweepEngine(csr, X, dev, table_alloc="pinned")
