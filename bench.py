@@ -191,14 +191,17 @@ def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=12.0):
             stride = max(2, stride // 4)
             per_n, share_n, rows_n, _ = timed(stride, threads, 2)
             samples.append((share_n, per_n * share_n, rows_n, stride))
-        (s1, t1, r1, st1) = samples[-1]
-        if len(samples) > 1 and t1 > samples[-2][1] and s1 > samples[-2][0]:
-            s0, t0 = samples[-2][0], samples[-2][1]
+        if len(samples) == 1:               # the first sample was big enough: a second one of half the size for the line
+            per_n, share_n, rows_n, _ = timed(2 * stride, threads, 2)
+            samples.insert(0, (share_n, per_n * share_n, rows_n, 2 * stride))
+        (s0, t0, _, _), (s1, t1, r1, st1) = samples[-2], samples[-1]
+        if t1 > t0 and s1 > s0:
             whole = t1 + (t1 - t0) / (s1 - s0) * (1.0 - s1)
             how = "the line through the two largest samples (fixed per-call cost + per-edge cost)"
-        else:
-            whole = t1 / s1
-            how = "scaled by the share of the edges it holds"
+        else:                               # the per-call cost drowns the difference: no slope to extend
+            whole = max(t1, t0)
+            how = ("NOTHING: the two samples took the same time (a per-call cost that does not shrink with the sample), so "
+                   "this is a LOWER bound of a sweep's time, i.e. an upper bound of sweeps/s")
         return whole, (f"random row samples, the largest 1/{st1} of the rows ({r1} rows, {s1:.1%} of the edges), best of 2 "
                        f"each, extended to a whole sweep by {how}")
 
