@@ -286,14 +286,18 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
     const Mirror<T> mir = make_mirror<T>(mirror);
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
-        if constexpr (LPR < kWave && VEC > 1)      // short rows of narrow matrices: one sub-wave per row
-            spmm_update_subrow_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-                rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, sq_out, delta_partials);
-        else
-            spmm_update_kernel<T, PT, VEC, LPR, U><<<grid, kBlock, 0, (hipStream_t)stream>>>(
-                rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, sq_out, delta_partials);
+        auto launch = [&]<bool MIRRORED>() {          // the mirrored instances prefetch a row's places (spmm_update.h)
+            if constexpr (LPR < kWave && VEC > 1)      // short rows of narrow matrices: one sub-wave per row
+                spmm_update_subrow_kernel<T, PT, VEC, LPR, U, MIRRORED><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+                    rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
+                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, sq_out, delta_partials);
+            else
+                spmm_update_kernel<T, PT, VEC, LPR, U, MIRRORED><<<grid, kBlock, 0, (hipStream_t)stream>>>(
+                    rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
+                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, sq_out, delta_partials);
+        };
+        if (mir.row_ptr != nullptr) launch.template operator()<true>();
+        else launch.template operator()<false>();
     });
     return check_launch("spmm_update");
 }

@@ -216,13 +216,46 @@ __device__ __forceinline__ void mirror_store(const Mirror<T> &mirror, int64_t ro
     }
 }
 
+// The same with the row's first GROUP places PREFETCHED: the row kernels know a row's place count when they claim the
+// row (the block's slice of mirror.row_ptr sits in LDS beside its rowptr slice) and request the places then (`mine`:
+// lane j of the group holds place j), so they arrive under the row's gathers and the finished row is stored without a
+// single memory round trip of its own -- on one rank's halo kernels at N = 8 the two dependent loads per row (row_ptr,
+// then slot) were 0.56 ms of a 1.36 ms pass (profiles/r04_rank_compute_halo_variants.jsonl).  Places beyond GROUP
+// (more readers than lanes: never with <= 8 GPUs) take the loop above.
+template <typename T, int VEC, int GROUP>
+__device__ __forceinline__ void mirror_store_prefetched(const Mirror<T> &mirror, int64_t m0, int64_t m1, int32_t mine,
+                                                        int col, const Pack<T, VEC> &out, bool writer, int group_lane,
+                                                        int base) {
+    if (mirror.row_ptr == nullptr) return;                       // kernel argument: uniform
+    const int n = m1 - m0 < GROUP ? int(m1 - m0) : GROUP;
+    for (int j = 0; j < n; ++j) {
+        int32_t place;
+        if constexpr (GROUP == kWave) place = lane_get_uniform(mine, j);
+        else place = lane_get(mine, base + j);
+        if (writer) store_pack<T, VEC>(mirror.row(place) + col, out);
+    }
+    for (int64_t s = m0 + GROUP; s < m1; s += GROUP) {           // the rest, if any, the plain way
+        const int k = m1 - s < GROUP ? int(m1 - s) : GROUP;
+        int32_t more = 0;
+        if (group_lane < k) more = mirror.slot[s + group_lane];
+        for (int j = 0; j < k; ++j) {
+            int32_t place;
+            if constexpr (GROUP == kWave) place = lane_get_uniform(more, j);
+            else place = lane_get(more, base + j);
+            if (writer) store_pack<T, VEC>(mirror.row(place) + col, out);
+        }
+    }
+}
+
 #if CLANE_SPMM_MIN_WAVES > 0
 #define CLANE_SPMM_BOUNDS __launch_bounds__(kBlock, CLANE_SPMM_MIN_WAVES)
 #else
 #define CLANE_SPMM_BOUNDS __launch_bounds__(kBlock)
 #endif
 
-template <typename T, typename PT, int VEC, int LPR, int U>
+// MIRRORED: compiled in only for launches that have a mirror (multi-GPU halo / p2p): the prefetched places cost
+// registers (the bf16 sub-wave instance would drop from 5 to 4 waves per SIMD) that a one-GPU sweep must not pay.
+template <typename T, typename PT, int VEC, int LPR, int U, bool MIRRORED>
 __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
@@ -231,6 +264,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
+    __shared__ int64_t s_mptr[MIRRORED ? kMaxRowsPerBlock + 1 : 1];   // the block's slice of mirror.row_ptr
     __shared__ double s_rowsum[kMaxRowsPerBlock];
     __shared__ int s_next;
     __shared__ int s_done;
@@ -242,13 +276,26 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     const int64_t row_begin = int64_t(blockIdx.x) * rows_per_block;
     const int nb = int((row_begin + rows_per_block < nrows ? row_begin + rows_per_block : nrows) - row_begin);
 
-    for (int i = threadIdx.x; i <= nb; i += kBlock) s_rowptr[i] = rowptr[row_begin + i];
+    for (int i = threadIdx.x; i <= nb; i += kBlock) {
+        s_rowptr[i] = rowptr[row_begin + i];
+        if constexpr (MIRRORED) s_mptr[i] = mirror.row_ptr[row_begin + i];
+    }
     for (int i = threadIdx.x; i < nb; i += kBlock) s_rowsum[i] = 0.0;
     if (threadIdx.x == 0) {
         s_next = kWavesPerBlock;
         s_done = 0;
     }
     __syncthreads();
+    // a row's first 64 mirror places, requested when the row is claimed (lane j: place j)
+    auto places_of = [&]([[maybe_unused]] int row, [[maybe_unused]] int64_t &m0, [[maybe_unused]] int64_t &m1) -> int32_t {
+        if constexpr (MIRRORED) {
+            m0 = s_mptr[row];
+            m1 = s_mptr[row + 1];
+            return lane < m1 - m0 ? mirror.slot[m0 + lane] : 0;
+        } else {
+            return 0;
+        }
+    };
 
     // next row of this block for the calling wave (wave-uniform)
     auto claim = [&]([[maybe_unused]] int prev) -> int {
@@ -262,16 +309,19 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     };
 
     int cur = wave;
-    int64_t e0 = 0, e1 = 0;
+    int64_t e0 = 0, e1 = 0, m0 = 0, m1 = 0;
+    int32_t places = 0;
     EdgeChunk<A> ch{0, A(0)};
     if (cur < nb) {
         e0 = s_rowptr[cur];
         e1 = s_rowptr[cur + 1];
         ch = load_chunk<A, PT>(colidx, P, e0, e1);
+        places = places_of(cur, m0, m1);
     }
     while (cur < nb) {
         const int nxt = claim(cur);
-        int64_t n0 = 0, n1 = 0;
+        int64_t n0 = 0, n1 = 0, mn0 = 0, mn1 = 0;
+        int32_t places_n = 0;
         EdgeChunk<A> chn{0, A(0)};
         if (nxt < nb) {
             n0 = s_rowptr[nxt];
@@ -279,6 +329,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
 #if CLANE_SPMM_PREFETCH
             chn = load_chunk<A, PT>(colidx, P, n0, n1);
 #endif
+            places_n = places_of(nxt, mn0, mn1);
         }
         if (!(long_threshold > 0 && e1 - e0 > long_threshold) && !(skip_sinks && e1 == e0)) {
             const int64_t r = row_begin + cur;
@@ -299,7 +350,8 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
                 fold_subwaves<LPR>(acc);
                 Pack<T, VEC> out{};
                 if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out, qsum);
-                mirror_store<T, VEC, kWave>(mirror, r, c0, out, writer, lane, 0);
+                if constexpr (MIRRORED)
+                    mirror_store_prefetched<T, VEC, kWave>(mirror, m0, m1, places, c0, out, writer, lane, 0);
             }
             rsum = group_sum<kWave>(rsum);
             if (lane == 0) s_rowsum[cur] = double(rsum);
@@ -311,6 +363,9 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
         cur = nxt;
         e0 = n0;
         e1 = n1;
+        m0 = mn0;
+        m1 = mn1;
+        places = places_n;
 #if CLANE_SPMM_PREFETCH
         ch = chn;
 #else
@@ -345,7 +400,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
 #else
 #define CLANE_SUBROW_BOUNDS __launch_bounds__(kBlock)
 #endif
-template <typename T, typename PT, int VEC, int LPR, int U>
+template <typename T, typename PT, int VEC, int LPR, int U, bool MIRRORED>
 __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
@@ -356,6 +411,7 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
     static_assert(LPR < kWave, "use spmm_update_kernel for rows that fill a wave");
     static_assert(LPR % U == 0, "a sub-wave's edge buffer is consumed in whole groups of U");
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
+    __shared__ int64_t s_mptr[MIRRORED ? kMaxRowsPerBlock + 1 : 1];   // the block's slice of mirror.row_ptr
     __shared__ double s_rowsum[kMaxRowsPerBlock];
     __shared__ int s_next;
     __shared__ int s_done;
@@ -370,7 +426,10 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
     const bool col_ok = c0 < d;
     const int c0s = col_ok ? c0 : 0;
 
-    for (int i = threadIdx.x; i <= nb; i += kBlock) s_rowptr[i] = rowptr[row_begin + i];
+    for (int i = threadIdx.x; i <= nb; i += kBlock) {
+        s_rowptr[i] = rowptr[row_begin + i];
+        if constexpr (MIRRORED) s_mptr[i] = mirror.row_ptr[row_begin + i];
+    }
     for (int i = threadIdx.x; i < nb; i += kBlock) s_rowsum[i] = 0.0;
     if (threadIdx.x == 0) {
         s_next = 0;
@@ -387,6 +446,8 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
     int nbuf = 0, pos = 0;     // buffered edges (one per lane: c, p) and how many of them are consumed
     int c = 0;
     A p = A(0);
+    [[maybe_unused]] int64_t m0 = 0, m1 = 0;   // the open row's mirror places: range in mirror.slot, the first LPR of
+    [[maybe_unused]] int32_t places = 0;       // them one per lane, requested when the row is claimed
     Pack<T, VEC> x{}, zo{};
     A acc[VEC];
 #pragma unroll
@@ -400,7 +461,8 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
                     A rsum = A(0), qsum = A(0);
                     Pack<T, VEC> out{};
                     if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out, qsum);
-                    mirror_store<T, VEC, LPR>(mirror, r, c0, out, col_ok, sl, sub_base);   // the sub-wave's LPR lanes
+                    if constexpr (MIRRORED)
+                        mirror_store_prefetched<T, VEC, LPR>(mirror, m0, m1, places, c0, out, col_ok, sl, sub_base);
                     rsum = group_sum<LPR>(rsum);
                     if (sl == 0) s_rowsum[mine] = double(rsum);
                     if (sq_out != nullptr) {
@@ -438,6 +500,11 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
                     }
                     e_next = e0;
                     e_end = e0 + dg;
+                    if constexpr (MIRRORED) {
+                        m0 = s_mptr[mine];
+                        m1 = s_mptr[mine + 1];
+                        places = sl < m1 - m0 ? mirror.slot[m0 + sl] : 0;
+                    }
                     if (col_ok) {
                         x = load_pack_stream<T, VEC>(X + r * ldx + c0);
                         zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
