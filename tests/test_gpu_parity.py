@@ -1238,7 +1238,8 @@ def test_bench_halo_p2p_two_processes_share_tables_through_ipc(tmp_path):
         port = sk.getsockname()[1]
     # one timed block: the delta shrinks by gamma per sweep while Z does not, so after 5 x 6 more sweeps the two
     # divisions' different summation orders show in its 5th digit (seen: 1.37668 vs 1.37669 after 33 sweeps)
-    common = ["--workload", "tiny", "--steps", "6", "--warmup", "2", "--blocks", "1", "--no-cpu-baseline"]
+    common = ["--workload", "tiny", "--steps", "6", "--warmup", "2", "--blocks", "1", "--no-cpu-baseline",
+              "--also-exchange", "none", "--no-delta-stream-ab"]          # hipIpc is the point: no further divisions
     one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"] + common, capture_output=True,
                          text=True, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]

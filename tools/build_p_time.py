@@ -37,8 +37,8 @@ for W in args.world:
     e_main = int(ldeg[in_main].sum())
     main_bytes = rows_main * (dl * s + 8) + e_main * (dl * s + 8)     # source row + rowptr; per edge: row, colidx, score
     steps = {
-        "K0 row_sqnorm + degree sums": lambda: (k.row_sqnorm(Z[b.row0:b.row0 + b.nrows], eng.d, eng.sq_loc),
-                                                k.degree_weighted_sums(eng.sq_loc, eng.rowptr, eng.indeg, eng.part.n_local,
+        "K0 row_sqnorm + degree sums": lambda: (k.row_sqnorm(Z[b.row0:b.row0 + b.nrows], eng.d, eng.sq_pp[eng.cur]),
+                                                k.degree_weighted_sums(eng.sq_pp[eng.cur], eng.rowptr, eng.indeg, eng.part.n_local,
                                                                        eng.ws, eng.sums2)),
         "K1 one (sub-)wave per row": lambda: k.edge_score(eng.rowptr, eng.colidx, b.nrows, b.row0, Z, eng.d, mode,
                                                           eng.sums2, None, eng.P, eng.k1_threshold, None, fuse_softmax=fuse),
