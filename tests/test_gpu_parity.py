@@ -430,12 +430,26 @@ def test_spmm_row_block_with_row0_offset(dev, k):
 
 
 def test_l1_distance(dev, k):
-    for dtype, d in [(torch.float32, 256), (torch.float64, 7), (torch.bfloat16, 128), (torch.float32, 1433)]:
+    """sum|A - B| (embedder.py:60) and, from the same pass, the squared norm of every row of A -- bit for bit what
+    row_sqnorm (K0) computes: padded and unpadded leading dimensions, one and several column tiles, a row count that
+    leaves the last wave half empty."""
+    for dtype, d, pad in [(torch.float32, 256, True), (torch.float64, 7, False), (torch.bfloat16, 128, True),
+                          (torch.float32, 1433, True), (torch.float32, 100, True), (torch.bfloat16, 24, True),
+                          (torch.float32, 2, True), (torch.float64, 64, True), (torch.float32, 37, False)]:
         A, B = synth.gaussian_X(321, d, seed=1).to(dtype), synth.gaussian_X(321, d, seed=2).to(dtype)
+        Ad, Bd = padded(A, dtype, dev, None if pad else d), padded(B, dtype, dev, None if pad else d)
         ws = torch.zeros(k.reduce_ws_len(), dtype=torch.float64, device=dev)
         out = torch.zeros(1, dtype=torch.float64, device=dev)
-        k.l1_distance(A.to(dev), B.to(dev), d, ws, out)
-        assert float(out) == pytest.approx(float((A.double() - B.double()).abs().sum()), rel=1e-6)
+        k.l1_distance(Ad, Bd, d, ws, out)
+        want = float((A.double() - B.double()).abs().sum())
+        assert float(out) == pytest.approx(want, rel=1e-6)
+        acc = _hip.acc_dtype(dtype)
+        sq, sq_k0 = torch.full((321,), -1.0, dtype=acc, device=dev), torch.zeros(321, dtype=acc, device=dev)
+        out2 = torch.zeros(1, dtype=torch.float64, device=dev)
+        k.l1_distance(Ad, Bd, d, ws, out2, sq_a=sq)
+        k.row_sqnorm(Ad, d, sq_k0)
+        assert torch.equal(out, out2) and torch.equal(sq, sq_k0), (dtype, d, pad)
+        assert rel(sq, A.to(acc).double().pow(2).sum(1)) < TOL[dtype]
 
 
 # ---- end to end through the reference surface, against the goldens ------------------------------------
