@@ -65,7 +65,8 @@ PARITY_P_TOL = {"f32": 2e-6, "f64": 1e-12, "bf16": 1e-4}     # P itself (fp32 ar
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 TRAFFIC_NOTE = ("traffic = rocprofv3 FETCH_SIZE x calibrated factor + WRITE_SIZE per launch, taken in separate --pmc "
                 "passes of this same command (profiles/) and matched to the live run by kernel configuration: bytes "
-                "and time come from different runs; these counters sit on the L2's fabric side, so Infinity-Cache "
+                "and time come from different runs (kernels[..].pmc_run_over_live_time says how the kernel's duration "
+                "in the PMC run compares with this run's); these counters sit on the L2's fabric side, so Infinity-Cache "
                 "hits are counted as traffic: frac = min(algorithmic, traffic) bytes / kernel time / 8 TB/s, capped "
                 "at 1, is an UPPER bound of the HBM share; achieved_algorithmic is the no-reuse gather model "
                 "(SURVEY 8d), which also counts L2 hits")
@@ -236,7 +237,9 @@ def traffic_entry(workload: str, world: int, eng, dom: str, slice_of=None):
     if diff:
         return None, f"{key}: stale, measured with another kernel configuration (differs in {', '.join(diff)})"
     got = entry.get(dom, {}).get("bytes_per_launch")
-    return got, (entry.get("source") if got is not None else f"{key}: kernel {dom} not in the measurement")
+    if got is None:
+        return None, f"{key}: kernel {dom} not in the measurement"
+    return got, {"source": entry.get("source"), "avg_us_under_pmc": entry[dom].get("avg_us_under_pmc")}
 
 
 def make_parser():
@@ -617,6 +620,10 @@ def roofline_block(args, world, m) -> dict:
         pk["traffic_over_algorithmic"] = None if tr is None else tr / alg
         if tr is None:
             pk["traffic_missing"] = why
+        elif why.get("avg_us_under_pmc"):
+            # bytes and time come from different runs of the same configuration: how far apart were those runs' kernels?
+            pk["pmc_run_avg_launch_ms"] = why["avg_us_under_pmc"] / 1e3
+            pk["pmc_run_over_live_time"] = why["avg_us_under_pmc"] / 1e3 / pk["avg_launch_ms"]
         pass_traffic = None if (tr is None or pass_traffic is None) else pass_traffic + tr * chunks
     pass_counted = min(pass_bytes, pass_traffic) if pass_traffic is not None else pass_bytes
     pass_rate = min(pass_counted / (pass_ms * 1e-3) / 1e9, HBM_PEAK_GBPS)
@@ -630,6 +637,7 @@ def roofline_block(args, world, m) -> dict:
             "separate --pmc runs of this command (profiles/traffic.json), not the timed run",
             "achieved_algorithmic": pd["achieved_algorithmic"],
             "traffic_over_algorithmic": pd["traffic_over_algorithmic"],
+            "pmc_run_over_live_time": pd.get("pmc_run_over_live_time"),
             "algorithmic_bytes_per_launch": pd["algorithmic_bytes_per_launch"],
             "avg_launch_ms": pd["avg_launch_ms"], "note": note, "kernels": per_kernel,
             "k3_pass": {"algorithmic_bytes": pass_bytes, "traffic": pass_traffic, "ms": pass_ms,

@@ -45,10 +45,10 @@ def test_traffic_is_only_quoted_for_the_configuration_it_was_measured_with(tmp_p
     monkeypatch.setattr(bench, "ROOT", tmp_path)
     (tmp_path / "profiles").mkdir()
     eng, cfg = _fake_engine()
-    table = {"w_n1": {"source": "profiles/x.md", "kernel_config": cfg, "k": {"bytes_per_launch": 123.0}},
+    table = {"w_n1": {"source": "profiles/x.md", "kernel_config": cfg, "k": {"bytes_per_launch": 123.0, "avg_us_under_pmc": 7.5}},
              "old_n1": {"k": {"bytes_per_launch": 5.0}}}
     (tmp_path / "profiles" / "traffic.json").write_text(json.dumps(table))
-    assert bench.traffic_entry("w", 1, eng, "k") == (123.0, "profiles/x.md")
+    assert bench.traffic_entry("w", 1, eng, "k") == (123.0, {"source": "profiles/x.md", "avg_us_under_pmc": 7.5})
     got, why = bench.traffic_entry("w", 1, eng, "other")
     assert got is None and "not in the measurement" in why
     got, why = bench.traffic_entry("old", 1, eng, "k")                  # an entry from before configurations were kept
@@ -62,6 +62,7 @@ def test_traffic_is_only_quoted_for_the_configuration_it_was_measured_with(tmp_p
     # the committed table: the headline workload's entry carries the configuration it was measured with
     real = json.loads((ROOT / "profiles" / "traffic.json").read_text())
     assert "kernel_config" in real["rmat2m_n1"] and real["rmat2m_n1"]["kernel_config"]["d"] == 256
+    assert real["rmat2m_n1"]["spmm_class_chunk_kernel+combine"]["avg_us_under_pmc"] > 1000   # the PMC run's own kernel time
 
 
 def test_torch_baseline_sampled_and_full(monkeypatch):

@@ -96,7 +96,8 @@ def main():
         entry["kernel_config"] = bench_line["roofline"]["kernel_config"]
     for k, v in summary.items():
         if bench_name(k):
-            entry[bench_name(k)] = {"bytes_per_launch": v["fetch_bytes"] + v["write_bytes"], "rocprof_name": k}
+            entry[bench_name(k)] = {"bytes_per_launch": v["fetch_bytes"] + v["write_bytes"], "rocprof_name": k,
+                                    "avg_us_under_pmc": round(v["avg_us_under_pmc"], 1)}
     for k, v in summary.items():        # the combine launch belongs to the same bench entry as its chunk / segment pass
         # (spmm_class_combine_kernel also closes the split-segment pass when the class pass is off)
         for part, whole in (("spmm_class_combine_kernel", "spmm_class_chunk_kernel+combine"),
@@ -104,6 +105,7 @@ def main():
             if part in k and whole in entry and not (whole.startswith("spmm_split") and
                                                      "spmm_class_chunk_kernel+combine" in entry):
                 entry[whole]["bytes_per_launch"] += v["fetch_bytes"] + v["write_bytes"]
+                entry[whole]["avg_us_under_pmc"] = round(entry[whole]["avg_us_under_pmc"] + v["avg_us_under_pmc"], 1)
     data[args.workload] = entry
     tfile.write_text(json.dumps(data, indent=1) + "\n")
     if args.stats:
