@@ -53,6 +53,7 @@ WORKLOADS = {
     # to reuse (the 2 GB table is 8x the cache), so the PMC traffic equals the algorithmic bytes and `frac` is a true HBM
     # fraction with no cache caveat.  Same |V|, |E|, d as the headline.
     "uniform2m": ("uniform", 2_000_000, 40_000_000, 256, "f32", 12, 4),
+    "rmat200k256": ("rmat", 200_000, 4_000_000, 256, "f32", 1, 2),    # config 2's graph at 1-KiB rows: a cache-resident table
     "tiny": ("rmat", 20_000, 200_000, 64, "f32", 7, 8),
     "tiny12": ("rmat", 20_000, 200_000, 12, "f32", 7, 8),             # 3 packs a row: more ranks than packs leaves idle column ranks
     # 8x config 3: a 16 GiB embedding matrix (byte offsets beyond 32 bits, ~85 GB of HBM in use) -- capacity check

@@ -69,6 +69,7 @@ TARGET_SEGMENTS = 512                   # two workgroups per CU
 # 2M-edge row scored by ONE workgroup took build_P from 6.6 to 29 ms) take the pass.
 SOFTMAX_EDGES_PER_WORKGROUP = 1 << 17     # build_P: edges of one class row that one workgroup of the rescale pass takes
 L2_BYTES_ALL_XCDS = 8 * 4 * 1024 * 1024
+INFINITY_CACHE_BYTES = 256 * 1024 * 1024
 MIN_HOT_READ_SHARE = 0.2
 HEAVY_ROW_EDGES = 4096
 UNSKEWED_LONG_THRESHOLD = 128
@@ -326,6 +327,11 @@ class SweepEngine:
         self.class_affinity = True
         if class_threshold is None:         # XCD-affine long rows, whatever the division
             class_threshold = CLASS_THRESHOLD_BY_ROWS_PER_WAVE[self.rows_per_wave]
+            if self.rows_per_wave == 2 and csr.num_vertices * row_bytes <= INFINITY_CACHE_BYTES:
+                # a table that sits in the Infinity Cache: misses of an L2 are cheap, so the class pass pays from
+                # twice the degree on (512-byte rows, 200k x 4M: 0.207 ms per sweep at 64, 0.192 at 128, 0.196 at 256;
+                # 1-KiB rows keep 64, narrower rows are at 256 anyway: profiles/r04_class_threshold_cache_resident.md)
+                class_threshold = max(class_threshold, 128)
             if self.hot_read_share < MIN_HOT_READ_SHARE:    # evenly spread reads: only rows that need splitting anyway
                 class_threshold = max(class_threshold, HEAVY_ROW_EDGES)
                 self.class_affinity = False
