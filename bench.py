@@ -262,15 +262,12 @@ def make_parser():
     ap.add_argument("--no-split-hubs", action="store_true", help="hub rows by one workgroup each (no segment split)")
     ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
     ap.add_argument("--exchange", default="auto",
-                    choices=["auto", "columns", "grid", "halo", "halo_p2p", "allgather", "allgather_all"],
+                    choices=["auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all"],
                     help="N > 1: auto = columns while a rank's row slice is >= 64 bytes, else halo; columns = every GPU "
-                         "holds d/N columns of every row, no exchange per sweep; grid = R row groups x C column groups "
-                         "(--grid-cols C): row SLICES exchanged inside a column group; allgather_all = north_star's literal "
+                         "holds d/N columns of every row, no exchange per sweep; allgather_all = north_star's literal "
                          "plan: rows divided, one in-place RCCL all-gather of the updated rows per sweep; allgather = "
                          "the same for the live rows only; halo / halo_p2p = rows sent only to the ranks that read "
                          "them (clane_amd/halo.py, partition.py; DESIGN.md section 6)")
-    ap.add_argument("--grid-cols", type=int, default=None,
-                    help="--exchange grid: column groups C (a divisor of N; default: the most whose slices stay 128 bytes wide)")
     ap.add_argument("--also-exchange", default="allgather_all,allgather",
                     help="N > 1: after the main division's timed blocks, rebuild the engine with each of these divisions "
                          "(comma-separated) and report its sweeps/s, parity and collective time in the same record: "
@@ -473,7 +470,7 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
     eng = SweepEngine(csr, X, dev, process_group=ranks.pg, comm=comm, chunks=args.chunks,
                       long_threshold=args.long_threshold, hub_threshold=args.hub_threshold, exchange=exchange,
                       hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs,
-                      class_threshold=args.class_threshold, class_chunk=args.class_chunk, grid_cols=args.grid_cols)
+                      class_threshold=args.class_threshold, class_chunk=args.class_chunk)
     torch.cuda.synchronize()
     log(f"engine up in {time.perf_counter() - t0:.1f}s ({eng.exchange}); rank rows={eng.part.n_local} edges={eng.E_loc} "
         f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
@@ -572,12 +569,6 @@ def describe_parallelism(args, world, eng, X, E) -> str:
                 f"[0:{X.shape[1]}) of X and Z, whole graph; not a headline number")
     if world == 1 and eng.exchange == "none":
         return f"1 GPU, {chunks} launch block(s)/sweep"
-    if eng.grid:
-        return (f"2-D division: {eng.R} row groups x {eng.C} column groups (rank = r * {eng.C} + c); a GPU holds columns "
-                f"[{eng.col0}:{eng.col1}) (rank 0) of its row group's rows; {chunks} launch block(s)/sweep, row slices "
-                f"exchanged among the {eng.R} ranks of a column group over RCCL per chunk "
-                f"({eng.exchange_bytes_per_sweep() / 1e6:.0f} MB received/rank/sweep), partial dot products of build_P "
-                f"all-reduced among the {eng.C} ranks of a row group, one scalar all-reduce over all")
     if eng.columns:
         return (f"column split x{world}: every GPU holds the whole graph and columns [{eng.col0}:{eng.col1}) "
                 f"(rank 0) of X and Z; no exchange per sweep, one scalar all-reduce (RCCL); build_P all-reduces "
@@ -794,8 +785,6 @@ DIVISION_NOTES = {
                  "reads are synchronised once at the end",
     "halo": "rows partitioned, each updated row sent only to the ranks that read it: one all_to_all_single per launch "
             "chunk into a compact per-rank table",
-    "grid": "R row groups x C column groups: row slices exchanged (halo) among the ranks that hold the same columns, "
-            "partial dot products summed among the ranks that hold the same rows",
 }
 
 
@@ -835,7 +824,7 @@ def division_block(args, ranks: Ranks, csr, X, E, exchange: str, main_division: 
 
 def main():
     args = make_parser().parse_args()
-    unknown = [x for x in args.also_exchange.split(",") if x not in ("", "none", "columns", "grid", "halo", "halo_p2p",
+    unknown = [x for x in args.also_exchange.split(",") if x not in ("", "none", "columns", "halo", "halo_p2p",
                                                                      "allgather", "allgather_all")]
     if unknown:
         raise SystemExit(f"--also-exchange: unknown division(s) {unknown}")

@@ -139,11 +139,11 @@ def get_parser():
                         help="(extension) .npy of shape [V, d]: start from these embeddings instead of the content "
                              "embeddings, e.g. the Z.npy of an interrupted run.")
     parser.add_argument("--exchange", default="auto",
-                        choices=["auto", "columns", "allgather_all", "allgather", "halo", "halo_p2p", "grid"],
+                        choices=["auto", "columns", "allgather_all", "allgather", "halo", "halo_p2p"],
                         help="(extension, multi-GPU runs under torchrun) how the sweep is divided over the GPUs: columns of "
                              "Z (no exchange per sweep; what auto picks for wide rows), rows with one all-gather of the "
-                             "updated rows per sweep (allgather_all), the leaner row splits, or both at once (grid: row groups x column "
-                             "groups); see DESIGN.md section 6.  A plug-in similarity needs a row division (default then: halo).")
+                             "updated rows per sweep (allgather_all) or the leaner row splits; "
+                             "see DESIGN.md section 6.  A plug-in similarity needs a row division (default then: halo).")
     parser.add_argument("--gpu", action='store_true')
     return parser
 

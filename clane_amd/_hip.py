@@ -20,7 +20,7 @@ import torch
 
 LIB_NAME = "libclane_hip.so"
 LIB_PATH = Path(__file__).resolve().parent / LIB_NAME
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SCORE_REFERENCE, SCORE_PER_EDGE, SCORE_RAW_DOT = 0, 1, 2
 SPMM_SINKS_UNTOUCHED = 1
@@ -55,15 +55,15 @@ for _s in ("f32", "f64", "bf16"):
         C.c_int, [_p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _i64, _p, _i64, _p])
     _g = C.c_double if _s == "f64" else C.c_float
     SIGNATURES[f"clane_spmm_update_{_s}"] = (
-        C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _p])
+        C.c_int, [_p, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i64, _i32, _p, _p, _p])
     SIGNATURES[f"clane_spmm_update_long_{_s}"] = (
-        C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
+        C.c_int, [_p, _p, _p, _p, _i64, _i32, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p])
     SIGNATURES[f"clane_spmm_update_split_{_s}"] = (
         C.c_int,
-        [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p, _p])
+        [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_spmm_update_class_{_s}"] = (
         C.c_int,
-        [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p, _p])
+        [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_edge_score_class_{_s}"] = (
         C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p])
     SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
@@ -289,16 +289,16 @@ class KernelBackend(abc.ABC):
     # K3
     @abc.abstractmethod
     def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials,
-                    sinks_untouched=False, mirror=None, sq_out=None): ...
+                    sinks_untouched=False, mirror=None): ...
     @abc.abstractmethod
     def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row, row0, Z_old, X, gamma, Z_new, d, partials,
-                         mirror=None, sq_out=None): ...
+                         mirror=None): ...
     @abc.abstractmethod
     def spmm_update_split(self, rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, row0, Z_old, X,
-                          gamma, Z_new, d, slab, partials, mirror=None, sq_out=None): ...
+                          gamma, Z_new, d, slab, partials, mirror=None): ...
     @abc.abstractmethod
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
-                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None, sq_out=None): ...
+                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None): ...
     @abc.abstractmethod
     def reduce_partials(self, partials, n, ws, out): ...
     @abc.abstractmethod
@@ -474,15 +474,13 @@ class HipKernels(KernelBackend):
 
     # -- K3 -----------------------------------------------------------------------------
     @staticmethod
-    def _sq_arg(sq_out: Optional[torch.Tensor], dtype: torch.dtype):
-        return None if sq_out is None else _vec(sq_out, acc_dtype(dtype), "sq_out")
+    def _sq_arg(sq: Optional[torch.Tensor], dtype: torch.dtype):
+        return None if sq is None else _vec(sq, acc_dtype(dtype), "sq_a")
 
     def spmm_update(self, rowptr, colidx, P, nrows: int, row0: int, Z_old, X, gamma: float, Z_new, d: int,
-                    long_threshold: int, partials, sinks_untouched: bool = False, mirror: Optional[Mirror] = None,
-                    sq_out: Optional[torch.Tensor] = None):
+                    long_threshold: int, partials, sinks_untouched: bool = False, mirror: Optional[Mirror] = None):
         """Main pass: every row of <= long_threshold edges (0 = all rows).  With `sinks_untouched` rows
-        without out-edges are neither read nor written (caller keeps Z_new == Z_old there).  `sq_out` (all four K3
-        calls; accumulate dtype, one entry per row of the call's block): the squared norm of every row written."""
+        without out-edges are neither read nor written (caller keeps Z_new == Z_old there)."""
         zo, ldz = _mat(Z_old, "Z_old")
         xp, ldx = _mat(X, "X")
         zn, ldo = _mat(Z_new, "Z_new")
@@ -492,12 +490,10 @@ class HipKernels(KernelBackend):
                      _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
                      _vec(P, acc_dtype(Z_old.dtype), "P"), nrows, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
                      long_threshold, SPMM_SINKS_UNTOUCHED if sinks_untouched else 0,
-                     _mirror_arg(mirror, Z_new.dtype), self._sq_arg(sq_out, Z_old.dtype),
-                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+                     _mirror_arg(mirror, Z_new.dtype), _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 
     def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row: int, row0: int, Z_old, X, gamma: float,
-                         Z_new, d: int, partials, mirror: Optional[Mirror] = None,
-                         sq_out: Optional[torch.Tensor] = None):
+                         Z_new, d: int, partials, mirror: Optional[Mirror] = None):
         """Row-split pass: one workgroup of `waves_per_row` (4 | 16) waves per listed row; writes
         long_rows.numel() partials."""
         zo, ldz = _mat(Z_old, "Z_old")
@@ -509,15 +505,13 @@ class HipKernels(KernelBackend):
                      _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
                      _vec(P, acc_dtype(Z_old.dtype), "P"), _vec(long_rows, torch.int32, "long_rows"),
                      long_rows.numel(), waves_per_row, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
-                     _mirror_arg(mirror, Z_new.dtype), self._sq_arg(sq_out, Z_old.dtype),
-                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+                     _mirror_arg(mirror, Z_new.dtype), _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 
     def spmm_split_slab_len(self, n_segments: int, d: int) -> int:
         return int(self.lib.clane_spmm_split_slab_len(n_segments, d))
 
     def spmm_update_split(self, rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment: int, row0: int,
-                          Z_old, X, gamma: float, Z_new, d: int, slab, partials, mirror: Optional[Mirror] = None,
-                          sq_out: Optional[torch.Tensor] = None):
+                          Z_old, X, gamma: float, Z_new, d: int, slab, partials, mirror: Optional[Mirror] = None):
         """Hub rows cut into segments over several workgroups + fixed-order combine; writes split_rows.numel()
         partials."""
         zo, ldz = _mat(Z_old, "Z_old")
@@ -529,14 +523,14 @@ class HipKernels(KernelBackend):
                      _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(seg_row, torch.int32, "seg_row"),
                      split_rows.numel(), seg_row.numel(), edges_per_segment, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
                      _vec(slab, acc_dtype(Z_old.dtype), "slab"), _mirror_arg(mirror, Z_new.dtype),
-                     self._sq_arg(sq_out, Z_old.dtype), _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 
     def spmm_class_slab_len(self, n_slots: int, d: int) -> int:
         return int(self.lib.clane_spmm_class_slab_len(n_slots, d))
 
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block: int, class_rows, slot_ptr,
                           row0: int, Z_old, X, gamma: float, Z_new, d: int, slab, partials,
-                          mirror: Optional[Mirror] = None, sq_out: Optional[torch.Tensor] = None):
+                          mirror: Optional[Mirror] = None):
         """XCD-affine pass over the listed long rows (edges sorted by (XCD class of the column, column), cut into items; item
         blocks of class b at block index 8 j + b) + fixed-order combine; writes class_rows.numel() partials."""
         zo, ldz = _mat(Z_old, "Z_old")
@@ -552,7 +546,7 @@ class HipKernels(KernelBackend):
                      _vec(class_rows, torch.int32, "class_rows"), _vec(slot_ptr, torch.int64, "slot_ptr"),
                      class_rows.numel(), row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
                      _vec(slab, acc_dtype(Z_old.dtype), "slab"), _mirror_arg(mirror, Z_new.dtype),
-                     self._sq_arg(sq_out, Z_old.dtype), _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 
     def reduce_partials(self, partials, n: int, ws, out):
         self._invoke(self.lib.clane_reduce_partials, "clane_reduce_partials",

@@ -69,23 +69,6 @@ class TorchComm:
             views.append([b.tensor for b in opened])
         return views, keep
 
-    def split(self, groups: List[List[int]]) -> "TorchComm":
-        """Collective over THIS communicator: every rank passes the same list of disjoint lists of ranks (ranks of this
-        communicator); returns the communicator of the list the caller is in.  The 2-D division uses two such splits:
-        the ranks that hold the same columns (they exchange rows) and the ranks that hold the same rows (they sum
-        partial dot products)."""
-        if self.pg is None:
-            raise RuntimeError("split() needs a process group")
-        to_global = self._dist.get_process_group_ranks(self.pg)
-        mine = None
-        for ranks in groups:                # every rank creates every group, in the same order (torch.distributed's rule)
-            pg = self._dist.new_group(ranks=[to_global[r] for r in ranks])
-            if self.rank in ranks:
-                mine = TorchComm(pg)
-        if mine is None:
-            raise ValueError(f"rank {self.rank} is in none of the groups {groups}")
-        return mine
-
     def all_gather_object(self, obj) -> list:
         if self.world == 1:
             return [obj]

@@ -270,7 +270,7 @@ template <typename T, typename PT>
 int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows, int64_t row0,
                 const T *Z_old, int64_t ldz, const T *X, int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new,
                 int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, const clane_mirror_t *mirror,
-                typename Elem<T>::acc_t *sq_out, double *delta_partials, void *stream) {
+                double *delta_partials, void *stream) {
     REQUIRE(nrows >= 0 && row0 >= 0 && d > 0, "spmm_update: bad shape nrows=%lld row0=%lld d=%d", (long long)nrows,
             (long long)row0, d);
     REQUIRE(mirror_ok(mirror, d), "spmm_update: incomplete mirror descriptor");
@@ -290,11 +290,11 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
             if constexpr (LPR < kWave && VEC > 1)      // short rows of narrow matrices: one sub-wave per row
                 spmm_update_subrow_kernel<T, PT, VEC, LPR, U, MIRRORED><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                     rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, sq_out, delta_partials);
+                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, delta_partials);
             else
                 spmm_update_kernel<T, PT, VEC, LPR, U, MIRRORED><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                     rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, sq_out, delta_partials);
+                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, delta_partials);
         };
         if (mir.row_ptr != nullptr) launch.template operator()<true>();
         else launch.template operator()<false>();
@@ -306,7 +306,7 @@ template <typename T, typename PT>
 int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, const int32_t *long_rows,
                      int64_t n_long, int32_t waves_per_row, int64_t row0, const T *Z_old, int64_t ldz, const T *X, int64_t ldx,
                      typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d, const clane_mirror_t *mirror,
-                     typename Elem<T>::acc_t *sq_out, double *delta_partials, void *stream) {
+                     double *delta_partials, void *stream) {
     REQUIRE(n_long >= 0 && n_long <= INT32_MAX && row0 >= 0 && d > 0, "spmm_update_long: bad shape");
     REQUIRE(mirror_ok(mirror, d), "spmm_update_long: incomplete mirror descriptor");
     REQUIRE(ldz >= d && ldx >= d && ldo >= d, "spmm_update_long: leading dimension < d");
@@ -322,11 +322,11 @@ int spmm_update_long(const int64_t *rowptr, const int32_t *colidx, const PT *P, 
         constexpr int U = VEC > 1 ? CLANE_LONG_U : 4;
         if (waves_per_row == 4)
             spmm_long_kernel<T, PT, VEC, LPR, U, 4><<<int(n_long), 4 * kWave, 0, (hipStream_t)stream>>>(
-                rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, sq_out, delta_partials);
+                rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
         else
             spmm_long_kernel<T, PT, VEC, LPR, U, kLongWaves>
                 <<<int(n_long), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
-                    rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, sq_out, delta_partials);
+                    rowptr, colidx, P, long_rows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
     });
     return check_launch("spmm_update_long");
 }
@@ -336,8 +336,8 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
                       const int64_t *seg_ptr, const int32_t *seg_row, int64_t n_split, int64_t n_segments,
                       int64_t edges_per_segment, int64_t row0, const T *Z_old, int64_t ldz, const T *X, int64_t ldx,
                       typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d,
-                      typename Elem<T>::acc_t *slab, const clane_mirror_t *mirror, typename Elem<T>::acc_t *sq_out,
-                      double *delta_partials, void *stream) {
+                      typename Elem<T>::acc_t *slab, const clane_mirror_t *mirror, double *delta_partials,
+                      void *stream) {
     REQUIRE(mirror_ok(mirror, d), "spmm_update_split: incomplete mirror descriptor");
     REQUIRE(n_split >= 0 && n_split <= INT32_MAX && n_segments >= n_split && n_segments <= INT32_MAX && row0 >= 0 &&
                 d > 0 && edges_per_segment >= kWave && edges_per_segment % kWave == 0,
@@ -359,8 +359,7 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
                 rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, Z_old, ldz, d, slab, ld_slab);
         // a row's segments sit in the slab like a class row's slots: the same fixed-order combine + epilogue
         spmm_class_combine_kernel<T, VEC><<<unsigned(n_split), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
-            split_rows, seg_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, sq_out,
-            delta_partials);
+            split_rows, seg_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
     });
     return check_launch("spmm_update_split");
 }
@@ -370,8 +369,8 @@ int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0
                       const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,
                       const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const T *Z_old, int64_t ldz, const T *X,
                       int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d,
-                      typename Elem<T>::acc_t *slab, const clane_mirror_t *mirror, typename Elem<T>::acc_t *sq_out,
-                      double *delta_partials, void *stream) {
+                      typename Elem<T>::acc_t *slab, const clane_mirror_t *mirror, double *delta_partials,
+                      void *stream) {
     REQUIRE(mirror_ok(mirror, d), "spmm_update_class: incomplete mirror descriptor");
     REQUIRE(n_blocks >= 0 && n_blocks <= INT32_MAX && n_rows >= 0 && n_rows <= INT32_MAX && row0 >= 0 && d > 0,
             "spmm_update_class: bad shape");
@@ -394,8 +393,7 @@ int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0
             spmm_class_chunk_kernel<T, PT, VEC, LPR, U><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
                 colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab);
         spmm_class_combine_kernel<T, VEC><<<unsigned(n_rows), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
-            class_rows, slot_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, sq_out,
-            delta_partials);
+            class_rows, slot_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
     });
     return check_launch("spmm_update_class");
 }
@@ -606,32 +604,30 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
     int clane_spmm_update_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64_t nrows,             \
                                 int64_t row0, const CT *Z_old, int64_t ldz, const CT *X, int64_t ldx, GT gamma,       \
                                 CT *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags,             \
-                                const clane_mirror_t *mirror, GT *sq_out, double *delta_partials, void *stream) {     \
+                                const clane_mirror_t *mirror, double *delta_partials, void *stream) {                \
         return spmm_update<T, PT>(rowptr, colidx, P, nrows, row0, reinterpret_cast<const T *>(Z_old), ldz,            \
                                   reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new), ldo, d,   \
-                                  long_threshold, flags, mirror, sq_out, delta_partials, stream);                     \
+                                  long_threshold, flags, mirror, delta_partials, stream);                             \
     }                                                                                                                 \
     int clane_spmm_update_long_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P,                       \
                                      const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const CT *Z_old,         \
                                      int64_t ldz, const CT *X, int64_t ldx, GT gamma, CT *Z_new, int64_t ldo,         \
-                                     int32_t d, const clane_mirror_t *mirror, GT *sq_out, double *delta_partials,     \
-                                     void *stream) {                                                                  \
+                                     int32_t d, const clane_mirror_t *mirror, double *delta_partials, void *stream) { \
         return spmm_update_long<T, PT>(rowptr, colidx, P, long_rows, n_long, waves_per_row, row0,                     \
                                        reinterpret_cast<const T *>(Z_old), ldz, reinterpret_cast<const T *>(X), ldx,  \
-                                       gamma, reinterpret_cast<T *>(Z_new), ldo, d, mirror, sq_out, delta_partials,   \
-                                       stream);                                                                       \
+                                       gamma, reinterpret_cast<T *>(Z_new), ldo, d, mirror, delta_partials, stream);  \
     }
 #define CLANE_SPLIT_WRAPPER(SUF, CT, T, PT, GT)                                                                         \
     int clane_spmm_update_split_##SUF(const int64_t *rowptr, const int32_t *colidx, const PT *P,                      \
                                       const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,      \
                                       int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,   \
                                       const CT *Z_old, int64_t ldz, const CT *X, int64_t ldx, GT gamma, CT *Z_new,    \
-                                      int64_t ldo, int32_t d, GT *slab, const clane_mirror_t *mirror, GT *sq_out,     \
+                                      int64_t ldo, int32_t d, GT *slab, const clane_mirror_t *mirror,                 \
                                       double *delta_partials, void *stream) {                                         \
         return spmm_update_split<T, PT>(rowptr, colidx, P, split_rows, seg_ptr, seg_row, n_split, n_segments,         \
                                         edges_per_segment, row0, reinterpret_cast<const T *>(Z_old), ldz,             \
                                         reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new),     \
-                                        ldo, d, slab, mirror, sq_out, delta_partials, stream);                        \
+                                        ldo, d, slab, mirror, delta_partials, stream);                                \
     }
 CLANE_SPLIT_WRAPPER(f32, float, float, float, float)
 CLANE_SPLIT_WRAPPER(f64, double, double, double, double)
@@ -643,12 +639,11 @@ CLANE_SPLIT_WRAPPER(bf16, uint16_t, bf16_t, float, float)
                                       int32_t items_per_block, const int32_t *class_rows, const int64_t *slot_ptr,    \
                                       int64_t n_rows, int64_t row0, const CT *Z_old, int64_t ldz, const CT *X,        \
                                       int64_t ldx, GT gamma, CT *Z_new, int64_t ldo, int32_t d, GT *slab,             \
-                                      const clane_mirror_t *mirror, GT *sq_out, double *delta_partials,               \
-                                      void *stream) {                                                                 \
+                                      const clane_mirror_t *mirror, double *delta_partials, void *stream) {           \
         return spmm_update_class<T, PT>(colidx, P, item_e0, item_len, item_slot, n_blocks, items_per_block,           \
                                         class_rows, slot_ptr, n_rows, row0, reinterpret_cast<const T *>(Z_old), ldz,  \
                                         reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new),     \
-                                        ldo, d, slab, mirror, sq_out, delta_partials, stream);                        \
+                                        ldo, d, slab, mirror, delta_partials, stream);                                \
     }
 CLANE_CLASS_WRAPPER(f32, float, float, float, float)
 CLANE_CLASS_WRAPPER(f64, double, double, double, double)

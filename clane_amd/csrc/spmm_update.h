@@ -167,17 +167,12 @@ struct Mirror {
     }
 };
 
-// Epilogue of one row's column tile; returns this lane's share of sum|z_new - z_old| and adds its share of
-// |z_new|^2 (of the STORED values) to `qsum` -- in exactly the order row_sqnorm_kernel (K0, build_p.h) walks a row:
-// lane l takes the packs l, l + LPR, ... and one fma per element.  Every K3 kernel folds `qsum` over the row's lanes
-// with the same butterfly as K0 and stores it to sq_out[row], so the next build_P starts from a norm that is bit for
-// bit K0's without reading Z again (similarity.py:37's norms, one outer round later).
+// Epilogue of one row's column tile; returns this lane's share of sum|z_new - z_old| (of the STORED values).
 template <typename T, int VEC>
 __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC> &x, const Pack<T, VEC> &zo,
                                                                const typename Elem<T>::acc_t (&acc)[VEC],
                                                                typename Elem<T>::acc_t gamma, bool has_edges,
-                                                               T *__restrict__ dst, Pack<T, VEC> &out,
-                                                               typename Elem<T>::acc_t &qsum) {
+                                                               T *__restrict__ dst, Pack<T, VEC> &out) {
     using A = typename Elem<T>::acc_t;
     A rsum = A(0);
 #pragma unroll
@@ -187,7 +182,6 @@ __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC
         out.v[k] = Elem<T>::from_acc(znew);
         const A stored = Elem<T>::to_acc(out.v[k]);
         rsum += fabs(stored - zold);
-        qsum = fma(stored, stored, qsum);
     }
     store_pack_stream<T, VEC>(dst, out);
     return rsum;
@@ -260,8 +254,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    bool skip_sinks, int rows_per_block, Mirror<T> mirror, typename Elem<T>::acc_t *__restrict__ sq_out,
-    double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
     __shared__ int64_t s_mptr[MIRRORED ? kMaxRowsPerBlock + 1 : 1];   // the block's slice of mirror.row_ptr
@@ -333,7 +326,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
         }
         if (!(long_threshold > 0 && e1 - e0 > long_threshold) && !(skip_sinks && e1 == e0)) {
             const int64_t r = row_begin + cur;
-            A rsum = A(0), qsum = A(0);
+            A rsum = A(0);
             for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
                 const int c0 = t0 + sl * VEC;
                 const bool col_ok = c0 < d;
@@ -349,16 +342,12 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
                 gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
                 fold_subwaves<LPR>(acc);
                 Pack<T, VEC> out{};
-                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out, qsum);
+                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out);
                 if constexpr (MIRRORED)
                     mirror_store_prefetched<T, VEC, kWave>(mirror, m0, m1, places, c0, out, writer, lane, 0);
             }
             rsum = group_sum<kWave>(rsum);
             if (lane == 0) s_rowsum[cur] = double(rsum);
-            if (sq_out != nullptr) {             // kernel argument: uniform
-                qsum = group_sum<LPR>(qsum);     // the writers are the lanes of sub-wave 0
-                if (lane == 0) sq_out[r] = qsum;
-            }
         }
         cur = nxt;
         e0 = n0;
@@ -405,8 +394,7 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    bool skip_sinks, int rows_per_block, Mirror<T> mirror, typename Elem<T>::acc_t *__restrict__ sq_out,
-    double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     static_assert(LPR < kWave, "use spmm_update_kernel for rows that fill a wave");
     static_assert(LPR % U == 0, "a sub-wave's edge buffer is consumed in whole groups of U");
@@ -458,17 +446,13 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
             if (e_next == e_end) {           // row finished (or none yet): write it, claim the next one with work
                 if (have) {
                     const int64_t r = row_begin + mine;
-                    A rsum = A(0), qsum = A(0);
+                    A rsum = A(0);
                     Pack<T, VEC> out{};
-                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out, qsum);
+                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out);
                     if constexpr (MIRRORED)
                         mirror_store_prefetched<T, VEC, LPR>(mirror, m0, m1, places, c0, out, col_ok, sl, sub_base);
                     rsum = group_sum<LPR>(rsum);
                     if (sl == 0) s_rowsum[mine] = double(rsum);
-                    if (sq_out != nullptr) {
-                        qsum = group_sum<LPR>(qsum);
-                        if (sl == 0) sq_out[r] = qsum;
-                    }
                     have = false;
                 }
                 for (;;) {
@@ -485,17 +469,7 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
                     if (dg == 0 && skip_sinks) continue;
                     const int64_t r = row_begin + mine;
                     if (dg == 0) {           // row without out-edges, sinks not skipped: z stays (embedder.py:88-89)
-                        A qsum = A(0);
-                        if (col_ok) {
-                            const Pack<T, VEC> z0 = load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0);
-                            store_pack<T, VEC>(Znew + r * ldo + c0, z0);
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) qsum = fma(Elem<T>::to_acc(z0.v[k]), Elem<T>::to_acc(z0.v[k]), qsum);
-                        }
-                        if (sq_out != nullptr) {
-                            qsum = group_sum<LPR>(qsum);
-                            if (sl == 0) sq_out[r] = qsum;
-                        }
+                        if (col_ok) store_pack<T, VEC>(Znew + r * ldo + c0, load_pack<T, VEC>(Zold + (row0 + r) * ldz + c0));
                         continue;
                     }
                     e_next = e0;
@@ -569,7 +543,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P,
     const int32_t *__restrict__ long_rows, int64_t row0, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
-    Mirror<T> mirror, typename Elem<T>::acc_t *__restrict__ sq_out, double *__restrict__ partials) {
+    Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ A red[WAVES][kWave][VEC];
     const int lane = lane_id();
@@ -585,7 +559,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     const int64_t a = e0 + wave * seg;
     const int64_t b = a + seg < e1 ? a + seg : e1;
     const EdgeChunk<A> none{0, A(0)};
-    A rsum = A(0), qsum = A(0);
+    A rsum = A(0);
 
     for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
         const int c0 = t0 + sl * VEC;
@@ -613,7 +587,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
                 }
-                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out, qsum);
+                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out);
             }
             mirror_store<T, VEC, kWave>(mirror, r, c0, out, writer, lane, 0);
         }
@@ -622,10 +596,6 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
     if (wave == 0) {
         rsum = group_sum<kWave>(rsum);
         if (lane == 0) partials[blockIdx.x] = double(rsum);
-        if (sq_out != nullptr) {
-            qsum = group_sum<kWave>(qsum);  // zero outside sub-wave 0: the same bits as K0's fold over LPR lanes
-            if (lane == 0) sq_out[r] = qsum;
-        }
     }
 }
 
@@ -797,7 +767,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
     const int32_t *__restrict__ class_rows, const int64_t *__restrict__ slot_ptr, int64_t row0,
     const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
-    Mirror<T> mirror, typename Elem<T>::acc_t *__restrict__ sq_out, double *__restrict__ partials) {
+    Mirror<T> mirror, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ A s_part[kCombineWaves > 1 ? kCombineWaves - 1 : 1][kWave][VEC];
     const int i = blockIdx.x;
@@ -808,7 +778,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
     const int64_t share = ceil_div(s1 - s0, int64_t(kCombineWaves));
     const int64_t a = s0 + wave * share < s1 ? s0 + wave * share : s1;
     const int64_t b = a + share < s1 ? a + share : s1;
-    A rsum = A(0), qsum = A(0);
+    A rsum = A(0);
     for (int t0 = 0; t0 < d; t0 += kWave * VEC) {       // the same trip count in every wave (barriers inside)
         const int c0 = t0 + lane * VEC;
         const bool ok = c0 < d;
@@ -856,7 +826,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
                 }
                 const Pack<T, VEC> x = load_pack_stream<T, VEC>(X + r * ldx + c0);
                 const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
-                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out, qsum);
+                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out);
             }
             mirror_store<T, VEC, kWave>(mirror, r, c0, out, ok, lane, 0);
         }
@@ -864,10 +834,6 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
     if (wave == 0) {
         rsum = group_sum<kWave>(rsum);
         if (lane == 0) partials[i] = double(rsum);
-        if (sq_out != nullptr) {
-            qsum = group_sum<kWave>(qsum);  // lane l holds the packs l, l + 64, ...: K0's order (zero where K0 has no lane)
-            if (lane == 0) sq_out[r] = qsum;
-        }
     }
 }
 

@@ -97,35 +97,17 @@ def _round_up(a: int, b: int) -> int:
 
 
 MIN_SLICE_ROW_BYTES = 64
-GRID_SLICE_ROW_BYTES = 128
-
-
-def pick_division(d: int, dtype: torch.dtype, world: int):
-    """(exchange, column groups) for ``exchange="auto"``.  Column split while a rank's slice of a row is at least
-    MIN_SLICE_ROW_BYTES (HBM is fetched in 64/128-byte lines: below that every gather drags in bytes of columns the rank
-    does not own -- measured on the 10M-vertex bf16 graph, DESIGN.md 6.1); else divide the rows and exchange halo rows.
-    The 2-D division ("grid") is never picked here: on a fully connected fabric it loses to the halo division, because
-    the row exchange of a column group runs over R - 1 of a GPU's 7 links instead of all of them (config 4's shape at
-    N = 8, one rank's kernels and bytes measured, profiles/r04_rank_compute_grid_powerlaw10m.jsonl: halo 1.95 ms of
-    kernels + 175 MB per link; 4 x 2 grid 2.38 ms + 237 MB per link; 2 x 4 grid 3.51 ms + 290 MB on ONE link).  It stays
-    available by name for fabrics where links are shared (``grid_cols``; `grid_cols_for` suggests C)."""
-    row_bytes = d * torch.empty(0, dtype=dtype).element_size()
-    world = max(world, 1)
-    return ("columns", world) if row_bytes // world >= MIN_SLICE_ROW_BYTES else ("halo", 1)
-
-
-def grid_cols_for(d: int, dtype: torch.dtype, world: int) -> int:
-    """Column groups of ``exchange="grid"`` when the caller names none: the most (a proper divisor of the world size)
-    whose slices are still GRID_SLICE_ROW_BYTES wide; else the smallest proper divisor."""
-    row_bytes = d * torch.empty(0, dtype=dtype).element_size()
-    for C in range(world - 1, 1, -1):
-        if world % C == 0 and row_bytes // C >= GRID_SLICE_ROW_BYTES:
-            return C
-    return next((c for c in range(2, world) if world % c == 0), world)
 
 
 def pick_exchange(d: int, dtype: torch.dtype, world: int) -> str:
-    return pick_division(d, dtype, world)[0]
+    """The division ``exchange="auto"`` takes.  Column split while a rank's slice of a row is at least
+    MIN_SLICE_ROW_BYTES (HBM is fetched in 64/128-byte lines: below that every gather drags in bytes of columns the rank
+    does not own -- measured on the 10M-vertex bf16 graph, DESIGN.md 6.1); else divide the rows and exchange halo rows.
+    (A 2-D division -- R row groups x C column groups -- was built and measured in round 4 and removed in round 5: on a
+    fully connected fabric it loses to the halo division, because a column group's row exchange runs over R - 1 of a
+    GPU's 7 links instead of all of them; numbers in profiles/HISTORY.md, profiles/r04_rank_compute_grid_powerlaw10m.jsonl.)"""
+    row_bytes = d * torch.empty(0, dtype=dtype).element_size()
+    return "columns" if row_bytes // max(world, 1) >= MIN_SLICE_ROW_BYTES else "halo"
 
 
 def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
@@ -163,8 +145,7 @@ class StagedZ:
         return self._resolve()
 
     def piece(self) -> dict:
-        """{'kind': 'columns', 'c0', 'c1', 'Z': [V, c1 - c0]}, {'kind': 'rows', 'vertex': int64 [n], 'Z': [n, d]} or
-        (2-D division) {'kind': 'tile', 'vertex', 'c0', 'c1', 'Z': [n, c1 - c0]}."""
+        """{'kind': 'columns', 'c0', 'c1', 'Z': [V, c1 - c0]} or {'kind': 'rows', 'vertex': int64 [n], 'Z': [n, d]}."""
         if self._where is None:
             raise RuntimeError("this copy holds the whole matrix: use result()")
         return dict(self._where, Z=self._resolve())
@@ -182,15 +163,17 @@ def place_piece(out: torch.Tensor, piece: dict) -> None:
 
 class SweepEngine:
     STAGE_SLOTS = 3          # copies of Z that may be in flight to the host at once (stage_Z)
-    # Z tables.  Two would do for the sweeps (read old / write new); the third replaces the reference's
+    # Z tables.  Two do for the sweeps (read old / write new).  A third replaces the reference's
     # `prev_Z = graph.Z.clone()` (embedder.py:58): snapshot() PINS the current table instead of copying 2 GB, and the
-    # sweeps of the round ping-pong between the other two.
+    # sweeps of the round ping-pong between the other two.  It is allocated by the first snapshot(): a propagate-only
+    # run never pays for it (2 GB at config 3, 16 GiB at the 16M-vertex capacity run) -- except in halo_p2p mode, where
+    # the tables are shared allocations mapped by every peer and all three are made at start-up.
     N_TABLES = 3
     # time_kernels: at most this many sweeps get HIP events.  Hundreds of live timing events slow every launch down
     # (config 2, 200 timed sweeps: 0.475 ms per step with 1 000 events alive, 0.248 ms with 160)
     MAX_TIMED_SWEEPS = 32
 
-    EXCHANGES = ("auto", "columns", "grid", "halo", "halo_p2p", "allgather", "allgather_all")
+    EXCHANGES = ("auto", "columns", "halo", "halo_p2p", "allgather", "allgather_all")
 
     def __init__(self, csr: HostCSR, X: torch.Tensor, device, kernels=None, *, cosine_mode: str = "reference",
                  process_group=None, chunks: Optional[int] = None, long_threshold: Optional[int] = None,
@@ -199,13 +182,9 @@ class SweepEngine:
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
                  phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None,
-                 grid_cols: Optional[int] = None, table_alloc: str = "torch", fused_norms: bool = False):
+                 table_alloc: str = "torch"):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
-        "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_division).
-        "grid" -- both at once, for rows too narrow to cut N ways: the N ranks form R row groups x C column groups
-        (``grid_cols`` = C; rank = r * C + c).  Rank (r, c) holds columns slice c of the rows of group r: the row
-        exchange ("halo") runs among the R ranks that hold the same columns and moves SLICES of rows (1/C of the bytes),
-        build_P sums the partial dot products over the C ranks that hold the same rows, the delta over everybody.
+        "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
         is independent per column, so a sweep needs no exchange at all (only the delta scalar is all-reduced);
         build_P all-reduces the partial dot products (E values, once per outer iteration).
@@ -231,15 +210,7 @@ class SweepEngine:
         if table_alloc not in ("torch", "contiguous"):
             raise ValueError("table_alloc must be 'torch' or 'contiguous'")
         self.table_alloc, self._own_tables, self.table_alloc_note = table_alloc, [], None
-        # Where build_P's row norms come from (similarity.py:37).  Always available: row_sqnorm (K0), a 2 GB pass over Z.
-        # In the outer loop (embedder.py:58-60) the pass that measures how far a round moved Z reads every row of the
-        # new Z anyway and leaves the norms behind (l1_between) -- free, and what Embedder.iterate() lives on.
-        # fused_norms=True: the K3 kernels leave them behind too (every sweep): build_P never runs K0 after the first,
-        # but every sweep pays ~1.2 % (measured on one box, interleaved: config 3 3.946 -> 3.991 ms per sweep for
-        # 0.34 ms per build_P, and a propagate runs >= 11 sweeps per build_P: a net loss, profiles/r04_fused_norms_ab.jsonl)
-        # -- hence off.
-        self.fused_norms = bool(fused_norms)
-        X = self._choose_division(csr, X, process_group, comm, exchange, grid_cols)
+        X = self._choose_division(csr, X, process_group, comm, exchange)
         self._choose_class_pass(csr, class_threshold, class_chunk, class_k1, class_phases, phase_threshold)
         self._build_layout(csr, chunks, shuffle, seed, hot_rows_first)
         self._choose_row_bins(long_threshold, hub_threshold)
@@ -250,18 +221,15 @@ class SweepEngine:
         self._alloc_scratch(delta_stream, overlap_chunks)
 
     # ---- constructor steps ----------------------------------------------------------------------------------
-    def _choose_division(self, csr: HostCSR, X: torch.Tensor, process_group, comm, exchange: str,
-                         grid_cols: Optional[int]) -> torch.Tensor:
-        """Who the ranks are and how the sweep is divided over them; returns this rank's columns of X.
-        Every division is an R x C grid of the ranks (rank = r * C + c): C column groups (C = N: "columns"; C = 1: the
-        row divisions), R = N / C row groups.  ``row_comm`` joins the C ranks that hold the same rows (they sum partial
-        dot products in build_P), ``col_comm`` the R ranks that hold the same columns (they exchange rows)."""
+    def _choose_division(self, csr: HostCSR, X: torch.Tensor, process_group, comm, exchange: str) -> torch.Tensor:
+        """Who the ranks are and how the sweep is divided over them; returns this rank's columns of X.  Either the
+        COLUMNS are divided ("columns": C = N column groups, every rank holds all rows) or the ROWS are (C = 1)."""
         self.pg = process_group
         self.comm = comm if comm is not None else (TorchComm(process_group) if process_group is not None else None)
         self.world = self.comm.world if self.comm is not None else 1
         rank = self.comm.rank if self.comm is not None else 0
         if exchange not in self.EXCHANGES:
-            raise ValueError("exchange must be 'auto', 'columns', 'grid', 'halo', 'halo_p2p', 'allgather' or "
+            raise ValueError("exchange must be 'auto', 'columns', 'halo', 'halo_p2p', 'allgather' or "
                              f"'allgather_all', got {exchange!r}")
         # a one-rank group whose comm insists on its collectives keeps the division it is given (RCCL rehearsal on a
         # one-GPU box, comm.TorchComm(force_collectives=True)); "auto" is then the plain one-GPU plan
@@ -269,28 +237,12 @@ class SweepEngine:
             "columns", "allgather", "allgather_all")
         divided = self.world > 1 or self._forced
         if exchange == "auto":
-            exchange, auto_cols = pick_division(int(X.shape[1]), X.dtype, self.world)
-            grid_cols = grid_cols if grid_cols is not None else auto_cols
-        if exchange == "grid" and divided:
-            if grid_cols is None:
-                grid_cols = grid_cols_for(int(X.shape[1]), X.dtype, self.world)
-            if grid_cols < 1 or self.world % grid_cols:
-                raise ValueError(f"grid_cols={grid_cols} does not divide the {self.world} ranks")
-            if grid_cols == self.world:         # one row group: that IS the column split
-                exchange = "columns"
-            elif grid_cols == 1:                # one column group: that IS the halo division
-                exchange = "halo"
+            exchange = pick_exchange(int(X.shape[1]), X.dtype, self.world)
         self._exchange_asked = exchange
         self.exchange = exchange if divided else "none"
-        self.grid = divided and exchange == "grid"
-        self.C = (self.world if exchange == "columns" else grid_cols if self.grid else 1) if divided else 1
-        self.R = self.world // self.C
-        self.r, self.c = divmod(rank, self.C)
-        self.columns = divided and self.C > 1 or (self._forced and exchange == "columns")
-        self.row_comm = self.col_comm = self.comm
-        if self.grid:
-            self.row_comm = self.comm.split([[r * self.C + c for c in range(self.C)] for r in range(self.R)])
-            self.col_comm = self.comm.split([[r * self.C + c for r in range(self.R)] for c in range(self.C)])
+        self.columns = divided and exchange == "columns"
+        self.C = self.world if self.columns else 1      # column groups
+        self.c = rank if self.columns else 0
         self.V, self.d_full = csr.num_vertices, int(X.shape[1])
         self.E_total = csr.num_edges
         self.col0, self.col1 = column_slice(self.d_full, X.dtype, self.C, self.c) if self.columns else (0, self.d_full)
@@ -299,17 +251,17 @@ class SweepEngine:
             self.ld_max = _round_up(column_slice(self.d_full, X.dtype, self.C, 0)[1], _hip.VEC_ELEMS[X.dtype])
         self.d = self.col1 - self.col0                 # columns this rank computes (0: an idle rank, d < C packs)
         self.ld = _round_up(self.d, _hip.VEC_ELEMS[X.dtype])
-        # rows are divided over the `row_world` ranks of a column group; with one row group a rank owns every row
-        self.row_world, self.row_rank = self.R, self.r
-        self.halo = self.row_world > 1 and exchange in ("halo", "halo_p2p", "grid")
+        # rows are divided over `row_world` ranks; with the column split a rank owns every row
+        self.row_world, self.row_rank = (1, 0) if self.columns else (self.world, rank)
+        self.halo = self.row_world > 1 and exchange in ("halo", "halo_p2p")
         self.p2p = self.halo and exchange == "halo_p2p"       # finished rows are stored straight into the readers' tables
         if self.p2p and self.world > 8:
             raise ValueError("halo_p2p addresses at most 8 GPUs (one box)")
         # Everything that decides the LAYOUT (which rows are class rows, hence the order of every row's edges) follows
-        # from `d_plan`: the rank's own width -- except with several column groups, where it is the widest slice
-        # (group 0's) on EVERY rank, one without columns included: build_P all-reduces the partial dot products element
-        # by element, so all ranks of a row group must hold their edges in one order, even when their slices straddle a
-        # lane-layout boundary (33 packs over two ranks: 32 and 16 lanes per row, class thresholds 64 and 256).
+        # from `d_plan`: the rank's own width -- except with the column split, where it is the widest slice (rank 0's)
+        # on EVERY rank, one without columns included: build_P all-reduces the partial dot products element by
+        # element, so all ranks must hold their edges in one order, even when their slices straddle a lane-layout
+        # boundary (33 packs over two ranks: 32 and 16 lanes per row, class thresholds 64 and 256).
         self.d_plan = self.d
         if self.columns:
             c0, c1 = column_slice(self.d_full, X.dtype, self.C, 0)
@@ -559,8 +511,8 @@ class SweepEngine:
             self.Zbuf = [b.tensor for b in self._shared]
             self.peer_tables, self._mapped = self.comm.share_matrices(self.k, self._shared)
             self._build_p2p_mirrors(deg)
-        else:
-            self.Zbuf = [self._new_table(f"Z{i}", self.part.padded_vertices) for i in range(self.N_TABLES)]
+        else:           # the third table comes with the first snapshot() (_third_table)
+            self.Zbuf = [self._new_table(f"Z{i}", self.part.padded_vertices) for i in range(2)]
         # cur: the table holding the current embeddings; hold: the one snapshot() pinned (never a sweep's destination);
         # _prev_cur: what cur was before the latest sweep_launch (discard_launch); _tick: which of the two delta slots
         # the next launch uses
@@ -595,9 +547,11 @@ class SweepEngine:
             self._delta_stream = torch.cuda.Stream(self.device)
         self.block_out = torch.zeros(len(self.blocks), dtype=torch.float64, device=dev)
         # |z_v|^2 of the owned rows, one copy per Z table, and whether it matches the table (`sq_ok`): written by K0 in
-        # build_P, by the outer-delta pass (l1_between) or -- fused_norms -- by the K3 kernels that write the table.
-        self.sq_pp = [torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev) for _ in range(self.N_TABLES)]
-        self.sq_ok = [False] * self.N_TABLES
+        # build_P or by the outer-delta pass (l1_between), which reads every row of the new Z anyway -- free, and what
+        # Embedder.iterate() lives on.  (The K3 kernels could leave them behind too: built in round 4, +1.1-1.4 % per
+        # sweep to save 0.34 ms per build_P, a net loss -- removed; profiles/r04_fused_norms_ab.jsonl.)
+        self.sq_pp = [torch.zeros(self.part.n_local, dtype=self.acc_dtype, device=dev) for _ in self.Zbuf]
+        self.sq_ok = [False] * len(self.Zbuf)
         self.sq_full: Optional[torch.Tensor] = None
         self.sweeps_done = 0
         # optional per-kernel timing with HIP events on the launch stream (bench.py)
@@ -701,7 +655,7 @@ class SweepEngine:
         for other in self.Zbuf[1:]:
             other.copy_(first)
         self.cur, self.hold, self._prev_cur = 0, None, 0
-        self.sq_ok = [False] * self.N_TABLES
+        self.sq_ok = [False] * len(self.Zbuf)
         self.P_valid = False
         self.quiet_stale = False
         if self.p2p:        # nobody may store into a table that its owner is still loading
@@ -713,7 +667,7 @@ class SweepEngine:
         if self.halo:       # own rows of every rank of the column group, in slot order (slot = owner * n_local + local row)
             n = self.part.n_local
             everyone = torch.empty(self.row_world * n, self.ld, dtype=self.dtype, device=self.device)
-            self.col_comm.all_gather_into(everyone, self.Zcur[:n].contiguous())
+            self.comm.all_gather_into(everyone, self.Zcur[:n].contiguous())
             return everyone[self.slot]
         self._sync_quiet_rows()
         return self.Zcur[self.pos]
@@ -728,7 +682,7 @@ class SweepEngine:
         mine[:, :self.ld] = Zv
         del Zv
         everyone = torch.empty(self.C * self.V, self.ld_max, dtype=self.dtype, device=self.device)
-        self.row_comm.all_gather_into(everyone, mine)
+        self.comm.all_gather_into(everyone, mine)
         everyone = everyone.view(self.C, self.V, self.ld_max)
         out = torch.empty(self.V, self.d_full, dtype=self.dtype, device=self.device)
         for c in range(self.C):
@@ -744,7 +698,7 @@ class SweepEngine:
         stream.  At most STAGE_SLOTS copies are in flight; with none free this call waits for ``result()`` of an
         earlier one (possibly on another thread).
         Several GPUs: ``pieces=True`` stages only what THIS rank holds -- its column slice of every row (column
-        split), its own rows (row splits) or its columns of its rows (2-D division) -- the same way and with no collective: N PCIe links drain in parallel and
+        split) or its own rows (row splits) -- the same way and with no collective: N PCIe links drain in parallel and
         whoever wants the whole matrix puts the ranks' pieces together on the host (``StagedZ.piece``,
         ``place_piece``; ``Embedder`` does, through files).  Without ``pieces`` a multi-GPU run gathers synchronously
         (``get_Z``: collective), as a host-memory engine does."""
@@ -757,7 +711,7 @@ class SweepEngine:
                 return StagedZ(ready=self.get_Z())
             if by_rows:
                 own = torch.cat([self._zrows(self.Zcur, b)[:, :self.d] for b in self.blocks]).clone()
-                return StagedZ(ready=own, where=dict(cols, kind="tile" if cols else "rows",
+                return StagedZ(ready=own, where=dict(cols, kind="rows",
                                                      vertex=torch.from_numpy(self.local.vertex.astype(np.int64))))
             return StagedZ(ready=self.Zcur[self.pos, :self.d].clone(), where=dict(cols, kind="columns"))
         n_rows = self.part.n_local if by_rows else self.V
@@ -781,7 +735,7 @@ class SweepEngine:
                 slot["dev"][self._rows(b)].copy_(self._zrows(self.Zcur, b))
             if self._own_vertex is None:
                 self._own_vertex = torch.from_numpy(self.local.vertex.astype(np.int64))
-            where = dict(cols, kind="tile" if cols else "rows", vertex=self._own_vertex)
+            where = dict(cols, kind="rows", vertex=self._own_vertex)
         else:
             torch.index_select(self.Zcur, 0, self.pos, out=slot["dev"])     # vertex order, on the sweep stream
             if self.world > 1:
@@ -807,7 +761,7 @@ class SweepEngine:
             return
         begin, end, q = span
         mine = self.Zcur[begin + self.part.rank * q: begin + (self.part.rank + 1) * q]
-        self.col_comm.all_gather_into(self.Zcur[begin:end], mine)
+        self.comm.all_gather_into(self.Zcur[begin:end], mine)
         self.quiet_stale = False
 
     # ---- build_P (graph.py:118-128) -----------------------------------------------------
@@ -817,16 +771,13 @@ class SweepEngine:
         mode = _hip.SCORE_MODES[self.cosine_mode]
         busy = self.d > 0                   # a column-split rank without columns only joins the collectives
         sq = None
-        if not self.sq_ok[self.cur]:        # nobody has left this table's norms behind: K0
+        # the own rows' norms -- unless a row division in per_edge mode is about to norm the WHOLE table (own rows and
+        # the copies of the rows it reads) in one pass below
+        whole_table = self.cosine_mode == "per_edge" and self.row_world > 1
+        if not self.sq_ok[self.cur] and not whole_table:    # nobody has left this table's norms behind: K0
             if busy:
                 for b in self.blocks:
                     k.row_sqnorm(self._zrows(Z, b), self.d, self.sq_pp[self.cur][self._rows(b)])
-            if self.fused_norms and not any(self.sq_ok):
-                # fresh from set_Z: all tables are alike, and the K3 kernels will only write the rows WITH out-edges
-                for i in range(self.N_TABLES):
-                    if i != self.cur:
-                        self.sq_pp[i].copy_(self.sq_pp[self.cur])
-                self.sq_ok = [True] * self.N_TABLES
             self.sq_ok[self.cur] = True
         sq_own = self.sq_pp[self.cur]       # K0's bits, whoever wrote them (tests: test_row_norms_are_bitwise_k0)
         if self.cosine_mode == "reference":
@@ -840,7 +791,7 @@ class SweepEngine:
             elif busy:
                 k.row_sqnorm(Z, self.d, self.sq_full)   # row split: every rank holds valid copies of all rows it reads
             if self.columns:
-                self._all_reduce(self.sq_full, self.row_comm)     # partial norms over the column groups' slices
+                self._all_reduce(self.sq_full)                    # partial norms over the ranks' column slices
             sq = self.sq_full
         if self.E_loc > 0 and not self.columns:
             for i, b in enumerate(self.blocks):
@@ -855,8 +806,7 @@ class SweepEngine:
                                        self.slabs[i % len(self.slabs)], fuse_softmax=True,
                                        n_slots=self.class_slots[i], row_parts=self.softmax_row_parts)
         elif self.E_loc > 0:
-            # several column groups: dot products of the owned columns, summed over the ranks that hold the same rows,
-            # then denominators + softmax
+            # column split: dot products of the owned columns, summed over the ranks, then denominators + softmax
             if busy:
                 for i, b in enumerate(self.blocks):
                     k.edge_score(self.rowptr[b.local_start:], self.colidx, b.nrows, b.row0, Z, self.d,
@@ -868,7 +818,7 @@ class SweepEngine:
                                            _hip.SCORE_RAW_DOT, None, None, self.P)
             else:
                 self.P.zero_()
-            self._all_reduce(self.P, self.row_comm)               # the ranks that hold the same rows, other columns
+            self._all_reduce(self.P)                              # every rank holds the same rows, other columns
             for i, b in enumerate(self.blocks):
                 rp = self.rowptr[b.local_start:]
                 k.edge_score_finalize(rp, self.colidx, b.nrows, b.row0, mode, self.sums2, sq, self.P)
@@ -902,7 +852,6 @@ class SweepEngine:
                 rp, Xb, Zn = self.rowptr[b.local_start:], self.X_loc[self._rows(b)], self._zrows(Znew, b)
                 po = self.partial_off[i]
                 mir = self.mirrors_p2p[dst][i] if self.p2p else self.mirrors[i]
-                sq_new = self.sq_pp[dst][b.local_start:] if self.fused_norms else None   # the finished rows' norms go with Z_new
                 po_mid = po + k.spmm_partials_len(b.nrows, 0)
                 po_hub = po_mid + (0 if self.mid_rows[i] is None else self.mid_rows[i].numel())
                 po_split = po_hub + (0 if self.hub_rows[i] is None else self.hub_rows[i].numel())
@@ -916,28 +865,24 @@ class SweepEngine:
                     rows_c, slot_ptr, it_e0, it_len, it_slot, _, ipb = self.class_rows[i]
                     steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
                                                      ipb, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
-                                                     Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:],
-                                                     mirror=mir, sq_out=sq_new)))
+                                                     Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:], mirror=mir)))
                 if self.split_rows[i] is not None:
                     rows_s, seg_ptr, seg_row = self.split_rows[i]
                     steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
                                                      seg_row, self.segment_edges, b.row0, Zold, Xb, gamma, Zn, self.d,
-                                                     self.slabs[i % len(self.slabs)], self.partials[po_split:], mirror=mir,
-                                                     sq_out=sq_new)))
+                                                     self.slabs[i % len(self.slabs)], self.partials[po_split:], mirror=mir)))
                 steps.append(("event", i, 4))
                 if self.hub_rows[i] is not None:
                     steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
-                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:],
-                                                     mirror=mir, sq_out=sq_new)))
+                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:], mirror=mir)))
                 steps.append(("event", i, 1))
                 if self.mid_rows[i] is not None:
                     steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.mid_rows[i], 4,
-                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:],
-                                                     mirror=mir, sq_out=sq_new)))
+                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:], mirror=mir)))
                 steps.append(("event", i, 2))
                 steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb,
                                                  gamma, Zn, self.d, self.long_threshold, self.partials[po:],
-                                                 sinks_untouched=True, mirror=mir, sq_out=sq_new)))
+                                                 sinks_untouched=True, mirror=mir)))
                 steps.append(("event", i, 3))
                 if b.span is not None:
                     steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))
@@ -967,7 +912,7 @@ class SweepEngine:
             raise RuntimeError("sweep() before build_P()")
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
         src = self.cur
-        dst = next(i for i in range(self.N_TABLES) if i != src and i != self.hold)
+        dst = next(i for i in range(len(self.Zbuf)) if i != src and i != self.hold)
         parity = self._tick                 # delta slot of this launch (two launches may be in flight)
         self._tick ^= 1
         if self._delta_stream is not None and self._delta_busy[parity]:
@@ -1001,9 +946,9 @@ class SweepEngine:
                         if events is not None:
                             events[step[1]][step[2]].record()
                     elif kind == "allgather":
-                        works.append(self.col_comm.all_gather_into(step[1], step[2], async_op=True))
+                        works.append(self.comm.all_gather_into(step[1], step[2], async_op=True))
                     else:
-                        works.append(self.col_comm.all_to_all_rows(step[1], step[2], step[3], step[4], async_op=True))
+                        works.append(self.comm.all_to_all_rows(step[1], step[2], step[3], step[4], async_op=True))
         if side:
             for st in side:
                 done = torch.cuda.Event()
@@ -1040,7 +985,7 @@ class SweepEngine:
             if self._delta_ev is not None:
                 self._delta_ev[parity].record()
         self._prev_cur, self.cur = src, dst
-        self.sq_ok[dst] = self.fused_norms and self.sq_ok[src]   # the K3 kernels wrote its norms, or nobody did
+        self.sq_ok[dst] = False
         self.sweeps_done += 1
         self.quiet_stale = True
         return parity
@@ -1128,7 +1073,7 @@ class SweepEngine:
                 "class_affinity": self.class_affinity, "mega_segment_edges": self.mega_segment_edges,
                 "class_items_per_block": [c[6] for c in self.class_rows if c is not None][:1],
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange,
-                "grid": [self.R, self.C] if self.grid else None, "fused_norms": self.fused_norms}
+                }
 
     def exchange_bytes_per_sweep(self) -> int:
         """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""
@@ -1143,7 +1088,18 @@ class SweepEngine:
     def snapshot(self) -> None:
         """Remember the current embeddings (the reference's ``prev_Z = graph.Z.clone()``, embedder.py:58) WITHOUT a
         copy: the current table is pinned -- no sweep writes to it until the next snapshot() or set_Z()."""
+        if len(self.Zbuf) < self.N_TABLES:
+            self._third_table()
         self.hold = self.cur
+
+    def _third_table(self) -> None:
+        """The table the sweeps need once one is pinned, made on the first snapshot(): a copy of the current one, so the
+        rows the kernels never write (no out-edges; other ranks' constant halo rows) agree in all three."""
+        table = self._new_table(f"Z{len(self.Zbuf)}", self.part.padded_vertices)
+        table.copy_(self.Zcur)
+        self.Zbuf.append(table)
+        self.sq_pp.append(torch.zeros_like(self.sq_pp[0]))
+        self.sq_ok.append(False)
 
     def l1_between(self, i: int, j: int) -> float:
         """sum |Zbuf[i] - Zbuf[j]| over the owned rows, all ranks (embedder.py:60's reduction).  The pass reads every
@@ -1164,7 +1120,7 @@ class SweepEngine:
         return self.l1_between(self.cur, self.hold)
 
     # ---- collectives ------------------------------------------------------------------
-    def _all_reduce(self, t: torch.Tensor, comm=None) -> None:
-        """Sum over all ranks, or over the ranks of `comm` (row_comm: the ranks that hold the same rows)."""
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        """Sum over all ranks."""
         if self.world > 1 or self._forced:
-            (comm if comm is not None else self.comm).all_reduce_sum(t)
+            self.comm.all_reduce_sum(t)

@@ -471,7 +471,7 @@ class Graph(torch.utils.data.Dataset):
         out = torch.empty(self.csr.num_edges, dtype=eng.acc_dtype)
         local = (torch.from_numpy(eng.local.edge_origin), eng.P[:eng.E_loc].to("cpu"))
         # rows divided: the ranks that hold the same columns have the rows of P between them
-        pieces = [local] if eng.row_world == 1 else eng.col_comm.all_gather_object(local)
+        pieces = [local] if eng.row_world == 1 else eng.comm.all_gather_object(local)
         for origin, vals in pieces:
             out[origin] = vals
         return out

@@ -38,9 +38,11 @@
 extern "C" {
 #endif
 
-#define CLANE_ABI_VERSION 3 /* 2: + clane_build_info, clane_xcc_ids, clane_check_csr, clane_spmm_update_class_*, clane_edge_score_class_*
-                             * 3: every clane_spmm_update* takes `sq_out` (the finished rows' squared norms, K0 fused into K3),
-                             *    clane_l1_distance_* takes `sq_a` (the same from the outer-delta pass), clane_device_alloc_contiguous */
+#define CLANE_ABI_VERSION 4 /* 2: + clane_build_info, clane_xcc_ids, clane_check_csr, clane_spmm_update_class_*, clane_edge_score_class_*
+                             * 3: clane_l1_distance_* takes `sq_a` (the rows' squared norms from the outer-delta pass: free),
+                             *    clane_device_alloc_contiguous; every clane_spmm_update* took `sq_out` (the same norms out of K3)
+                             * 4: `sq_out` is gone again: it cost every sweep 1.1-1.4 % to save one 0.34 ms pass per build_P, and a
+                             *    propagate runs >= 11 sweeps per build_P (profiles/r04_fused_norms_ab.jsonl) */
 
 #define CLANE_OK 0
 #define CLANE_ERR_INVALID_ARGUMENT (-1)
@@ -179,10 +181,6 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
  *     Z_new[i,:] = X[i,:] + gamma * sum_e P[e] * Z_old[colidx[e],:]     rowptr[i] <= e < rowptr[i+1]
  *     Z_new[i,:] = Z_old[row0+i,:]                                       if the row has no out-edge (embedder.py:88-89)
  *     delta_partials[b] = partial sums of |Z_new[i,:] - Z_old[row0+i,:]| (fixed order; reduce with clane_reduce_partials)
- *     sq_out[i]         = |Z_new[i,:]|^2 of the stored values (accumulate type; NULL: not wanted) -- bit for bit what
- *                         clane_row_sqnorm_* gives on Z_new, so the next clane_edge_score_* / clane_degree_weighted_sums_*
- *                         (similarity.py:37's norms, one outer round later) need not read Z again; rows the call does
- *                         not write (CLANE_SPMM_SINKS_UNTOUCHED, rows above long_threshold) keep their entry
  * Z_new must not alias Z_old.
  *  clane_spmm_update_*      : one wave per row; rows with more than `long_threshold` edges (0 = never)
  *                             are skipped.  Writes clane_spmm_partials_len(nrows, 0) doubles.
@@ -198,28 +196,27 @@ int clane_segment_softmax_f64(const int64_t *rowptr, int64_t nrows, double *vals
 int clane_spmm_update_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
                           const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
                           int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, const clane_mirror_t *mirror,
-                          float *sq_out, double *delta_partials, void *stream);
+                          double *delta_partials, void *stream);
 int clane_spmm_update_f64(const int64_t *rowptr, const int32_t *colidx, const double *P, int64_t nrows, int64_t row0,
                           const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma, double *Z_new,
                           int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, const clane_mirror_t *mirror,
-                          double *sq_out, double *delta_partials, void *stream);
+                          double *delta_partials, void *stream);
 int clane_spmm_update_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P, int64_t nrows, int64_t row0,
                            const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
-                           uint16_t *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags, const clane_mirror_t *mirror,
-                          float *sq_out, double *delta_partials,
-                           void *stream);
+                           uint16_t *Z_new, int64_t ldo, int32_t d, int64_t long_threshold, int32_t flags,
+                           const clane_mirror_t *mirror, double *delta_partials, void *stream);
 int clane_spmm_update_long_f32(const int64_t *rowptr, const int32_t *colidx, const float *P, const int32_t *long_rows,
                                int64_t n_long, int32_t waves_per_row, int64_t row0, const float *Z_old, int64_t ldz, const float *X,
                                int64_t ldx, float gamma, float *Z_new, int64_t ldo, int32_t d,
-                               const clane_mirror_t *mirror, float *sq_out, double *delta_partials, void *stream);
+                               const clane_mirror_t *mirror, double *delta_partials, void *stream);
 int clane_spmm_update_long_f64(const int64_t *rowptr, const int32_t *colidx, const double *P,
                                const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const double *Z_old,
                                int64_t ldz, const double *X, int64_t ldx, double gamma, double *Z_new, int64_t ldo,
-                               int32_t d, const clane_mirror_t *mirror, double *sq_out, double *delta_partials, void *stream);
+                               int32_t d, const clane_mirror_t *mirror, double *delta_partials, void *stream);
 int clane_spmm_update_long_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P,
                                 const int32_t *long_rows, int64_t n_long, int32_t waves_per_row, int64_t row0, const uint16_t *Z_old,
                                 int64_t ldz, const uint16_t *X, int64_t ldx, float gamma, uint16_t *Z_new,
-                                int64_t ldo, int32_t d, const clane_mirror_t *mirror, float *sq_out, double *delta_partials,
+                                int64_t ldo, int32_t d, const clane_mirror_t *mirror, double *delta_partials,
                                 void *stream);
 
 /*  clane_spmm_update_split_* : hub rows, each cut into segments of `edges_per_segment` edges (a multiple of 64)
@@ -234,19 +231,19 @@ int clane_spmm_update_split_f32(const int64_t *rowptr, const int32_t *colidx, co
                                 const int64_t *seg_ptr, const int32_t *seg_row, int64_t n_split, int64_t n_segments,
                                 int64_t edges_per_segment, int64_t row0, const float *Z_old, int64_t ldz,
                                 const float *X, int64_t ldx, float gamma, float *Z_new, int64_t ldo, int32_t d,
-                                float *slab, const clane_mirror_t *mirror, float *sq_out, double *delta_partials, void *stream);
+                                float *slab, const clane_mirror_t *mirror, double *delta_partials, void *stream);
 int clane_spmm_update_split_f64(const int64_t *rowptr, const int32_t *colidx, const double *P,
                                 const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,
                                 int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,
                                 const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma,
                                 double *Z_new, int64_t ldo, int32_t d, double *slab, const clane_mirror_t *mirror,
-                                double *sq_out, double *delta_partials, void *stream);
+                                double *delta_partials, void *stream);
 int clane_spmm_update_split_bf16(const int64_t *rowptr, const int32_t *colidx, const float *P,
                                  const int32_t *split_rows, const int64_t *seg_ptr, const int32_t *seg_row,
                                  int64_t n_split, int64_t n_segments, int64_t edges_per_segment, int64_t row0,
                                  const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
                                  uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
-                                 float *sq_out, double *delta_partials, void *stream);
+                                 double *delta_partials, void *stream);
 
 /*  clane_edge_score_class_* : K1 (graph.py:119-123 + similarity.py:26-37) over the listed long rows with XCD-affine
  *                             gathers -- the build_P counterpart of clane_spmm_update_class_* below, over the SAME item
@@ -299,19 +296,19 @@ int clane_spmm_update_class_f32(const int32_t *colidx, const float *P, const int
                                 const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
                                 const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
                                 int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
-                                float *sq_out, double *delta_partials, void *stream);
+                                double *delta_partials, void *stream);
 int clane_spmm_update_class_f64(const int32_t *colidx, const double *P, const int64_t *item_e0, const int32_t *item_len,
                                 const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
                                 const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
                                 const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma,
                                 double *Z_new, int64_t ldo, int32_t d, double *slab, const clane_mirror_t *mirror,
-                                double *sq_out, double *delta_partials, void *stream);
+                                double *delta_partials, void *stream);
 int clane_spmm_update_class_bf16(const int32_t *colidx, const float *P, const int64_t *item_e0, const int32_t *item_len,
                                  const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
                                  const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
                                  const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
                                  uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
-                                 float *sq_out, double *delta_partials, void *stream);
+                                 double *delta_partials, void *stream);
 
 /* out[0] = sum of partials[0..n) in a fixed order (bitwise reproducible).  Finishes embedder.py:94 / :60.
  * ws: clane_reduce_ws_len() doubles. */

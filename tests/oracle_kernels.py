@@ -123,7 +123,7 @@ class OracleKernels(KernelBackend):
     def contiguous_matrix(self, shape, dtype, device):
         return self.shareable_matrix(shape, dtype, device)          # host memory: nothing to be contiguous about
 
-    def _spmm_rows(self, rowptr, colidx, P, rows_sel, row0, Z_old, X, gamma, Z_new, d, mirror=None, sq_out=None):
+    def _spmm_rows(self, rowptr, colidx, P, rows_sel, row0, Z_old, X, gamma, Z_new, d, mirror=None):
         rp = _np(rowptr)
         acc = P.dtype
         total = 0.0
@@ -136,8 +136,6 @@ class OracleKernels(KernelBackend):
             else:
                 new = own.clone()
             Z_new[r, :d] = new
-            if sq_out is not None:          # K0 fused into K3: the squared norm of the STORED row
-                sq_out[r] = new.to(acc).pow(2).sum()
             if mirror is not None:
                 mp, ms, mbs = mirror
                 for s in ms[int(mp[r]):int(mp[r + 1])].tolist():
@@ -146,35 +144,35 @@ class OracleKernels(KernelBackend):
         return total
 
     def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials,
-                    sinks_untouched=False, mirror=None, sq_out=None):
+                    sinks_untouched=False, mirror=None):
         rp = _np(rowptr[:nrows + 1])
         deg = np.diff(rp)
         sel = [r for r in range(nrows) if not (long_threshold > 0 and deg[r] > long_threshold)
                and not (sinks_untouched and deg[r] == 0)]
         n = self.spmm_partials_len(nrows, 0)
         partials[:n] = 0
-        partials[0] = self._spmm_rows(rowptr, colidx, P, sel, row0, Z_old, X, gamma, Z_new, d, mirror, sq_out)
+        partials[0] = self._spmm_rows(rowptr, colidx, P, sel, row0, Z_old, X, gamma, Z_new, d, mirror)
 
     def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row, row0, Z_old, X, gamma, Z_new, d,
-                         partials, mirror=None, sq_out=None):
+                         partials, mirror=None):
         assert waves_per_row in (4, 16)
         for i, r in enumerate(long_rows.tolist()):
-            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d, mirror, sq_out)
+            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d, mirror)
 
     def spmm_split_slab_len(self, n_segments, d):
         return n_segments * (-(-d // 8) * 8)
 
     def spmm_update_split(self, rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, row0, Z_old, X,
-                          gamma, Z_new, d, slab, partials, mirror=None, sq_out=None):
+                          gamma, Z_new, d, slab, partials, mirror=None):
         assert edges_per_segment % 64 == 0 and seg_row.numel() == int(seg_ptr[-1])
         for i, r in enumerate(split_rows.tolist()):
-            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d, mirror, sq_out)
+            partials[i] = self._spmm_rows(rowptr, colidx, P, [r], row0, Z_old, X, gamma, Z_new, d, mirror)
 
     def spmm_class_slab_len(self, n_slots, d):
         return n_slots * (-(-d // 8) * 8)
 
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
-                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None, sq_out=None):
+                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None):
         """The XCD-affine pass: partial sums per item into the slab, a row's slots added in order.  Also checks the
         layout contract the kernel relies on: whole blocks, every item of block w gathers only rows of XCD class w % 8."""
         e0, ln, sl = _np(item_e0), _np(item_len), _np(item_slot)
@@ -199,8 +197,6 @@ class OracleKernels(KernelBackend):
             own = Z_old[row0 + r, :d]
             new = (X[r, :d].to(acc) + gamma * agg).to(Z_new.dtype)
             Z_new[r, :d] = new
-            if sq_out is not None:
-                sq_out[r] = new.to(acc).pow(2).sum()
             if mp is not None:
                 p_, ms, mbs = mp
                 for s_ in ms[int(p_[r]):int(p_[r + 1])].tolist():

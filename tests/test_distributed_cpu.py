@@ -36,8 +36,6 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         from tests.conftest import load_golden, write_data_root
         from tests.oracle_kernels import OracleKernels
 
-        exchange, _, cols = exchange.partition(":")          # "grid:2" = the 2-D division with 2 column groups
-        division = dict(exchange=exchange, grid_cols=int(cols) if cols else None)
         gold = load_golden(name)
         k = load_golden("g2_karate_csr.npz")
         src, dst = (gold["edge_src"], gold["edge_dst"]) if "edge_src" in gold.files else (k["edge_src"], k["edge_dst"])
@@ -45,22 +43,14 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         root = write_data_root(Path(out_dir) / f"r{rank}", vids, src, dst, gold["X"])
         g = Graph(root)
         eng = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), process_group=dist.group.WORLD, chunks=chunks, seed=3,
-                          **division)
+                          exchange=exchange)
         g._attach_engine(eng)
-        assert eng.world == world and eng.halo == (exchange in ("halo", "grid"))
-        if exchange == "grid":
-            assert (eng.R, eng.C) == (world // int(cols), int(cols)) and eng.columns and eng.row_comm.world == eng.C \
-                and eng.col_comm.world == eng.R and (eng.r, eng.c) == divmod(rank, eng.C)
+        assert eng.world == world and eng.halo == (exchange == "halo")
         full = (world - 1) * -(-len(g) // world) * eng.ld * 4
         if exchange == "allgather":                                        # live / quiet split
             n_quiet = int((~g.csr.live_mask()).sum())
             assert eng.part.quiet_per_rank == -(-n_quiet // world)
-        if exchange == "grid":              # columns: every column exactly once per row group; rows: a halo of row slices
-            widths = [None] * world
-            dist.all_gather_object(widths, (eng.r, eng.d))
-            assert all(sum(w for r_, w in widths if r_ == r) == g.X.shape[1] for r in range(eng.R))
-            assert 0 <= eng.exchange_bytes_per_sweep() <= len(g) * eng.ld * 4
-        elif exchange == "columns":
+        if exchange == "columns":
             from clane_amd.engine import column_slice
             assert eng.columns and eng.exchange_bytes_per_sweep() == 0 and eng.part.n_local >= len(g)
             assert (eng.col0, eng.col1) == column_slice(g.X.shape[1], g.X.dtype, world, rank)
@@ -96,7 +86,7 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         # full Embedder control flow on top: identical decisions on every rank, final Z = reference
         g2 = Graph(root)
         g2._attach_engine(SweepEngine(g2.csr, g2.X, "cpu", OracleKernels(), process_group=dist.group.WORLD,
-                                      chunks=chunks, seed=3, **division))
+                                      chunks=chunks, seed=3, exchange=exchange))
         emb = Embedder(g2, CosineSimilarity(), torch.device("cpu"), gamma=gamma, tolerence=int(gold["tolerence"]),
                        verbose=False)
         emb.iterate()
@@ -110,7 +100,7 @@ def _worker(rank, world, port, chunks, name, out_dir, exchange):
         # ones a single process keeps in history["Z"]
         g3 = Graph(root)
         g3._attach_engine(SweepEngine(g3.csr, g3.X, "cpu", OracleKernels(), process_group=dist.group.WORLD,
-                                      chunks=chunks, seed=3, **division))
+                                      chunks=chunks, seed=3, exchange=exchange))
         got = []
         emb3 = Embedder(g3, CosineSimilarity(), torch.device("cpu"), gamma=gamma, tolerence=3, verbose=False,
                         save_history=True, history_sink=lambda o, s, Z: got.append((o, s, Z)),
@@ -148,17 +138,6 @@ def test_two_rank_gloo_matches_reference(tmp_path, name, chunks, exchange):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
-@pytest.mark.parametrize("exchange,chunks", [("grid:2", 1), ("grid:2", 3)])
-def test_four_rank_gloo_grid(tmp_path, exchange, chunks):
-    """The 2-D division at its smallest: 2 row groups x 2 column groups.  Rows are exchanged between the two ranks
-    that hold the same columns (sub-group of the world), partial dot products summed between the two that hold the
-    same rows (another sub-group), the delta over all four."""
-    world = 4
-    mp.spawn(_worker, args=(world, _free_port(), chunks, "g5_symkarate_d16_g0.76.npz", str(tmp_path), exchange),
-             nprocs=world, join=True)
-    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
-
-
 @pytest.mark.parametrize("exchange", ["halo", "columns"])
 def test_three_rank_gloo(tmp_path, exchange):
     """Odd world size: every (source, destination, chunk) list of the halo exchange is exercised; the column
@@ -177,9 +156,6 @@ def test_three_rank_gloo(tmp_path, exchange):
     ("halo", "g4_karate_d2.npz", 1),
     ("halo", "g5_symkarate_d16_g0.76.npz", 2),
     ("halo", "g11_hubs320_d8_g0.9.npz", 4),                # 320 rows, hubs: 40 rows per rank, 10 per chunk
-    ("grid:2", "g5_symkarate_d16_g0.76.npz", 2),           # 2-D: 4 row groups x 2 column groups (2 packs each)
-    ("grid:4", "g5_symkarate_d16_g0.76.npz", 1),           # 2 row groups x 4 column groups (1 pack each)
-    ("grid:4", "g4_karate_d2.npz", 2),                     # d = 2: one pack -- column groups 1-3 idle, 17 rows per row group
 ])
 def test_eight_rank_gloo_every_division(tmp_path, exchange, name, chunks):
     """The driver's largest case, rehearsed on CPU with the world size it runs: 8 ranks in every division that

@@ -318,8 +318,7 @@ def test_class_pass_random_engines(dev, case):
         mode = "per_edge" if case % 2 else "reference"
         phases, pt = int(rng.choice([1, 2, 4, 8])), int(rng.choice([2, 6, 20]))     # heavy rows phased in time as well
         eng = SweepEngine(csr, X, dev, chunks=1 if case % 4 else 3, hot_rows_first=bool(case % 3), cosine_mode=mode,
-                          class_threshold=ct, class_chunk=chunk, class_phases=phases, phase_threshold=pt,
-                          fused_norms=bool(case % 2))
+                          class_threshold=ct, class_chunk=chunk, class_phases=phases, phase_threshold=pt)
         tag = (f"case {case}: V={V} d={d} {dtype} class_threshold={ct} chunk={chunk} phases={phases}>{pt} "
                f"E={csr.num_edges} {mode}")
         assert sum(0 if c is None else c[0].numel() for c in eng.class_rows) == int((deg > ct).sum()), tag
@@ -339,15 +338,12 @@ def test_class_pass_random_engines(dev, case):
             assert delta == pytest.approx(float((got - Z).abs().sum()), rel=1e-5 if dtype != torch.bfloat16 else 2e-2,
                                           abs=1e-9), tag
             Z = got                                  # follow the GPU's (bf16-rounded) trajectory
-            assert eng.sq_ok[eng.cur] == eng.fused_norms
-            if eng.fused_norms:                      # the K3 kernels left the new rows' norms behind
-                assert_norms_are_k0s(eng, tag)
         del eng
 
 
 def assert_norms_are_k0s(eng, tag=""):
-    """The squared row norms the K3 kernels leave behind (SweepEngine.sq_pp, K0 fused into K3's epilogue) are BIT FOR
-    BIT what row_sqnorm_kernel (K0) computes from the table those kernels wrote -- for every owned row, sinks included."""
+    """The squared row norms the outer-delta pass leaves behind (SweepEngine.sq_pp) are BIT FOR BIT what
+    row_sqnorm_kernel (K0) computes from the same table -- for every owned row, sinks included."""
     want = torch.zeros_like(eng.sq_pp[eng.cur])
     for b in eng.blocks:
         eng.k.row_sqnorm(eng._zrows(eng.Zcur, b), eng.d, want[eng._rows(b)])
@@ -362,41 +358,18 @@ def assert_norms_are_k0s(eng, tag=""):
                                                                                          class_threshold=0)])
 def test_row_norms_are_bitwise_k0(dev, dtype, d, kw):
     """build_P's row norms (similarity.py:37) come from K0 only when nobody has left them behind: the outer-delta pass
-    (l1_between: it reads every row of the new Z anyway) and -- fused_norms=True -- every K3 kernel (one (sub-)wave per
-    row, 4- and 16-wave rows, split hub rows + combine, class chunks + combine) leave norms that are the SAME BITS as
-    K0's on the table they belong to.  Also after set_Z (K0 itself runs once) and after a discarded launch."""
+    (l1_between: it reads every row of the new Z anyway) leaves norms that are the SAME BITS as K0's on the table they
+    belong to, whichever K3 kernels wrote it.  The sweeps leave nothing behind; the third table appears with the first
+    snapshot()."""
     csr = ragged_csr(5000, seed=11, max_deg=30, hubs=(4500, 700, 129, 65, 64, 5000, 300, 33))
     X = synth.gaussian_X(5000, d, seed=3).to(dtype)
-    # ---- the K3 kernels' norms
-    eng = SweepEngine(csr, X, dev, fused_norms=True, **kw)
-    eng.build_P()
-    assert_norms_are_k0s(eng, "after load")
-    for i in range(3):
-        eng.sweep(0.7)
-        assert_norms_are_k0s(eng, f"sweep {i}")
-    eng.snapshot()                          # the pinned table is never a destination: three tables rotate
-    t = eng.sweep_launch(0.7)
-    eng.sweep_wait(t)
-    t2 = eng.sweep_launch(0.7)
-    eng.sweep_wait(t2)
-    eng.discard_launch()
-    assert_norms_are_k0s(eng, "after a discarded launch")
-    P_before = eng.P.clone()
-    eng.build_P()                           # from the fused norms ...
-    P_fused = eng.P.clone()
-    eng.sq_ok[eng.cur] = False
-    eng.build_P()                           # ... and from K0 over the same table: the same P, bit for bit
-    assert torch.equal(P_fused, eng.P) and not torch.equal(P_before, P_fused)
-    assert eng.distance_from_snapshot() > 0
-    eng.set_Z(X.float() * 2)
-    eng.build_P()
-    assert_norms_are_k0s(eng, "after set_Z")
-    # ---- the default: the sweeps leave nothing behind, the outer-delta pass does (what Embedder.iterate() lives on)
     eng = SweepEngine(csr, X, dev, **kw)
-    assert not eng.fused_norms
     eng.build_P()
-    assert eng.sq_ok[eng.cur]
-    eng.snapshot()
+    assert eng.sq_ok[eng.cur] and len(eng.Zbuf) == 2
+    assert_norms_are_k0s(eng, "after load")
+    eng.sweep(0.7)
+    eng.snapshot()                          # the pinned table is never a destination: three tables rotate from here on
+    assert len(eng.Zbuf) == 3 and len(eng.sq_pp) == 3 and torch.equal(eng.Zbuf[2], eng.Zcur)
     for _ in range(2):
         eng.sweep(0.7)
     assert not eng.sq_ok[eng.cur]           # a sweep's destination starts without norms ...
@@ -696,8 +669,6 @@ def test_powerlaw_generator_and_bf16_sweep(dev):
     ("columns", 2, True, 132),        # 33 packs: slices of 32 and 16 lanes per row, ONE class-sorted edge order (r03 fix)
     ("halo", 4, True, 256), ("halo", 3, True, 256), ("halo", 4, False, 256), ("allgather", 4, True, 256),
     ("halo_p2p", 4, True, 256), ("halo_p2p", 3, True, 100),
-    # the 2-D division: 2 x 2, 3 row groups x 2 column groups, 2 x 3 with ragged d (per-edge cosine), 4 x 2 at 8 ranks
-    ("grid:2", 4, True, 256), ("grid:2", 6, True, 64), ("grid:3", 6, True, 100), ("grid:2", 8, True, 128),
     # the divisions of the driver's N = 8 record at that world size, with the real kernels
     ("allgather_all", 8, True, 64), ("allgather", 8, True, 64), ("halo", 8, True, 64), ("columns", 8, True, 64)])
 def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, fused, d):
@@ -707,8 +678,6 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
     import threading
     from .thread_comm import ThreadWorld
     V, E, gamma = 20_000, 300_000, 0.76
-    exchange, _, cols = exchange.partition(":")
-    cols = int(cols) if cols else None
     csr = synth.rmat_csr(V, E, seed=9)
     X = synth.gaussian_X(V, d, seed=10)
     P_or = O.build_P_values(csr.rowptr, csr.colidx, X, mode="per_edge" if d == 100 else "reference")
@@ -723,8 +692,8 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
         try:
             with torch.cuda.device(dev):
                 eng = SweepEngine(csr, X, dev, comm=shared.comm(rank), chunks=3, exchange=exchange, seed=4,
-                                  fused_pack=fused, cosine_mode=("per_edge" if d == 100 else "reference"), grid_cols=cols)
-                assert any(m is not None for m in eng.mirrors) == (fused and exchange in ("halo", "grid"))
+                                  fused_pack=fused, cosine_mode=("per_edge" if d == 100 else "reference"))
+                assert any(m is not None for m in eng.mirrors) == (fused and exchange == "halo")
                 assert eng.p2p == (exchange == "halo_p2p")
                 eng.build_P()
                 P_local = eng.P[:eng.E_loc].cpu()
@@ -742,7 +711,7 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
         t.join(timeout=300)
     assert not errors, errors
     P_all = torch.empty(E)
-    R = world // (cols or 1)                                        # ranks that divide the rows between them
+    R = world                                                       # ranks that divide the rows between them
     for Z, deltas, P_local, origin, nbytes, ld in results:
         assert O.rel_l2(Z, Z_or) < 1e-5
         for a, b in zip(deltas, deltas_or):
@@ -751,7 +720,7 @@ def test_partitioned_engine_with_real_kernels_on_one_gpu(dev, exchange, world, f
         # at most every other rank's rows (each of the 3 chunks may be padded by a row)
         assert (nbytes == 0) if exchange == "columns" else (0 < nbytes <= (R - 1) * (-(-V // R) + 3) * ld * 4)
     assert rel(P_all, P_or) < 1e-5
-    if exchange in ("halo", "halo_p2p", "grid"):                    # the point of the halo: fewer bytes than all rows
+    if exchange in ("halo", "halo_p2p"):                            # the point of the halo: fewer bytes than all rows
         assert results[0][4] < 0.8 * (R - 1) * (V // R) * results[0][5] * 4
 
 

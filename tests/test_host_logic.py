@@ -258,10 +258,9 @@ def test_column_slices_and_auto_exchange():
     assert pick_exchange(256, torch.float32, 8) == "columns" and pick_exchange(256, torch.float32, 16) == "columns"
     assert pick_exchange(128, torch.bfloat16, 4) == "columns" and pick_exchange(128, torch.bfloat16, 8) == "halo"
     assert pick_exchange(2, torch.float32, 2) == "halo"
-    from clane_amd.engine import grid_cols_for, pick_division
-    assert pick_division(128, torch.bfloat16, 8) == ("halo", 1)          # the 2-D division is never picked by "auto" ...
-    assert grid_cols_for(128, torch.bfloat16, 8) == 2 and grid_cols_for(256, torch.float32, 8) == 4   # ... only by name
-    assert grid_cols_for(8, torch.float32, 6) == 2 and grid_cols_for(8, torch.float32, 7) == 7
+    with pytest.raises(ValueError, match="exchange must be"):           # the 2-D division of round 4 is gone
+        SweepEngine(HostCSR(2, np.array([0, 1, 1]), np.array([1], dtype=np.int32)), torch.zeros(2, 4), "cpu",
+                    OracleKernels(), exchange="grid")
     with pytest.raises(ValueError, match="exchange must be"):
         SweepEngine(HostCSR(2, np.array([0, 1, 1]), np.array([1], dtype=np.int32)), torch.zeros(2, 4), "cpu",
                     OracleKernels(), exchange="rows")

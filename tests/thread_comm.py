@@ -70,16 +70,6 @@ class ThreadComm:
         self._finish()
         return _Done()
 
-    def split(self, groups):
-        """clane_amd.comm's split(): rank 0 makes one ThreadWorld per group, everybody picks its own."""
-        made = {tuple(g): ThreadWorld(len(g)) for g in groups} if self.rank == 0 else None
-        worlds = self._exchange(made)[0]
-        self._finish()
-        for g in groups:
-            if self.rank in g:
-                return ThreadComm(worlds[tuple(g)], list(g).index(self.rank))
-        raise ValueError(f"rank {self.rank} is in none of the groups {groups}")
-
     def share_matrices(self, kernels, mine):
         """Same process: the other ranks' tensors themselves."""
         vals = self._exchange([b.tensor for b in mine])

@@ -46,7 +46,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="rmat2m")
 ap.add_argument("--world", type=int, nargs="+", default=[2, 4, 8])
 ap.add_argument("--exchange", default="halo")
-ap.add_argument("--grid-cols", type=int, default=None, help="--exchange grid: column groups")
 ap.add_argument("--chunks", type=int, default=4)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--natural-order", action="store_true")
@@ -69,7 +68,7 @@ for W in args.world:
         del lays
     eng = SweepEngine(csr, X, dev, comm=comm, chunks=args.chunks, exchange=args.exchange,
                       hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs, overlap_chunks=not args.no_overlap,
-                      fused_pack=not args.no_fused_pack, class_threshold=args.class_threshold, grid_cols=args.grid_cols)
+                      fused_pack=not args.no_fused_pack, class_threshold=args.class_threshold)
     eng.build_P()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -94,7 +93,7 @@ for W in args.world:
     n_items = sum(0 if c is None else int((c[3] > 0).sum()) for c in eng.class_rows)
     print(json.dumps({"world": W, "kernels_ms_summed_over_chunks": kt, "class_rows": n_class, "class_items": n_items,
                       "thresholds": [eng.long_threshold, eng.class_threshold],
-                      "items_per_workgroup": [c[6] for c in eng.class_rows if c is not None][:1], "exchange": args.exchange, "grid": [eng.R, eng.C], "rank0_compute_ms_per_sweep": round(ms, 3),
+                      "items_per_workgroup": [c[6] for c in eng.class_rows if c is not None][:1], "exchange": args.exchange, "rank0_compute_ms_per_sweep": round(ms, 3),
                       "rank0_build_P_ms_without_collectives": round(build_ms, 3),
                       "recv_MB_per_sweep": round(eng.exchange_bytes_per_sweep() / 1e6), "table_rows": eng.part.padded_vertices, "d_local": eng.d,
                       "n_local": eng.part.n_local, "E_loc": eng.E_loc, "hot_rows_first": not args.natural_order,
