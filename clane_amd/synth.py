@@ -73,6 +73,9 @@ def powerlaw_csr(num_vertices: int, num_edges: int, alpha: float = 2.1, max_degr
         if keys.numel() >= num_edges:
             break
         target *= 1.01 * num_edges / keys.numel()
+    if keys.numel() < num_edges:        # the docstring's promise: never hand back a smaller graph silently
+        raise RuntimeError(f"powerlaw_csr: only {keys.numel()} distinct edges after 8 rounds of drawing, {num_edges} wanted "
+                           f"(|V|={num_vertices}, max_degree={max_degree}: too dense for this generator)")
     if keys.numel() > num_edges:
         keep = torch.randperm(keys.numel(), generator=gen, device=dev)[:num_edges]
         keys = torch.sort(keys[keep]).values
