@@ -63,8 +63,7 @@ for _s in ("f32", "f64", "bf16"):
         [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_spmm_update_class_{_s}"] = (
         C.c_int,
-        [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p,
-         _p])
+        [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_edge_score_class_{_s}"] = (
         C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p])
     SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
@@ -299,8 +298,7 @@ class KernelBackend(abc.ABC):
                           gamma, Z_new, d, slab, partials, mirror=None): ...
     @abc.abstractmethod
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
-                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None, item_owner=None, item_nslots=None,
-                          arrivals=None): ...
+                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None): ...
     @abc.abstractmethod
     def reduce_partials(self, partials, n, ws, out): ...
     @abc.abstractmethod
@@ -532,33 +530,23 @@ class HipKernels(KernelBackend):
 
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block: int, class_rows, slot_ptr,
                           row0: int, Z_old, X, gamma: float, Z_new, d: int, slab, partials,
-                          mirror: Optional[Mirror] = None, item_owner=None, item_nslots=None, arrivals=None):
+                          mirror: Optional[Mirror] = None):
         """XCD-affine pass over the listed long rows (edges sorted by (XCD class of the column, column), cut into items; item
-        blocks of class b at block index 8 j + b) + fixed-order combine; writes class_rows.numel() partials.
-        With ``arrivals`` (int32 [rows], zero on entry and on exit) + ``item_owner`` / ``item_nslots`` ONE launch does
-        both: the last item of a row to finish adds the row's slots (bit for bit the two-launch result)."""
+        blocks of class b at block index 8 j + b) + fixed-order combine; writes class_rows.numel() partials."""
         zo, ldz = _mat(Z_old, "Z_old")
         xp, ldx = _mat(X, "X")
         zn, ldo = _mat(Z_new, "Z_new")
         n_items = item_e0.numel()
         if n_items % items_per_block or item_len.numel() != n_items or item_slot.numel() != n_items:
             raise ValueError("spmm_update_class: the item arrays must hold whole blocks of items_per_block items")
-        fused = arrivals is not None
-        if fused and (item_owner is None or item_nslots is None or item_owner.numel() != n_items
-                      or item_nslots.numel() != n_items or arrivals.numel() < class_rows.numel()):
-            raise ValueError("spmm_update_class: arrivals needs item_owner / item_nslots (one entry per item) and one "
-                             "counter per listed row")
         self._invoke(self._fn("clane_spmm_update_class", Z_old.dtype), "clane_spmm_update_class",
                      _vec(colidx, torch.int32, "colidx"), _vec(P, acc_dtype(Z_old.dtype), "P"),
                      _vec(item_e0, torch.int64, "item_e0"), _vec(item_len, torch.int32, "item_len"),
-                     _vec(item_slot, torch.int32, "item_slot"),
-                     _vec(item_owner, torch.int32, "item_owner") if fused else None,
-                     _vec(item_nslots, torch.int32, "item_nslots") if fused else None,
-                     n_items // items_per_block, items_per_block,
+                     _vec(item_slot, torch.int32, "item_slot"), n_items // items_per_block, items_per_block,
                      _vec(class_rows, torch.int32, "class_rows"), _vec(slot_ptr, torch.int64, "slot_ptr"),
                      class_rows.numel(), row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
-                     _vec(slab, acc_dtype(Z_old.dtype), "slab"), _vec(arrivals, torch.int32, "arrivals") if fused else None,
-                     _mirror_arg(mirror, Z_new.dtype), _vec(partials, torch.float64, "partials"), self._stream(Z_old))
+                     _vec(slab, acc_dtype(Z_old.dtype), "slab"), _mirror_arg(mirror, Z_new.dtype),
+                     _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 
     def reduce_partials(self, partials, n: int, ws, out):
         self._invoke(self.lib.clane_reduce_partials, "clane_reduce_partials",

@@ -366,12 +366,11 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
 
 template <typename T, typename PT>
 int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0, const int32_t *item_len,
-                      const int32_t *item_slot, const int32_t *item_owner, const int32_t *item_nslots, int64_t n_blocks,
-                      int32_t items_per_block,
-                      const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const T *Z_old,
-                      int64_t ldz, const T *X, int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo,
-                      int32_t d, typename Elem<T>::acc_t *slab, int32_t *arrivals, const clane_mirror_t *mirror,
-                      double *delta_partials, void *stream) {
+                      const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,
+                      const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const T *Z_old, int64_t ldz, const T *X,
+                      int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d,
+                      typename Elem<T>::acc_t *slab, const clane_mirror_t *mirror, double *delta_partials,
+                      void *stream) {
     REQUIRE(mirror_ok(mirror, d), "spmm_update_class: incomplete mirror descriptor");
     REQUIRE(n_blocks >= 0 && n_blocks <= INT32_MAX && n_rows >= 0 && n_rows <= INT32_MAX && row0 >= 0 && d > 0,
             "spmm_update_class: bad shape");
@@ -384,25 +383,15 @@ int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0
             "spmm_update_class: null pointer");
     REQUIRE((const void *)Z_new != (const void *)Z_old, "spmm_update_class: Z_new must not alias Z_old");
     REQUIRE(aligned16(slab), "spmm_update_class: slab must be 16-byte aligned");
-    REQUIRE(arrivals == nullptr || (item_owner != nullptr && item_nslots != nullptr && n_blocks > 0),
-            "spmm_update_class: arrivals (the fused finish) needs item_owner, item_nslots and at least one block of items");
     const Layout L = pick_layout<T>(d, {Z_old, X, Z_new, mirror_alignment_probe(mirror, Z_new)},
                                     {ldz, ldx, ldo, mirror && mirror->row_ptr ? mirror->ld : ldo});
     const int64_t ld_slab = ceil_div(d, 8) * 8;
     const Mirror<T> mir = make_mirror<T>(mirror);
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_LONG_U : 4;
-        if (arrivals != nullptr) {      // the last chunk of a row to finish also finishes the row: one launch
-            spmm_class_chunk_kernel<T, PT, VEC, LPR, U, true><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
-                colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab, item_owner,
-                item_nslots, arrivals,
-                ClassFinish<T>{class_rows, slot_ptr, X, Z_new, delta_partials, row0, ldx, ldo, mir, gamma});
-            return;
-        }
         if (n_blocks > 0)
-            spmm_class_chunk_kernel<T, PT, VEC, LPR, U, false><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
-                colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab, nullptr, nullptr,
-                nullptr, ClassFinish<T>{});
+            spmm_class_chunk_kernel<T, PT, VEC, LPR, U><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
+                colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab);
         spmm_class_combine_kernel<T, VEC><<<unsigned(n_rows), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
             class_rows, slot_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
     });
@@ -478,7 +467,7 @@ const char *clane_build_info(void) {
     return "arch=gfx950;SPMM_U=" CLANE_STR(CLANE_SPMM_U) ";LONG_U=" CLANE_STR(CLANE_LONG_U) ";LONG_WAVES=" CLANE_STR(
         CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM)
         ";TARGET_GRID=" CLANE_STR(CLANE_TARGET_GRID) ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH)
-        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";COMBINE_LOADS=" CLANE_STR(CLANE_COMBINE_LOADS) ";FUSED_LOADS=" CLANE_STR(CLANE_FUSED_LOADS) ";FUSED_MODE=" CLANE_STR(CLANE_FUSED_MODE);
+        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";COMBINE_LOADS=" CLANE_STR(CLANE_COMBINE_LOADS);
 }
 
 int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *stream) {
@@ -646,18 +635,15 @@ CLANE_SPLIT_WRAPPER(bf16, uint16_t, bf16_t, float, float)
 #undef CLANE_SPLIT_WRAPPER
 #define CLANE_CLASS_WRAPPER(SUF, CT, T, PT, GT)                                                                        \
     int clane_spmm_update_class_##SUF(const int32_t *colidx, const PT *P, const int64_t *item_e0,                     \
-                                      const int32_t *item_len, const int32_t *item_slot, const int32_t *item_owner,   \
-                                      const int32_t *item_nslots,                                                     \
-                                      int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,           \
-                                      const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const CT *Z_old,         \
-                                      int64_t ldz, const CT *X, int64_t ldx, GT gamma, CT *Z_new, int64_t ldo,        \
-                                      int32_t d, GT *slab, int32_t *arrivals, const clane_mirror_t *mirror,           \
-                                      double *delta_partials, void *stream) {                                         \
-        return spmm_update_class<T, PT>(colidx, P, item_e0, item_len, item_slot, item_owner, item_nslots, n_blocks,   \
-                                        items_per_block, class_rows, slot_ptr, n_rows, row0,                          \
-                                        reinterpret_cast<const T *>(Z_old), ldz, reinterpret_cast<const T *>(X), ldx, \
-                                        gamma, reinterpret_cast<T *>(Z_new), ldo, d, slab, arrivals, mirror,          \
-                                        delta_partials, stream);                                                      \
+                                      const int32_t *item_len, const int32_t *item_slot, int64_t n_blocks,            \
+                                      int32_t items_per_block, const int32_t *class_rows, const int64_t *slot_ptr,    \
+                                      int64_t n_rows, int64_t row0, const CT *Z_old, int64_t ldz, const CT *X,        \
+                                      int64_t ldx, GT gamma, CT *Z_new, int64_t ldo, int32_t d, GT *slab,             \
+                                      const clane_mirror_t *mirror, double *delta_partials, void *stream) {           \
+        return spmm_update_class<T, PT>(colidx, P, item_e0, item_len, item_slot, n_blocks, items_per_block,           \
+                                        class_rows, slot_ptr, n_rows, row0, reinterpret_cast<const T *>(Z_old), ldz,  \
+                                        reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new),     \
+                                        ldo, d, slab, mirror, delta_partials, stream);                                \
     }
 CLANE_CLASS_WRAPPER(f32, float, float, float, float)
 CLANE_CLASS_WRAPPER(f64, double, double, double, double)

@@ -112,18 +112,6 @@ __device__ __forceinline__ double lane_get_uniform(double v, int src) {
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
-// A wave-uniform 64-bit value (or pointer) the compiler cannot prove uniform -- read back from LDS, loaded through a
-// vector load -- moved to scalar registers, so that what is derived from it (loop bounds, row base addresses) is scalar.
-__device__ __forceinline__ int64_t uniform64(int64_t v) {
-    const int lo = __builtin_amdgcn_readfirstlane(int(v));
-    const int hi = __builtin_amdgcn_readfirstlane(int(v >> 32));
-    return int64_t((uint64_t(uint32_t(hi)) << 32) | uint32_t(lo));
-}
-template <typename P>
-__device__ __forceinline__ P *uniform_ptr(P *p) {
-    return reinterpret_cast<P *>(uniform64(reinterpret_cast<int64_t>(p)));
-}
-
 // Value of lane (lane ^ M), M a compile-time power of two -- WITHOUT the LDS crossbar: DPP moves inside a row of 16
 // lanes (quad_perm for 1 and 2; row_half_mirror + quad reversal for 4; row_ror:8 for 8), gfx950's
 // v_permlane16_swap / v_permlane32_swap across rows (16, 32).  A ds_bpermute (what __shfl_xor compiles to) is an

@@ -681,102 +681,15 @@ namespace clane {
 // in LDS, waves claim them from an LDS counter and request the next chunk's colidx / P before gathering the
 // current one, exactly like spmm_update_kernel does with rows.
 
-// FUSED: the wave whose chunk is the LAST of its row to finish also finishes the row -- the slab never comes back
-// through a second launch.  Per class row an arrival counter (`arrivals`, zero on entry, left zero): a wave stores its
-// partial sum WRITE-THROUGH (sc1: the bytes leave this XCD's L2 at once, no release fence), waits for its own stores
-// (s_waitcnt vmcnt(0)), and lane 0 adds 1 to the row's counter at agent scope; the wave whose add returns
-// n_slots - 1 knows every other slot is in memory, drops its CU's stale L1 lines (ONE agent-scope acquire) and adds the
-// row's slots IN SLOT ORDER with exactly the association of spmm_class_combine_kernel (kCombineWaves contiguous
-// shares, each summed in order, then the shares in order) -- the result does not depend on which chunk came last, and
-// is bit for bit what the two-launch form gives.  Then the usual epilogue.  Nobody ever waits: no spin, no residency
-// requirement.  (MI355X_MICROARCH.md, inter-workgroup visibility: write-through payload + drained counter add +
-// agent acquire is placement-independent.)
-constexpr int kCombineWaves = CLANE_COMBINE_WAVES;
-#ifndef CLANE_FUSED_LOADS
-#define CLANE_FUSED_LOADS 8       // slot loads in flight in the last-arriver combine (the gather keeps U = 8 rows in flight)
-#endif
-
-// Pack of accumulate-type elements stored write-through (sc1) at byte offset `off` of the buffer `rsrc`.
-template <typename A, int VEC>
-__device__ __forceinline__ void store_pack_wt(__amdgpu_buffer_rsrc_t rsrc, int off, const Pack<A, VEC> &v) {
-    constexpr int kBytes = int(sizeof(A)) * VEC;
-    if constexpr (kBytes % 16 == 0) {
-        clane_u32x4 w[kBytes / 16];
-        __builtin_memcpy(w, &v, kBytes);
-#pragma unroll
-        for (int i = 0; i < kBytes / 16; ++i) __builtin_amdgcn_raw_buffer_store_b128(w[i], rsrc, off + 16 * i, 0, 16);
-    } else if constexpr (kBytes == 8) {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 w;
-        __builtin_memcpy(&w, &v, 8);
-        __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, off, 0, 16);
-    } else {
-        static_assert(kBytes == 4, "store_pack_wt: 4-, 8- or 16n-byte packs");
-        uint32_t w;
-        __builtin_memcpy(&w, &v, 4);
-        __builtin_amdgcn_raw_buffer_store_b32(w, rsrc, off, 0, 16);
-    }
-}
-
-// What the wave that finishes a row needs and nobody else does.  Passed by value, parked in LDS by thread 0 and read
-// back by the finishing wave: as plain kernel arguments these 13 values sit in SGPRs for the whole kernel (the
-// compiler hoists the argument loads), 106 SGPRs + SGPR spills into VGPRs cost the gather loop two waves per SIMD.
-template <typename T>
-struct ClassFinish {
-    const int32_t *class_rows;
-    const int64_t *slot_ptr;
-    const T *X;
-    T *Znew;
-    double *partials;
-    int64_t row0, ldx, ldo;
-    Mirror<T> mirror;
-    typename Elem<T>::acc_t gamma;
-};
-
-// ... and loaded past the L1 (sc1: served by the L2 / the fabric), `off` + `soff` bytes into `rsrc`.
-template <typename A, int VEC>
-__device__ __forceinline__ Pack<A, VEC> load_pack_wt(__amdgpu_buffer_rsrc_t rsrc, int off, int soff) {
-    constexpr int kBytes = int(sizeof(A)) * VEC;
-    Pack<A, VEC> v;
-    if constexpr (kBytes % 16 == 0) {
-        clane_u32x4 w[kBytes / 16];
-#pragma unroll
-        for (int i = 0; i < kBytes / 16; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16 * i, soff, 16);
-        __builtin_memcpy(&v, w, kBytes);
-    } else if constexpr (kBytes == 8) {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, soff, 16);
-        __builtin_memcpy(&v, &w, 8);
-    } else {
-        static_assert(kBytes == 4, "load_pack_wt: 4-, 8- or 16n-byte packs");
-        const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, soff, 16);
-        __builtin_memcpy(&v, &w, 4);
-    }
-    return v;
-}
-#ifndef CLANE_FUSED_MODE
-#define CLANE_FUSED_MODE 1        // 0: agent-scope acquire fence, then plain slab loads; 1: no fence, every slab load sc1
-#endif
-
-// The gather loop of the 1-KiB-row instance runs at 7 waves per SIMD (68 registers); the finishing code in the middle
-// of that loop must not cost it a wave (the register allocator otherwise takes 76).
-template <typename T, typename PT, int VEC, int LPR, int U, bool FUSED>
-__global__ __launch_bounds__(kBlock, (FUSED && LPR == kWave && sizeof(T) * VEC == 16 && sizeof(T) == 4) ? 7 : 1)
-void spmm_class_chunk_kernel(
+template <typename T, typename PT, int VEC, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void spmm_class_chunk_kernel(
     const int32_t *__restrict__ colidx, const PT *__restrict__ P, const int64_t *__restrict__ item_e0,
     const int32_t *__restrict__ item_len, const int32_t *__restrict__ item_slot, int items_per_block,
-    const T *__restrict__ Zold, int64_t ldz, int d, typename Elem<T>::acc_t *slab, int64_t ld_slab,
-    // FUSED only (else unused): the row an item belongs to (index into class_rows) and how many slots that row has,
-    // the rows' arrival counters, the epilogue's operands
-    const int32_t *__restrict__ item_owner, const int32_t *__restrict__ item_nslots, int32_t *arrivals,
-    ClassFinish<T> fin) {
+    const T *__restrict__ Zold, int64_t ldz, int d, typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab) {
     using A = typename Elem<T>::acc_t;
     __shared__ int64_t s_e0[kMaxItemsPerBlock];
     __shared__ int s_len[kMaxItemsPerBlock];
     __shared__ int s_slot[kMaxItemsPerBlock];
-    __shared__ int s_owner[FUSED ? kMaxItemsPerBlock : 1];
-    __shared__ int s_nslots[FUSED ? kMaxItemsPerBlock : 1];
-    __shared__ ClassFinish<T> s_fin;
     __shared__ int s_next;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -787,111 +700,14 @@ void spmm_class_chunk_kernel(
         s_e0[i] = item_e0[base + i];
         s_len[i] = item_len[base + i];
         s_slot[i] = item_slot[base + i];
-        if constexpr (FUSED) {
-            s_owner[i] = item_owner[base + i];
-            s_nslots[i] = item_nslots[base + i];
-        }
     }
-    if (threadIdx.x == 0) {
-        s_next = kWavesPerBlock;
-        if constexpr (FUSED) s_fin = fin;
-    }
+    if (threadIdx.x == 0) s_next = kWavesPerBlock;
     __syncthreads();
 
     auto claim = [&]() -> int {
         int v = 0;
         if (lane == 0) v = atomicAdd(&s_next, 1);
         return __builtin_amdgcn_readfirstlane(v);
-    };
-    // FUSED: the row `i` (n_slots slots, all stored and counted) is finished by this wave
-    [[maybe_unused]] auto finish_row = [&](int i, int n_slots) {
-        if (lane == 0) __hip_atomic_store(arrivals + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-#if CLANE_FUSED_MODE == 0
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // no stale line of an earlier sweep's slab in this CU's L1
-#else
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the ticket)
-#endif
-        const int row_bytes = int(ld_slab * sizeof(A));
-        const ClassFinish<T> &f = s_fin;                     // read where needed, moved to scalar registers
-        const int64_t r = f.class_rows[i];                   // (row addresses stay in vector registers: they are free here)
-        A *const row_slab = slab + uniform64(uniform_ptr(f.slot_ptr)[i]) * ld_slab;     // the row's first slot
-        const T *x_row = f.X + r * f.ldx;
-        const T *zo_row = Zold + (f.row0 + r) * ldz;
-        T *zn_row = f.Znew + r * f.ldo;
-        const int share = (n_slots + kCombineWaves - 1) / kCombineWaves;
-        A rsum = A(0);
-        for (int t0 = 0; t0 < d; t0 += kWave * VEC) {
-            const int c0 = t0 + lane * VEC;
-            const bool ok = c0 < d;
-            A tot[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) tot[k] = A(0);
-            Pack<T, VEC> o{};
-            if (ok) {
-#pragma unroll
-                for (int w = 0; w < kCombineWaves; ++w) {    // spmm_class_combine_kernel's association
-                    const int a = w * share < n_slots ? w * share : n_slots;     // slots relative to the row's first
-                    const int b = a + share < n_slots ? a + share : n_slots;
-                    A acc[VEC];
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] = A(0);
-                    int s = a;
-                    for (; s + CLANE_FUSED_LOADS <= b; s += CLANE_FUSED_LOADS) {
-                        Pack<A, VEC> part[CLANE_FUSED_LOADS];
-                        [[maybe_unused]] const auto rs = __builtin_amdgcn_make_buffer_rsrc(
-                            row_slab + int64_t(s) * ld_slab, 0, CLANE_FUSED_LOADS * row_bytes, 0x00020000);
-#pragma unroll
-                        for (int u = 0; u < CLANE_FUSED_LOADS; ++u) {
-#if CLANE_FUSED_MODE == 0
-                            part[u] = load_pack<A, VEC>(row_slab + int64_t(s + u) * ld_slab + c0);
-#else
-                            part[u] = load_pack_wt<A, VEC>(rs, c0 * int(sizeof(A)), u * row_bytes);
-#endif
-                        }
-#pragma unroll
-                        for (int u = 0; u < CLANE_FUSED_LOADS; ++u) {
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) acc[k] += part[u].v[k];
-                        }
-                    }
-                    for (; s < b; ++s) {
-#if CLANE_FUSED_MODE == 0
-                        const Pack<A, VEC> part = load_pack<A, VEC>(row_slab + int64_t(s) * ld_slab + c0);
-#else
-                        const Pack<A, VEC> part = load_pack_wt<A, VEC>(
-                            __builtin_amdgcn_make_buffer_rsrc(row_slab + int64_t(s) * ld_slab, 0, row_bytes, 0x00020000),
-                            c0 * int(sizeof(A)), 0);
-#endif
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] += part.v[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) tot[k] = w == 0 ? acc[k] : tot[k] + acc[k];
-                }
-                const Pack<T, VEC> x = load_pack_stream<T, VEC>(x_row + c0);
-                const Pack<T, VEC> zo = load_pack_stream<T, VEC>(zo_row + c0);
-                rsum += finish_pack<T, VEC>(x, zo, tot, f.gamma, true, zn_row + c0, o);
-            }
-            mirror_store<T, VEC, kWave>(f.mirror, r, c0, o, ok, lane, 0);
-        }
-        rsum = group_sum<kWave>(rsum);
-        if (lane == 0) f.partials[i] = double(rsum);
-    };
-    // FUSED, two items behind: an item's slot is stored (write-through); ONE ITEM LATER -- its stores have had a whole
-    // gather to reach memory -- the wave waits for everything it has in flight and takes the item's ticket (agent-scope
-    // add on the row's counter); ANOTHER item later the ticket is back and looked at.  Neither the write-through
-    // latency nor the atomic's round trip is ever waited for on its own (waiting for both after every chunk cost the
-    // pass 30 %: profiles/r05_class_fused_ab.md).
-    [[maybe_unused]] int pend_i = -1, pend_n = 0;            // stored, ticket not yet taken
-    [[maybe_unused]] int tick_i = -1, tick_n = 0, ticket = 0;     // ticket taken, not yet looked at
-    [[maybe_unused]] auto settle = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the pending slot is in memory, the pending ticket is back
-        if (tick_i >= 0 && __builtin_amdgcn_readfirstlane(ticket) == tick_n - 1) finish_row(tick_i, tick_n);
-        tick_i = pend_i;
-        tick_n = pend_n;
-        pend_i = -1;
-        if (tick_i >= 0 && lane == 0)
-            ticket = __hip_atomic_fetch_add(arrivals + tick_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     int cur = wave;
     int64_t e0 = 0, e1 = 0;
@@ -901,55 +717,30 @@ void spmm_class_chunk_kernel(
         e1 = e0 + s_len[cur];
         ch = load_chunk<A, PT>(colidx, P, e0, e1);
     }
-    // FUSED: two more turns of the loop after the wave's last item (`drain`), so that settle() has ONE call site
-    [[maybe_unused]] int drain = 0;
-    for (;;) {
-        const bool have = cur < items_per_block;
-        if (!have && (!FUSED || drain == 2)) break;
-        int nxt = cur;
+    while (cur < items_per_block) {
+        const int nxt = claim();
         int64_t n0 = 0, n1 = 0;
         EdgeChunk<A> chn{0, A(0)};
-        if (have) {
-            nxt = claim();
-            if (nxt < items_per_block) {
-                n0 = s_e0[nxt];
-                n1 = n0 + s_len[nxt];
-                chn = load_chunk<A, PT>(colidx, P, n0, n1);
-            }
+        if (nxt < items_per_block) {
+            n0 = s_e0[nxt];
+            n1 = n0 + s_len[nxt];
+            chn = load_chunk<A, PT>(colidx, P, n0, n1);
         }
-        const bool work = have && e1 > e0;
-        if (work || !have) {
-            const int64_t slot = work ? __builtin_amdgcn_readfirstlane(s_slot[cur]) : 0;
-            A *out = slab + slot * ld_slab;
-            [[maybe_unused]] __amdgpu_buffer_rsrc_t out_wt;
-            if constexpr (FUSED) out_wt = __builtin_amdgcn_make_buffer_rsrc(out, 0, int(ld_slab * sizeof(A)), 0x00020000);
-            for (int t0 = 0; t0 < (work ? d : 1); t0 += LPR * VEC) {
+        if (e1 > e0) {
+            A *out = slab + int64_t(s_slot[cur]) * ld_slab;
+            for (int t0 = 0; t0 < d; t0 += LPR * VEC) {
                 const int c0 = t0 + sl * VEC;
                 const bool col_ok = c0 < d;
                 A acc[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = A(0);
-                if (work) {
-                    gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
-                    fold_subwaves<LPR>(acc);
-                }
-                if constexpr (FUSED) {
-                    if (t0 == 0) settle();           // the items before this one, before this one's first store
-                }
-                if (work && col_ok && sub == 0) {
+                gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
+                fold_subwaves<LPR>(acc);
+                if (col_ok && sub == 0) {
                     Pack<A, VEC> o;
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];
-                    if constexpr (FUSED) store_pack_wt<A, VEC>(out_wt, c0 * int(sizeof(A)), o);
-                    else store_pack<A, VEC>(out + c0, o);
-                }
-            }
-            if constexpr (FUSED) {
-                if (work) {
-                    pend_i = __builtin_amdgcn_readfirstlane(s_owner[cur]);
-                    pend_n = __builtin_amdgcn_readfirstlane(s_nslots[cur]);
-                } else {
-                    ++drain;
+                    store_pack<A, VEC>(out + c0, o);
                 }
             }
         }
@@ -965,6 +756,7 @@ void spmm_class_chunk_kernel(
 // delta, store.  The association is fixed by (slot count, kCombineWaves) alone -- reproducible, no atomics -- and a
 // heavy row's chain of dependent loads is a kCombineWaves-th of what one wave would walk (config 3's heaviest row:
 // 280 slots; the 2.4e9-edge test's hubs: 4 688).
+constexpr int kCombineWaves = CLANE_COMBINE_WAVES;
 #ifndef CLANE_COMBINE_LOADS
 #define CLANE_COMBINE_LOADS 16    // slot loads in flight per wave of the combine (rows of fewer slots take the plain loop)
 #endif

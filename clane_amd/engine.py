@@ -182,7 +182,7 @@ class SweepEngine:
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
                  phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None,
-                 table_alloc: str = "torch", class_fused: bool = True):
+                 table_alloc: str = "torch"):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
@@ -210,9 +210,6 @@ class SweepEngine:
         if table_alloc not in ("torch", "contiguous"):
             raise ValueError("table_alloc must be 'torch' or 'contiguous'")
         self.table_alloc, self._own_tables, self.table_alloc_note = table_alloc, [], None
-        # class rows finished by their last-arriving chunk inside the chunk launch (True), or by a second launch over the
-        # slab (False): bit-identical results (csrc/spmm_update.h, FUSED)
-        self.class_fused = bool(class_fused)
         X = self._choose_division(csr, X, process_group, comm, exchange)
         self._choose_class_pass(csr, class_threshold, class_chunk, class_k1, class_phases, phase_threshold)
         self._build_layout(csr, chunks, shuffle, seed, hot_rows_first)
@@ -388,8 +385,7 @@ class SweepEngine:
         self.mid_rows: List[Optional[torch.Tensor]] = []      # long_threshold < deg <= hub_threshold: 4 waves/row
         self.hub_rows: List[Optional[torch.Tensor]] = []      # hub_threshold < deg <= SPLIT_EDGES: 16 waves/row
         self.split_rows: List[Optional[tuple]] = []           # deg > SPLIT_EDGES: (rows, seg_ptr, seg_row) on device
-        self.class_rows: List[Optional[tuple]] = []           # deg > class_threshold: (rows, slot_ptr, e0, len, slot, row, ipb)
-        self.class_finish: List[Optional[tuple]] = []         # ... and for the one-launch form: (owner, nslots, arrivals)
+        self.class_rows: List[Optional[tuple]] = []           # deg > class_threshold: (rows, slot_ptr, e0, len, slot, row)
         self.class_slots: List[int] = []                      # slot_ptr[-1] of each block's class rows, known on the host
         self.k1_long_rows: List[Optional[torch.Tensor]] = []  # K1's workgroup-per-row list: above k1_threshold, not class
         self.split_edges = SPLIT_EDGES if split_hubs else 0
@@ -423,13 +419,10 @@ class SweepEngine:
                                         torch.from_numpy(items["e0"]).to(dev), torch.from_numpy(items["len"]).to(dev),
                                         torch.from_numpy(items["slot"]).to(dev), torch.from_numpy(items["row"]).to(dev),
                                         ipb))
-                self.class_finish.append((torch.from_numpy(items["owner"]).to(dev), torch.from_numpy(items["nslots"]).to(dev),
-                                          torch.zeros(rows_c.size, dtype=torch.int32, device=dev)))
                 self.class_slots.append(int(items["slot_ptr"][-1]))
                 max_slots = max(max_slots, self.class_slots[-1])
             else:
                 self.class_rows.append(None)
-                self.class_finish.append(None)
                 self.class_slots.append(0)
             k1_long = (db > self.k1_threshold) & ~(is_class if self.class_k1 else np.zeros_like(is_class)) \
                 if self.k1_threshold > 0 else np.zeros_like(is_class)
@@ -870,11 +863,9 @@ class SweepEngine:
                     continue
                 if self.class_rows[i] is not None:
                     rows_c, slot_ptr, it_e0, it_len, it_slot, _, ipb = self.class_rows[i]
-                    owner, nslots, arrivals = self.class_finish[i] if self.class_fused else (None, None, None)
                     steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
                                                      ipb, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
-                                                     Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:],
-                                                     mirror=mir, item_owner=owner, item_nslots=nslots, arrivals=arrivals)))
+                                                     Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:], mirror=mir)))
                 if self.split_rows[i] is not None:
                     rows_s, seg_ptr, seg_row = self.split_rows[i]
                     steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
@@ -1054,8 +1045,7 @@ class SweepEngine:
         narrow = self.d > 0 and lanes_per_row(self.d, self.dtype) < 64
         return {"main": "spmm_update_subrow_kernel" if narrow else "spmm_update_kernel",
                 "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>",
-                "split": ("spmm_class_chunk_kernel" if self.class_fused else "spmm_class_chunk_kernel+combine")
-                if self.class_threshold > 0
+                "split": "spmm_class_chunk_kernel+combine" if self.class_threshold > 0
                 else "spmm_split_segment_kernel+combine"}
 
     def estimated_sweep_seconds(self) -> float:
@@ -1082,7 +1072,6 @@ class SweepEngine:
                 "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
                 "class_affinity": self.class_affinity, "mega_segment_edges": self.mega_segment_edges,
                 "class_items_per_block": [c[6] for c in self.class_rows if c is not None][:1],
-                "class_fused": self.class_fused,
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange,
                 }
 

@@ -95,9 +95,7 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     edges sorted by xcd_subclass -- and their blocks come first, phase by phase (each phase a whole number of
     8-block rounds, so block index % 8 stays the class), then the blocks of the other rows.  Inside a class the items go row
     by row, except those of mega rows (`mega_segment_edges`), which come first ordered by their first column.  Returns int64 e0, int32 len, int32 slot, int32 row (flat, whole blocks; row = `row_ids` of the
-    item's row, default `rows` itself), int32 owner (the item's row as an index into `rows`) and int32 nslots (that
-    row's slot count) -- what the kernel that lets a row's last-arriving item finish the row needs --, int64 slot_ptr
-    [rows + 1] and the items_per_block used (None on entry: chosen
+    item's row, default `rows` itself), int64 slot_ptr [rows + 1] and the items_per_block used (None on entry: chosen
     by `items_per_block_for` from the item count, once the O(E) counting pass has it -- the layout itself is cheap)."""
     n = rows.size
     NS = XCD_CLASSES * max(1, phases)                       # sub-classes per row (phase-major)
@@ -150,8 +148,6 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
     item_group = np.where(heavy[seg_of // NS], (seg_of % NS) // XCD_CLASSES, max(1, phases))
     ids = (rows if row_ids is None else row_ids).astype(np.int32)
     item_row = ids[seg_of // NS]
-    item_owner = (seg_of // NS).astype(np.int32)
-    item_nslots = np.diff(slot_ptr).astype(np.int32)[item_owner]
     pieces = []
     for g in range(max(1, phases) + 1):
         in_group = item_group == g
@@ -177,22 +173,18 @@ def class_items(rowptr: np.ndarray, colidx: np.ndarray, rows: np.ndarray, chunk:
         g_len = np.zeros(flat, dtype=np.int32)
         g_slot = np.full(flat, -1, dtype=np.int32)
         g_row = np.zeros(flat, dtype=np.int32)
-        g_owner = np.zeros(flat, dtype=np.int32)
-        g_nslots = np.zeros(flat, dtype=np.int32)
         for c, pc in enumerate(per_class):
             t = np.arange(len(pc))
             where = (t // items_per_block) * (XCD_CLASSES * items_per_block) + c * items_per_block + t % items_per_block
             g_e0[where], g_len[where], g_slot[where], g_row[where] = e0[pc], ln[pc], pc, item_row[pc]
-            g_owner[where], g_nslots[where] = item_owner[pc], item_nslots[pc]
-        pieces.append((g_e0, g_len, g_slot, g_row, g_owner, g_nslots))
+        pieces.append((g_e0, g_len, g_slot, g_row))
     if not pieces:                                          # no edges at all: one round of empty blocks
         flat = XCD_CLASSES * items_per_block
         pieces.append((np.zeros(flat, dtype=np.int64), np.zeros(flat, dtype=np.int32),
-                       np.full(flat, -1, dtype=np.int32), np.zeros(flat, dtype=np.int32),
-                       np.zeros(flat, dtype=np.int32), np.zeros(flat, dtype=np.int32)))
-    out_e0, out_len, out_slot, out_row, out_owner, out_nslots = (np.concatenate([p[i] for p in pieces]) for i in range(6))
-    return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "owner": out_owner, "nslots": out_nslots,
-            "slot_ptr": slot_ptr, "items_per_block": int(items_per_block)}
+                       np.full(flat, -1, dtype=np.int32), np.zeros(flat, dtype=np.int32)))
+    out_e0, out_len, out_slot, out_row = (np.concatenate([p[i] for p in pieces]) for i in range(4))
+    return {"e0": out_e0, "len": out_len, "slot": out_slot, "row": out_row, "slot_ptr": slot_ptr,
+            "items_per_block": int(items_per_block)}
 
 
 def items_per_block_for(n_items: int) -> int:

@@ -42,8 +42,7 @@ extern "C" {
                              * 3: clane_l1_distance_* takes `sq_a` (the rows' squared norms from the outer-delta pass: free),
                              *    clane_device_alloc_contiguous; every clane_spmm_update* took `sq_out` (the same norms out of K3)
                              * 4: `sq_out` is gone again: it cost every sweep 1.1-1.4 % to save one 0.34 ms pass per build_P, and a
-                             *    propagate runs >= 11 sweeps per build_P (profiles/r04_fused_norms_ab.jsonl);
-                             *    clane_spmm_update_class_* takes item_owner + arrivals (a row finished by its last-arriving item) */
+                             *    propagate runs >= 11 sweeps per build_P (profiles/r04_fused_norms_ab.jsonl) */
 
 #define CLANE_OK 0
 #define CLANE_ERR_INVALID_ARGUMENT (-1)
@@ -290,34 +289,26 @@ int clane_edge_score_class_bf16(const int64_t *rowptr, const int32_t *colidx, co
  *                             working set at any moment is a fraction of its class (clane_amd/xcd.py).
  *                             class_rows[n_rows] local row ids; slot_ptr[n_rows+1]: the slots of
  *                             row i are [slot_ptr[i], slot_ptr[i+1]) and are added in that order (reproducible),
- *                             then the usual epilogue.  Writes n_rows doubles to delta_partials.
- *                             arrivals == NULL: two launches, the items' partial sums and then one workgroup per row
- *                             that adds its slots.  arrivals = n_rows int32 counters, ZERO on entry (every call leaves
- *                             them zero again), with item_owner[k] = index into class_rows of item k's row and
- *                             item_nslots[k] = that row's slot count (both laid out like the other item arrays): ONE
- *                             launch -- the wave whose item is the last of its row to finish adds the row's slots
- *                             (same order, same association: bit for bit the two-launch result, whichever item comes
- *                             last) and runs the epilogue; partial sums are stored write-through and handed over with
- *                             an agent-scope counter add + acquire (no spinning: nothing ever waits). */
+ *                             then the usual epilogue.  Writes n_rows doubles to delta_partials. */
 int64_t clane_spmm_class_slab_len(int64_t n_slots, int32_t d);
 int clane_spmm_update_class_f32(const int32_t *colidx, const float *P, const int64_t *item_e0, const int32_t *item_len,
-                                const int32_t *item_slot, const int32_t *item_owner, const int32_t *item_nslots, int64_t n_blocks,
-                                int32_t items_per_block, const int32_t *class_rows, const int64_t *slot_ptr,
-                                int64_t n_rows, int64_t row0, const float *Z_old, int64_t ldz, const float *X, int64_t ldx,
-                                float gamma, float *Z_new, int64_t ldo, int32_t d, float *slab, int32_t *arrivals,
-                                const clane_mirror_t *mirror, double *delta_partials, void *stream);
+                                const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
+                                const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
+                                const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
+                                int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
+                                double *delta_partials, void *stream);
 int clane_spmm_update_class_f64(const int32_t *colidx, const double *P, const int64_t *item_e0, const int32_t *item_len,
-                                const int32_t *item_slot, const int32_t *item_owner, const int32_t *item_nslots, int64_t n_blocks,
-                                int32_t items_per_block, const int32_t *class_rows, const int64_t *slot_ptr,
-                                int64_t n_rows, int64_t row0, const double *Z_old, int64_t ldz, const double *X, int64_t ldx,
-                                double gamma, double *Z_new, int64_t ldo, int32_t d, double *slab, int32_t *arrivals,
-                                const clane_mirror_t *mirror, double *delta_partials, void *stream);
+                                const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
+                                const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
+                                const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma,
+                                double *Z_new, int64_t ldo, int32_t d, double *slab, const clane_mirror_t *mirror,
+                                double *delta_partials, void *stream);
 int clane_spmm_update_class_bf16(const int32_t *colidx, const float *P, const int64_t *item_e0, const int32_t *item_len,
-                                const int32_t *item_slot, const int32_t *item_owner, const int32_t *item_nslots, int64_t n_blocks,
-                                int32_t items_per_block, const int32_t *class_rows, const int64_t *slot_ptr,
-                                int64_t n_rows, int64_t row0, const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx,
-                                float gamma, uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, int32_t *arrivals,
-                                const clane_mirror_t *mirror, double *delta_partials, void *stream);
+                                 const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
+                                 const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
+                                 const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
+                                 uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
+                                 double *delta_partials, void *stream);
 
 /* out[0] = sum of partials[0..n) in a fixed order (bitwise reproducible).  Finishes embedder.py:94 / :60.
  * ws: clane_reduce_ws_len() doubles. */

@@ -172,19 +172,11 @@ class OracleKernels(KernelBackend):
         return n_slots * (-(-d // 8) * 8)
 
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
-                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None, item_owner=None, item_nslots=None,
-                          arrivals=None):
+                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None):
         """The XCD-affine pass: partial sums per item into the slab, a row's slots added in order.  Also checks the
         layout contract the kernel relies on: whole blocks, every item of block w gathers only rows of XCD class w % 8."""
         e0, ln, sl = _np(item_e0), _np(item_len), _np(item_slot)
         assert 4 <= items_per_block <= 64 and e0.size % items_per_block == 0 and e0.size // items_per_block % 8 == 0
-        if arrivals is not None:            # the one-launch form: every item names its row and that row's slot count
-            own, ns, sp = _np(item_owner), _np(item_nslots), _np(slot_ptr)
-            live = ln > 0
-            assert not arrivals.any() and arrivals.numel() >= class_rows.numel()
-            assert ((sp[own[live]] <= sl[live]) & (sl[live] < sp[own[live] + 1])).all(), "item slot outside its row's range"
-            assert (ns[live] == (sp[own[live] + 1] - sp[own[live]])).all(), "item_nslots is not the row's slot count"
-            assert (np.bincount(own[live], minlength=class_rows.numel()) == np.diff(sp)).all(), "a row's arrivals"
         acc = P.dtype
         ld = -(-d // 8) * 8
         view = slab[:self.spmm_class_slab_len(int(slot_ptr[-1]), d)].view(-1, ld)

@@ -341,39 +341,6 @@ def test_class_pass_random_engines(dev, case):
         del eng
 
 
-@pytest.mark.parametrize("workload", ["rmat200k", "rmat200k256", "powerlaw1m_bf16", "hubs_f64"])
-def test_class_rows_finished_in_one_launch_are_bit_identical(dev, workload):
-    """SweepEngine(class_fused=True) -- the default: the last chunk of a class row to finish adds the row's slots and
-    runs the epilogue inside the chunk launch (agent-scope arrival counters, write-through slab stores) -- against
-    class_fused=False (a second launch adds the slots): Z, the deltas and the row-by-row partials are the SAME BITS
-    sweep after sweep, on a chip that is busy (10^5 chunks in flight, rows of 2 to hundreds of slots whose chunks run
-    on different XCDs), with both engines' launches interleaved so that each reads lines the other has left in the
-    caches.  Embeddings follow embedder.py:84-94 either way (checked against the oracle elsewhere)."""
-    if workload == "powerlaw1m_bf16":
-        csr, X = synth.powerlaw_csr(1_000_000, 20_000_000, seed=5, device=str(dev)), synth.gaussian_X(1_000_000, 128, seed=6).bfloat16()
-    elif workload == "hubs_f64":
-        csr = ragged_csr(30_000, seed=5, max_deg=90, hubs=(30_000, 9_000, 4_097, 513, 300, 129, 65))
-        X = synth.gaussian_X(30_000, 64, seed=6).double()
-    else:
-        csr = synth.rmat_csr(200_000, 4_000_000, seed=1, device=str(dev))
-        X = synth.gaussian_X(200_000, 256 if workload.endswith("256") else 128, seed=2)
-    kw = dict(class_threshold=16, class_chunk=64) if workload == "hubs_f64" else {}
-    one, two = SweepEngine(csr, X, dev, class_fused=True, **kw), SweepEngine(csr, X, dev, class_fused=False, **kw)
-    n_class = sum(0 if c is None else c[0].numel() for c in one.class_rows)
-    assert n_class > 1000 or workload == "hubs_f64"
-    assert one.kernel_names()["split"] == "spmm_class_chunk_kernel" and two.kernel_names()["split"].endswith("+combine")
-    for eng in (one, two):
-        eng.build_P()
-    assert torch.equal(one.P, two.P)
-    for sweep in range(12):
-        d1, d2 = one.sweep(0.76), two.sweep(0.76)
-        assert d1 == d2, (sweep, d1, d2)
-        assert torch.equal(one.partials, two.partials), sweep
-        assert torch.equal(one.Zcur, two.Zcur), (sweep, int((one.Zcur != two.Zcur).sum()))
-        assert all(int(f[2].abs().sum()) == 0 for f in one.class_finish if f is not None)     # counters back at zero
-    del one, two
-
-
 def assert_norms_are_k0s(eng, tag=""):
     """The squared row norms the outer-delta pass leaves behind (SweepEngine.sq_pp) are BIT FOR BIT what
     row_sqnorm_kernel (K0) computes from the same table -- for every owned row, sinks included."""
@@ -911,19 +878,6 @@ def test_spmm_class_affine_rows(dev, k, dtype, d, pad, chunk):
     p2 = torch.zeros_like(pc)
     k.spmm_update_class(*args, Z2, d, slab, p2)
     assert torch.equal(Z2, Zc) and torch.equal(p2, pc)               # fixed slot order: bitwise reproducible
-    # the ONE-launch form: a row is finished by whichever of its items arrives last -- the same bits, launch after launch,
-    # the arrival counters back at zero every time; a poisoned slab shows any slot read before it was written
-    arrivals = torch.zeros(rows.size, dtype=torch.int32, device=dev)
-    fused = dict(item_owner=t(items["owner"]), item_nslots=t(items["nslots"]), arrivals=arrivals)
-    for _ in range(3):
-        slab.fill_(float("nan"))
-        Z3, p3 = torch.zeros_like(Zo), torch.zeros_like(pc)
-        buf.fill_(7.0)
-        k.spmm_update_class(*args, Z3, d, slab, p3, mirror=mir, **fused)
-        assert torch.equal(Z3, Zc) and torch.equal(p3, pc) and torch.equal(buf[:, :d], Zc[src, :d])
-        assert int(arrivals.abs().sum()) == 0
-    with pytest.raises(ValueError, match="item_owner"):
-        k.spmm_update_class(*args, Z2, d, slab, p2, arrivals=arrivals)
     with pytest.raises(_hip.ClaneHipError, match="items_per_block"):
         k.spmm_update_class(ci_d, P_d, t(items["e0"]), t(items["len"]), t(items["slot"]), 2, rows_d,
                             t(items["slot_ptr"]), 0, Zo, Xd, gamma, Z2, d, slab, p2)
