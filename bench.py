@@ -94,128 +94,6 @@ def launch_ranks(n: int) -> int:
     return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
 
 
-def oracle_first_sweep(csr, X, P_host, gamma):
-    """The C oracle's first sweep from Z = X (oracle/clane_oracle.c); P from the oracle's own build_P
-    (graph.py:118-128) unless one is given.  Returns (Z1, seconds of the sweep, threads, the P used, X as fp32)."""
-    from oracle import clane_oracle_c as OC
-    Xf = X.float() if X.dtype != torch.float32 else X    # the oracle computes in fp32 on the (bf16-)rounded inputs
-    if P_host is None:
-        P_host, _ = OC.build_P(csr.rowptr, csr.colidx, Xf)
-    out = torch.empty_like(Xf)
-    t0 = time.perf_counter()
-    Z, _ = OC.sweep(csr.rowptr, csr.colidx, P_host.float(), Xf, Xf, gamma, out=out)
-    return Z, time.perf_counter() - t0, OC.threads(), P_host.float(), Xf
-
-
-def cpu_baseline(csr, Xf, P_host, gamma, Z1_oracle, first, budget_s=15.0):
-    """The oracle's sweep timed on this box's host cores: the plain-C restatement (oracle/clane_oracle.c,
-    OpenMP over rows, same CSR / fp32) -- kind "port"."""
-    from oracle import clane_oracle_c as OC
-    threads = OC.threads()
-    n = int(max(1, min(20, budget_s // max(first, 1e-3))))
-    Za, Zb = Z1_oracle.clone(), torch.empty_like(Z1_oracle)
-    t0 = time.perf_counter()
-    for _ in range(n):
-        Zb, _ = OC.sweep(csr.rowptr, csr.colidx, P_host, Xf, Za, gamma, out=Zb)
-        Za, Zb = Zb, Za
-    per = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / per, "unit": "sweeps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} full sweeps of the same graph by oracle/clane_oracle.c (plain C, OpenMP over rows, "
-                      f"{threads} threads), P from the oracle's own build_P (graph.py:118-128)"}
-
-
-def cpu_baseline_torch(csr, Xf, P_host, gamma, budget_s=12.0):
-    """The PyTorch-CPU restatement SURVEY 8d names --  Z = X + gamma * (P @ Z)  plus the L1 delta, as in
-    oracle/clane_oracle.py:sweep -- with P as a torch.sparse_csr_tensor (its CPU kernel is parallel over rows; the COO
-    form of torch.sparse.mm is not: 0.127 sweeps/s on 128 threads against 0.130 on one in round 2), on all host
-    threads and on ONE thread.  FULL sweeps (1 warm-up + up to 10 timed, at least one) whenever the estimate of one sweep
-    fits the budget (config 3 on all threads: ~4 s a sweep -- it does; SURVEY 8d asks for full sweeps); else a bounded
-    SAMPLE of the workload, a seeded random 1/m of the rows (same degree mix; every m-th row would not do: R-MAT's hubs
-    sit on the ids with trailing zero bits), scaled by the share of the edges the sample holds -- `sample` says which."""
-    import warnings
-    deg = np.diff(csr.rowptr)
-    E, V = int(csr.rowptr[-1]), csr.num_vertices
-    Z = Xf
-    all_threads = torch.get_num_threads()
-
-    def timed(stride, threads, max_reps):
-        rows = np.arange(V, dtype=np.int64) if stride == 1 else \
-            np.sort(np.random.default_rng(stride).choice(V, size=max(1, V // stride), replace=False))
-        if stride == 1:
-            crow, cols, vals = csr.rowptr, csr.colidx, P_host
-        else:
-            take = np.repeat(csr.rowptr[rows], deg[rows]) + (np.arange(int(deg[rows].sum())) -
-                                                             np.repeat(np.cumsum(deg[rows]) - deg[rows], deg[rows]))
-            crow = np.concatenate([[0], np.cumsum(deg[rows])])
-            cols, vals = csr.colidx[take], P_host[torch.from_numpy(take)]
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")                    # "Sparse CSR tensor support is in beta state"
-            Ps = torch.sparse_csr_tensor(torch.from_numpy(np.asarray(crow, dtype=np.int64)),
-                                         torch.from_numpy(np.asarray(cols).astype(np.int64)), vals, size=(rows.size, V))
-        rows_t = torch.from_numpy(rows)
-        Xs, Zs = (Xf, Z) if stride == 1 else (Xf[rows_t], Z[rows_t])
-        sink = torch.from_numpy(deg[rows] == 0)
-        n_edges = int(deg[rows].sum())
-        torch.set_num_threads(threads)
-        try:
-            times = []
-            spent = 0.0
-            for i in range(max_reps + 1):                      # first pass = warm-up
-                t0 = time.perf_counter()
-                Zn = Xs + gamma * (Ps @ Z)
-                Zn[sink] = Zs[sink]
-                (Zn - Zs).abs().sum()
-                dt = time.perf_counter() - t0
-                spent += dt
-                if i:
-                    times.append(dt)
-                if i >= 1 and spent + dt > budget_s:
-                    break
-        finally:
-            torch.set_num_threads(all_threads)
-        share = n_edges / max(E, 1)
-        return min(times) / share, share, rows.size, len(times)
-
-    def figure(threads, probe_rows):
-        probe, _, _, _ = timed(max(1, V // probe_rows), threads, 1)           # a small probe sizes the sample
-        # the probe (a small sample, scaled) over-estimates: its per-call costs are scaled too.  Full sweeps whenever
-        # the ESTIMATE of one fits the budget (config 3, all threads: estimated 4-7 s, really 3.5 s)
-        stride = 1 if probe <= budget_s else max(2, int(np.ceil(probe * 3 / budget_s)))
-        per, share, n_rows, reps = timed(stride, threads, 10 if stride == 1 else 2)
-        if stride == 1:
-            return per, f"{reps} full sweeps (after 1 warm-up), best"
-        # A sample's time is not proportional to its edges alone (per-call costs that do not shrink with the sample --
-        # thread wake-ups, touching the whole of Z: seconds at 16M vertices -- would be multiplied by 1/share): grow the
-        # sample until it takes a real share of the budget, then take the line through the two largest samples,
-        # cost(E) = a + b * edges.
-        samples = [(share, per * share, n_rows, stride)]
-        while samples[-1][1] < budget_s / 6 and stride > 2 and len(samples) < 4:
-            stride = max(2, stride // 4)
-            per_n, share_n, rows_n, _ = timed(stride, threads, 2)
-            samples.append((share_n, per_n * share_n, rows_n, stride))
-        if len(samples) == 1:               # the first sample was big enough: a second one of half the size for the line
-            per_n, share_n, rows_n, _ = timed(2 * stride, threads, 2)
-            samples.insert(0, (share_n, per_n * share_n, rows_n, 2 * stride))
-        (s0, t0, _, _), (s1, t1, r1, st1) = samples[-2], samples[-1]
-        if t1 > t0 and s1 > s0:
-            whole = t1 + (t1 - t0) / (s1 - s0) * (1.0 - s1)
-            how = "the line through the two largest samples (fixed per-call cost + per-edge cost)"
-        else:                               # the per-call cost drowns the difference: no slope to extend
-            whole = max(t1, t0)
-            how = ("NOTHING: the two samples took the same time (a per-call cost that does not shrink with the sample), so "
-                   "this is a LOWER bound of a sweep's time, i.e. an upper bound of sweeps/s")
-        return whole, (f"random row samples, the largest 1/{st1} of the rows ({r1} rows, {s1:.1%} of the edges), best of 2 "
-                       f"each, extended to a whole sweep by {how}")
-
-    per_all, what_all = figure(all_threads, 20_000)
-    per_1, what_1 = figure(1, 5_000)
-    return {"value": 1.0 / per_all, "unit": "sweeps/s", "cores": all_threads, "kind": "port",
-            "sample": f"X + gamma*(P @ Z) + L1 delta with P a torch.sparse_csr_tensor (oracle/clane_oracle.py:sweep): "
-                      f"{what_all}; torch {torch.__version__}, {all_threads} threads",
-            "one_thread": {"value": 1.0 / per_1, "unit": "sweeps/s", "cores": 1,
-                           "sample": f"the same with torch.set_num_threads(1): {what_1}"}}
-
-
 def traffic_entry(workload: str, world: int, eng, dom: str, slice_of=None):
     """PMC traffic of kernel `dom` from profiles/traffic.json -- only if it was measured with THIS kernel
     configuration (thresholds, launch blocks, compile-time tuning, ...); else (None, why)."""
@@ -301,6 +179,14 @@ def make_parser():
                          "tolerance (build_P + propagate per outer round) -- and report rounds, sweeps, wall time")
     ap.add_argument("--tolerence", type=int, default=10, help="(reference spelling) for --iterate")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baselines (the parity check stays)")
+    ap.add_argument("--legs", default="auto",
+                    help="further workloads measured after the main one, in the same process and JSON line (one GPU only): "
+                         "auto (default) = uniform2m,rmat200k,powerlaw10m when the main workload is the headline (rmat2m): the "
+                         "roofline's no-reuse anchor -> roofline.anchor, BASELINE configs 2 and 4 (the latter incl. "
+                         "Embedder.iterate() to tolerence) -> other_workloads; a comma-separated list; none = off")
+    ap.add_argument("--budget-s", type=float, default=270.0,
+                    help="wall-time plan of the whole command: a leg is only started while the time used so far plus its "
+                         "estimate fits (the driver allows 600 s; the main record never waits for a leg)")
     ap.add_argument("--no-parity", action="store_true", help="skip the first-sweep check against the C oracle too")
     ap.add_argument("--column-slice-of", type=int, default=None, metavar="N",
                     help="one-GPU rehearsal of ONE rank of the N-GPU column split: sweep only the first d/N columns "
@@ -723,7 +609,16 @@ def main_record(args, ranks: Ranks, m, X, E) -> dict:
     return result
 
 
-def check_parity(args, ranks: Ranks, eng, m, csr, X, result):
+DEGENERATE_SOFTMAX_NOTE = (
+    "reference-mode scores are dot / (||Z[src_all]||_F * ||Z[dst_all]||_F) (similarity.py:35-37: GLOBAL denominators): at "
+    "|E| >= 4M they are O(1e-9), exp() of them is exactly 1 in fp32 and P = 1/deg on both sides, so parity_P_rel_l2_vs_oracle "
+    "checks the softmax plumbing and the edge order, not K1's dot products.  Those are checked by "
+    "parity_P_per_edge_rel_l2_vs_oracle here (the same kernels with per-edge cosine scores, all edges, against the C "
+    "oracle) and in the GPU suite by test_k1_scores_at_scale / test_config3_per_edge_P_sampled_rows (raw dots, per-edge "
+    "cosine, million-edge rows)")
+
+
+def check_parity(args, ranks: Ranks, eng, m, csr, X, result, baselines: bool = True):
     """The first GPU sweep (and P itself) against the C oracle, which builds its OWN P; at N = 1 also the CPU
     baselines (the oracle timed on this box's host cores).  Returns (the oracle's first sweep on rank 0, failed) -- the
     verdict is all-reduced, so every rank leaves together."""
@@ -731,24 +626,51 @@ def check_parity(args, ranks: Ranks, eng, m, csr, X, result):
     Z1_oracle, failed = None, False
     P_gpu = eng.P_global() if eng.row_world == 1 else None      # row splits: each rank holds its rows of P
     if ranks.rank == 0:
+        from oracle import baseline as B
         from oracle import clane_oracle as O
         from oracle import clane_oracle_c as OC
         if ranks.world > 1:     # torchrun gives every rank OMP_NUM_THREADS=1; the others are idle in the collective below
             OC.set_threads(os.cpu_count() or 1)
-        Z1_oracle, first, _, P_oracle, Xf = oracle_first_sweep(csr, X, None, args.gamma)
+        Z1_oracle, first, _, P_oracle, Xf = B.oracle_first_sweep(csr, X, None, args.gamma)
         parity = O.rel_l2(m["Z1"].float(), Z1_oracle)
         result["parity_rel_l2_vs_oracle_after_1_sweep"] = parity
         result["parity_note"] = ("first sweep from Z = X on the GPU(s), P from the GPU build_P, against "
-                                 "oracle/clane_oracle.c running its own build_P and sweep")
+                                 "oracle/clane_oracle.c running its own build_P and sweep (fp32, on the bf16-rounded "
+                                 "inputs where the storage is bf16); " + DEGENERATE_SOFTMAX_NOTE)
         failed = not parity < PARITY_TOL[dname]
         if P_gpu is not None:
             parity_p = O.rel_l2(P_gpu.float(), P_oracle)
             result["parity_P_rel_l2_vs_oracle"] = parity_p
             failed = failed or not parity_p < PARITY_P_TOL[dname]
-        if ranks.world == 1 and not ranks.rehearsal and not args.no_cpu_baseline and not failed:
-            result["cpu_baseline"] = cpu_baseline(csr, Xf, P_oracle, args.gamma, Z1_oracle, first)
-            result["cpu_baseline_torch"] = cpu_baseline_torch(csr, Xf, P_oracle, args.gamma)
+        if ranks.world == 1 and not ranks.rehearsal and not args.no_cpu_baseline and not failed and baselines:
+            result["cpu_baseline"] = B.cpu_baseline(csr, Xf, P_oracle, args.gamma, Z1_oracle, first)
+            result["cpu_baseline_torch"] = B.cpu_baseline_torch(csr, Xf, P_oracle, args.gamma)
     return Z1_oracle, ranks.agree_to_fail(failed)
+
+
+def per_edge_parity(args, ranks: Ranks, eng, csr, X, result) -> bool:
+    """A K1 check that is NOT degenerate at full size (one GPU): the same engine scores every edge with the per-edge
+    cosine (cosine_mode "per_edge": dot / (|z_src| |z_dst|), the cosine similarity.py's docstring describes) from Z = X
+    and all of P is compared with the C oracle's per-edge build_P.  Leaves the engine with a reference-mode P of Z = X."""
+    from oracle import clane_oracle as O
+    from oracle import clane_oracle_c as OC
+    dname = WORKLOADS[args.workload][4]
+    eng.set_Z(X)
+    eng.set_cosine_mode("per_edge")
+    eng.build_P()
+    P_pe = eng.P_global().float()
+    eng.set_cosine_mode("reference")
+    eng.build_P()
+    P_or, _ = OC.build_P(csr.rowptr, csr.colidx, X.float(), mode="per_edge")
+    err = O.rel_l2(P_pe, P_or)
+    deg = np.diff(csr.rowptr)
+    hub = int(np.argmax(deg))
+    ph = P_or[int(csr.rowptr[hub]):int(csr.rowptr[hub + 1])]
+    result["parity_P_per_edge_rel_l2_vs_oracle"] = err
+    result["parity_P_per_edge_note"] = (f"all {csr.num_edges} values of P with per-edge cosine scores (not 1/deg: the "
+                                        f"heaviest row's P spans a factor {float(ph.max() / ph.min()):.2f}) against "
+                                        f"oracle/clane_oracle.c's per-edge build_P")
+    return not err < PARITY_P_TOL[dname] * 5         # scores O(0.1): exp and the softmax sums see real arguments
 
 
 def run_iterate(args, ranks: Ranks, eng, csr, X) -> dict:
@@ -774,6 +696,54 @@ def run_iterate(args, ranks: Ranks, eng, csr, X) -> dict:
                     "stopping rule (embedder.py:56-108); sweeps whose delta is provably 0 (after an "
                     "exactly-zero delta with P frozen) are counted, not launched; not part of the "
                     "headline value"}
+
+
+LEG_SETTINGS = {    # workload: (steps, warmup, blocks, iterate) of the short legs after the headline measurement
+    "uniform2m": (20, 5, 3, False), "rmat200k": (200, 20, 3, False), "powerlaw10m": (20, 5, 3, True),
+}
+LEG_WHAT = {
+    "uniform2m": "the roofline's ANCHOR: uniform-random pairs at the headline's |V|, |E|, d -- no hubs, nothing for the L2s "
+                 "or the Infinity Cache to reuse (PMC traffic == algorithmic bytes), so its frac is a true HBM fraction",
+    "rmat200k": "BASELINE config 2 (R-MAT 200k / 4M / d=128 fp32; the table sits in the Infinity Cache)",
+    "powerlaw10m": "BASELINE config 4 (power-law 10M / 200M / d=128, bf16 storage, fp32 accumulate) on ONE GPU, incl. "
+                   "Embedder.iterate() from Z = X to `tolerence` convergence -- that run IS configs[4]",
+}
+
+
+def workload_leg(args, ranks: Ranks, name: str) -> dict:
+    """One more workload measured in the same process with the same protocol (fewer blocks), parity-checked against the
+    C oracle, as a compact block of the main record."""
+    import copy
+    steps, warmup, blocks, iterate = LEG_SETTINGS[name]
+    la = copy.copy(args)
+    la.workload, la.steps, la.warmup, la.blocks, la.calibrate, la.column_slice_of = name, steps, warmup, blocks, False, None
+    t0 = time.perf_counter()
+    csr, X = generate_input(la, ranks)
+    m = measure_division(la, ranks, csr, X, "auto", time_kernels=True)
+    eng = m["eng"]
+    rec = main_record(la, ranks, m, X, csr.num_edges)
+    _, failed = check_parity(la, ranks, eng, m, csr, X, rec, baselines=False)
+    roof = rec["roofline"]
+    out = {"what": LEG_WHAT[name], "workload": rec["config"]["workload"], "value": rec["value"], "unit": rec["unit"],
+           "ms_per_step": rec["ms_per_step"], "ms_per_step_min": rec["ms_per_step_min"],
+           "ms_per_step_max": rec["ms_per_step_max"], "steps": steps, "warmup": warmup, "blocks": blocks,
+           "dtype": rec["dtype"], "host_sync": rec["config"]["host_sync"],
+           "build_P_ms": rec["build_P_ms"], "build_P_cold_ms": rec["build_P_cold_ms"],
+           "parity_rel_l2_vs_oracle_after_1_sweep": rec.get("parity_rel_l2_vs_oracle_after_1_sweep"),
+           "parity_P_rel_l2_vs_oracle": rec.get("parity_P_rel_l2_vs_oracle"),
+           "parity_tolerance": {"Z1": PARITY_TOL[rec["dtype"]], "P": PARITY_P_TOL[rec["dtype"]]},
+           "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                 "traffic_over_algorithmic", "achieved_algorithmic",
+                                                 "algorithmic_bytes_per_launch", "avg_launch_ms", "pmc_run_over_live_time",
+                                                 "k3_pass")}}
+    if roof.get("traffic") is None:
+        out["roofline"]["traffic_missing"] = roof.get("kernels", {}).get(roof.get("kernel"), {}).get("traffic_missing")
+    if failed:
+        out["error"] = "parity check failed"
+    elif iterate:
+        out["iterate"] = run_iterate(la, ranks, eng, csr, X)
+    out["leg_wall_s"] = time.perf_counter() - t0
+    return out
 
 
 DIVISION_NOTES = {
@@ -822,6 +792,9 @@ def division_block(args, ranks: Ranks, csr, X, E, exchange: str, main_division: 
     return block, failed
 
 
+T_START = time.perf_counter()
+
+
 def main():
     args = make_parser().parse_args()
     unknown = [x for x in args.also_exchange.split(",") if x not in ("", "none", "columns", "halo", "halo_p2p",
@@ -858,8 +831,47 @@ def main():
                 dist.destroy_process_group()
             raise SystemExit(f"parity check failed: {result.get('parity_rel_l2_vs_oracle_after_1_sweep')} "
                              f"(P: {result.get('parity_P_rel_l2_vs_oracle')})")
+    if not args.no_parity and not ranks.grouped and not args.column_slice_of and WORKLOADS[args.workload][4] != "f64":
+        if per_edge_parity(args, ranks, eng, csr, X, result):
+            print(json.dumps(result), flush=True)
+            raise SystemExit(f"per-edge parity check of P failed: {result['parity_P_per_edge_rel_l2_vs_oracle']}")
     if args.iterate:
         result["iterate"] = run_iterate(args, ranks, eng, csr, X)
+
+    # ---- further workloads in the same record (one GPU): the roofline's anchor, BASELINE configs 2 and 4 --------
+    legs = [] if (ranks.grouped or args.column_slice_of or args.legs == "none") else \
+        (list(LEG_SETTINGS) if args.workload == "rmat2m" else []) if args.legs == "auto" else \
+        [x for x in args.legs.split(",") if x]
+    if legs:
+        log("main workload measured; the record so far (the ONE stdout line follows after the legs): " + json.dumps(result))
+        del m["eng"]
+        eng = None
+        estimate = {"uniform2m": 25.0, "rmat200k": 10.0, "powerlaw10m": 70.0}
+        result["legs_plan"] = {"budget_s": args.budget_s, "estimate_s": {n: estimate.get(n, 60.0) for n in legs},
+                               "used_before_legs_s": time.perf_counter() - T_START}
+        for name in legs:
+            used = time.perf_counter() - T_START
+            if name not in LEG_SETTINGS:
+                block = {"error": f"no leg settings for workload {name}"}
+            elif used + estimate.get(name, 60.0) > args.budget_s:
+                block = {"skipped": f"{used:.0f} s used, estimate {estimate.get(name, 60.0):.0f} s: over the {args.budget_s:.0f} s plan"}
+            else:
+                try:
+                    torch.cuda.empty_cache()
+                    block = workload_leg(args, ranks, name)
+                    log(f"leg {name}: {block['value']:.1f} sweeps/s, frac {block['roofline']['frac']:.3f}, "
+                        f"{block['leg_wall_s']:.1f} s")
+                except Exception as exc:    # noqa: BLE001 -- reported in the record; the main measurement stands
+                    block = {"error": f"{type(exc).__name__}: {exc}"}
+            if name == "uniform2m":
+                result["roofline"]["anchor"] = block
+            else:
+                result.setdefault("other_workloads", {})[name] = block
+        result["legs_plan"]["used_s"] = time.perf_counter() - T_START
+        blocks_ = [result["roofline"].get("anchor", {})] + list(result.get("other_workloads", {}).values())
+        if any(b_.get("error") == "parity check failed" for b_ in blocks_):     # loud: a wrong result is not a measurement
+            print(json.dumps(result), flush=True)
+            raise SystemExit("a workload measured after the main one failed its parity check (see its block in the record)")
 
     # ---- north_star's literal division beside the default one, in the same record -----------------------------
     printed = threading.Event()

@@ -14,31 +14,50 @@ namespace clane {
 
 
 // ---- K0 ------------------------------------------------------------------------------------
-// LPR lanes per row; a wave covers 64/LPR rows at once.
+// LPR lanes per row; a wave covers 64/LPR rows with one load instruction and stream_rows(LPR) such groups per turn, all
+// their loads issued before the first is used: a streaming pass needs ~8 MB in flight on this chip (2 us x 4+ TB/s),
+// and one 16-byte load per lane per turn left the 1-KiB-row instance at 5.3 TB/s.  Measured per shape
+// (profiles/r05_stream_kernels.md): a row per instruction wants 4 groups in flight (row_sqnorm 5.33 -> 5.73 TB/s,
+// l1_distance + norms 5.44 -> 6.14), 2 or 4 rows per instruction want 2 (bf16 d=128: 5.30 -> 5.50; 4 groups there cost
+// registers and 10-20 %), 8 per turn lose everywhere.
+constexpr int stream_rows(int lpr) { return lpr >= kWave ? 4 : lpr >= 16 ? 2 : 1; }
 template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kBlock) void row_sqnorm_kernel(const T *__restrict__ Z, int64_t nrows, int d, int64_t ldz,
                                                             typename Elem<T>::acc_t *__restrict__ sq) {
     using A = typename Elem<T>::acc_t;
     constexpr int RPW = kWave / LPR;
+    constexpr int kStreamRows = stream_rows(LPR);
     const int lane = lane_id();
     const int sub = lane / LPR, sl = lane % LPR;
     const int64_t wave = int64_t(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
     const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
-    for (int64_t base = wave * RPW; base < nrows; base += nwaves * RPW) {
-        const int64_t r = base + sub;
-        A s = A(0);
-        if (r < nrows) {
-            for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC) {
-                const Pack<T, VEC> z = load_pack<T, VEC>(Z + r * ldz + c0);
+    for (int64_t base = wave * (RPW * kStreamRows); base < nrows; base += nwaves * (RPW * kStreamRows)) {
+        A s[kStreamRows];
+#pragma unroll
+        for (int j = 0; j < kStreamRows; ++j) s[j] = A(0);
+        for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC) {      // a row's packs in the same order, whatever kStreamRows
+            Pack<T, VEC> z[kStreamRows];
+#pragma unroll
+            for (int j = 0; j < kStreamRows; ++j) {
+                const int64_t r = base + j * RPW + sub;
+                z[j] = Pack<T, VEC>{};
+                if (r < nrows) z[j] = load_pack<T, VEC>(Z + r * ldz + c0);
+            }
+#pragma unroll
+            for (int j = 0; j < kStreamRows; ++j) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const A v = Elem<T>::to_acc(z.v[k]);
-                    s = fma(v, v, s);
+                    const A v = Elem<T>::to_acc(z[j].v[k]);
+                    s[j] = fma(v, v, s[j]);
                 }
             }
         }
-        s = group_sum<LPR>(s);
-        if (r < nrows && sl == 0) sq[r] = s;
+#pragma unroll
+        for (int j = 0; j < kStreamRows; ++j) {
+            const int64_t r = base + j * RPW + sub;
+            const A t = group_sum<LPR>(s[j]);
+            if (r < nrows && sl == 0) sq[r] = t;
+        }
     }
 }
 
@@ -186,29 +205,45 @@ __global__ __launch_bounds__(kBlock) void l1_distance_kernel(const T *__restrict
     using A = typename Elem<T>::acc_t;
     __shared__ double smem[kWavesPerBlock];
     constexpr int RPW = kWave / LPR;
+    constexpr int kStreamRows = stream_rows(LPR);
     const int lane = lane_id();
     const int sub = lane / LPR, sl = lane % LPR;
     const int64_t wave = int64_t(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
     const int64_t nwaves = int64_t(gridDim.x) * kWavesPerBlock;
     double dsum = 0.0;
-    for (int64_t base = wave * RPW; base < nrows; base += nwaves * RPW) {
-        const int64_t r = base + sub;
-        if (r >= nrows) continue;            // uniform over the LPR lanes of a row
-        A s = A(0), q = A(0);
-        for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC) {
-            const Pack<T, VEC> a = load_pack<T, VEC>(Am + r * lda + c0);
-            const Pack<T, VEC> b = load_pack<T, VEC>(Bm + r * ldb + c0);
+    for (int64_t base = wave * (RPW * kStreamRows); base < nrows; base += nwaves * (RPW * kStreamRows)) {
+        A s[kStreamRows], q[kStreamRows];                  // kStreamRows row groups per turn: 2 x kStreamRows loads in flight
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const A av = Elem<T>::to_acc(a.v[k]);
-                s += fabs(av - Elem<T>::to_acc(b.v[k]));
-                q = fma(av, av, q);
+        for (int j = 0; j < kStreamRows; ++j) s[j] = q[j] = A(0);
+        for (int c0 = sl * VEC; c0 < d; c0 += LPR * VEC) {
+            Pack<T, VEC> a[kStreamRows], b[kStreamRows];
+#pragma unroll
+            for (int j = 0; j < kStreamRows; ++j) {
+                const int64_t r = base + j * RPW + sub;
+                a[j] = b[j] = Pack<T, VEC>{};
+                if (r < nrows) {
+                    a[j] = load_pack<T, VEC>(Am + r * lda + c0);
+                    b[j] = load_pack<T, VEC>(Bm + r * ldb + c0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kStreamRows; ++j) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    const A av = Elem<T>::to_acc(a[j].v[k]);
+                    s[j] += fabs(av - Elem<T>::to_acc(b[j].v[k]));
+                    q[j] = fma(av, av, q[j]);               // K0's order: lane l takes the packs l, l + LPR, ...
+                }
             }
         }
-        dsum += double(s);
-        if (sq_a != nullptr) {               // kernel argument: uniform
-            q = group_sum<LPR>(q);
-            if (sl == 0) sq_a[r] = q;
+#pragma unroll
+        for (int j = 0; j < kStreamRows; ++j) {
+            const int64_t r = base + j * RPW + sub;
+            dsum += double(s[j]);                           // rows past the end contribute exact zeros
+            if (sq_a != nullptr) {                          // kernel argument: uniform
+                const A t = group_sum<LPR>(q[j]);
+                if (r < nrows && sl == 0) sq_a[r] = t;
+            }
         }
     }
     const double t = block_sum_fixed(dsum, smem);

@@ -142,7 +142,7 @@ int row_sqnorm(const T *Z, int64_t nrows, int32_t d, int64_t ldz, typename Elem<
     REQUIRE(Z && sq, "row_sqnorm: null pointer");
     const Layout L = pick_layout<T>(d, {Z}, {ldz});
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
-        const int grid = grid_for_waves(ceil_div(nrows, kWave / LPR));
+        const int grid = grid_for_waves(ceil_div(nrows, (kWave / LPR) * stream_rows(LPR)));
         row_sqnorm_kernel<T, VEC, LPR><<<grid, kBlock, 0, (hipStream_t)stream>>>(Z, nrows, d, ldz, sq);
     });
     return check_launch("row_sqnorm");
@@ -412,7 +412,7 @@ int l1_distance(const T *A, int64_t lda, const T *B, int64_t ldb, int64_t nrows,
     }
     int grid = 1;
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
-        grid = grid_for_waves(ceil_div(nrows > 0 ? nrows : 1, kWave / LPR));
+        grid = grid_for_waves(ceil_div(nrows > 0 ? nrows : 1, (kWave / LPR) * stream_rows(LPR)));
         if (grid > kReduceGrid) grid = kReduceGrid;
         l1_distance_kernel<T, VEC, LPR><<<grid, kBlock, 0, (hipStream_t)stream>>>(A, lda, B, ldb, nrows, d, sq_a, ws);
     });

@@ -826,6 +826,14 @@ class SweepEngine:
                                   self.long_rows[i])
         self.P_valid = True
 
+    def set_cosine_mode(self, mode: str) -> None:
+        """Switch between the reference's scores (global Frobenius denominators, similarity.py:35-37) and true per-edge
+        cosine for the NEXT build_P; the row layout does not depend on it."""
+        if mode not in ("reference", "per_edge"):
+            raise ValueError(f"cosine_mode must be 'reference' or 'per_edge', got {mode!r}")
+        if mode != self.cosine_mode:
+            self.cosine_mode, self.P_valid = mode, False
+
     def P_global(self) -> torch.Tensor:
         """P values of the rows this rank owns as a CPU tensor in the GLOBAL (row, col)-sorted edge order,
         zeros elsewhere (the engine stores them in its own row / column order)."""

@@ -69,9 +69,13 @@ double clane_c_sweep_f32(const int64_t *rowptr, const int32_t *colidx, const flo
     return delta;
 }
 
-/* P[e] = row-softmax of dot(z_src, z_dst) / D, D = sqrt(sum_e |z_src|^2) * sqrt(sum_e |z_dst|^2). Returns D. */
-double clane_c_build_P_f32(const int64_t *rowptr, const int32_t *colidx, int64_t V, int32_t d, const float *Z,
-                           float *P) {
+/* P[e] = row-softmax of dot(z_src, z_dst) / D, D = sqrt(sum_e |z_src|^2) * sqrt(sum_e |z_dst|^2). Returns D.
+ * per_edge != 0 (the build's extension, clane_amd cosine_mode="per_edge": the cosine CosineSimilarity's docstring
+ * describes, similarity.py:9-19, instead of what line 37 computes): score = dot / (|z_src| * |z_dst|); returns 0.
+ * Scores at the reference's global denominator are O(1e-9) on large graphs, where exp() is exactly 1 and P = 1/deg: this
+ * mode is what makes a full-size comparison of P sensitive to the dot products. */
+double clane_c_build_P_mode_f32(const int64_t *rowptr, const int32_t *colidx, int64_t V, int32_t d, const float *Z,
+                                float *P, int per_edge) {
     double *sq = (double *)malloc(sizeof(double) * (size_t)V);
     int64_t *indeg = (int64_t *)calloc((size_t)V, sizeof(int64_t));
 #pragma omp parallel for schedule(static)
@@ -92,12 +96,13 @@ double clane_c_build_P_f32(const int64_t *rowptr, const int32_t *colidx, int64_t
         const int64_t e0 = rowptr[v], e1 = rowptr[v + 1];
         if (e0 == e1) continue;
         const float *zs = Z + v * d;
+        const float ns = sqrtf((float)sq[v]);
         float m = -INFINITY;
         for (int64_t e = e0; e < e1; ++e) {
             const float *zd = Z + (int64_t)colidx[e] * d;
             float dot = 0.0f;
             for (int32_t k = 0; k < d; ++k) dot += zs[k] * zd[k];
-            P[e] = dot / D;
+            P[e] = per_edge ? dot / (ns * sqrtf((float)sq[colidx[e]])) : dot / D;
             if (P[e] > m) m = P[e];
         }
         float s = 0.0f;
@@ -109,5 +114,10 @@ double clane_c_build_P_f32(const int64_t *rowptr, const int32_t *colidx, int64_t
     }
     free(sq);
     free(indeg);
-    return (double)D;
+    return per_edge ? 0.0 : (double)D;
+}
+
+double clane_c_build_P_f32(const int64_t *rowptr, const int32_t *colidx, int64_t V, int32_t d, const float *Z,
+                           float *P) {
+    return clane_c_build_P_mode_f32(rowptr, colidx, V, d, Z, P, 0);
 }

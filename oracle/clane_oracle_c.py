@@ -28,6 +28,8 @@ def lib():
         L.clane_c_sweep_f32.argtypes = [p, p, p, i64, i32, p, p, C.c_float, p]
         L.clane_c_build_P_f32.restype = C.c_double
         L.clane_c_build_P_f32.argtypes = [p, p, i64, i32, p, p]
+        L.clane_c_build_P_mode_f32.restype = C.c_double
+        L.clane_c_build_P_mode_f32.argtypes = [p, p, i64, i32, p, p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -58,12 +60,15 @@ def sweep(rowptr: np.ndarray, colidx: np.ndarray, P: torch.Tensor, X: torch.Tens
     return Zn, float(delta)
 
 
-def build_P(rowptr: np.ndarray, colidx: np.ndarray, Z: torch.Tensor):
-    """(P values in CSR order, global denominator D) -- graph.py:118-128 + similarity.py:26-37, fp32."""
+def build_P(rowptr: np.ndarray, colidx: np.ndarray, Z: torch.Tensor, mode: str = "reference"):
+    """(P values in CSR order, global denominator D) -- graph.py:118-128 + similarity.py:26-37, fp32.
+    mode "per_edge" (the build's extension): true per-edge cosine scores; D is 0 then."""
+    if mode not in ("reference", "per_edge"):
+        raise ValueError(mode)
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     colidx = np.ascontiguousarray(colidx, dtype=np.int32)
     Z = _f32(Z)
     P = torch.empty(int(rowptr[-1]), dtype=torch.float32)
-    D = lib().clane_c_build_P_f32(rowptr.ctypes.data, colidx.ctypes.data, Z.shape[0], Z.shape[1], Z.data_ptr(),
-                                  P.data_ptr())
+    D = lib().clane_c_build_P_mode_f32(rowptr.ctypes.data, colidx.ctypes.data, Z.shape[0], Z.shape[1], Z.data_ptr(),
+                                       P.data_ptr(), int(mode == "per_edge"))
     return P, float(D)

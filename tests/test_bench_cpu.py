@@ -73,14 +73,15 @@ def test_torch_baseline_sampled_and_full(monkeypatch):
     import warnings
     import numpy as np
     from clane_amd import synth
+    from oracle import baseline as B
     from oracle import clane_oracle as O
     csr = synth.rmat_csr(60_000, 1_500_000, seed=1, device="cpu")
     X = synth.gaussian_X(60_000, 64, seed=2)
     P = O.build_P_values(csr.rowptr, csr.colidx, X)
-    out = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=0.001)     # tiny budget: forces row sampling
+    out = B.cpu_baseline_torch(csr, X, P, 0.76, budget_s=0.001)     # tiny budget: forces row sampling
     assert out["kind"] == "port" and out["cores"] == torch.get_num_threads() and out["one_thread"]["cores"] == 1
     assert "sparse_csr_tensor" in out["sample"] and "random row samples, the largest 1/" in out["sample"]
-    full_run = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=20.0)
+    full_run = B.cpu_baseline_torch(csr, X, P, 0.76, budget_s=20.0)
     assert "full sweeps" in full_run["sample"] and "full sweeps" in full_run["one_thread"]["sample"]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -104,7 +105,7 @@ def test_torch_baseline_sampled_and_full(monkeypatch):
     if torch.get_num_threads() >= 4:        # the CSR kernel threads (round 2's COO form: 0.98x); a loaded host gets a second try
         ratio = full_run["value"] / full_run["one_thread"]["value"]
         if ratio <= 1.2:
-            again = bench.cpu_baseline_torch(csr, X, P, 0.76, budget_s=20.0)
+            again = B.cpu_baseline_torch(csr, X, P, 0.76, budget_s=20.0)
             ratio = max(ratio, again["value"] / again["one_thread"]["value"])
         assert ratio > 1.2, ratio
     assert torch.get_num_threads() == out["cores"]                      # thread count restored

@@ -12,7 +12,7 @@ import sys, json
 for ln in sys.stdin:
     j = json.loads(ln); print('  slice W=%d d=%d: %.3f ms  main %.3f hub %.3f split %.3f  build_P %.2f' % (j['world'], j['d_local'], j['ms_per_sweep'], j['kernels_ms']['main'], j['kernels_ms']['hub'], j['kernels_ms']['split'], j['build_P_ms']))"
   for w in rmat2m rmat200k powerlaw10m; do
-    CLANE_HIP_LIB=$lib python3 "$R/bench.py" --workload $w --no-cpu-baseline --steps 30 --warmup 5 2>/dev/null | python3 -c "
+    CLANE_HIP_LIB=$lib python3 "$R/bench.py" --workload $w --no-cpu-baseline --legs none --steps 30 --warmup 5 2>/dev/null | python3 -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = j['roofline']
 print('  $w: %.1f sweeps/s  %.3f ms  main %.3f  parity %.2e' % (j['value'], j['ms_per_step'], r['kernels'].get('spmm_update_kernel', {}).get('avg_launch_ms', 0), j['parity_rel_l2_vs_oracle_after_1_sweep']))"

@@ -19,7 +19,7 @@ for rnd in range(args.rounds):
     for lib in libs:
         name = Path(lib).stem.replace("libclane_hip_", "")
         env = dict(os.environ, CLANE_HIP_LIB=lib)
-        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--steps", str(args.steps),
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--legs", "none", "--steps", str(args.steps),
                               "--warmup", "5", "--workload", args.workload], env=env, capture_output=True, text=True)
         try:
             j = json.loads(out.stdout.strip().splitlines()[-1])

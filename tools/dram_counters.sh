@@ -10,7 +10,7 @@ RAW="/tmp/clane_dram_${TAG}_${W}"; rm -rf "$RAW"; mkdir -p "$RAW" "$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for C in TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum; do
   if rocprofv3 --pmc $C --output-format csv -d "$RAW/$C" -- python3 "$R/bench.py" --workload $W --steps 6 --warmup 2 \
-      --blocks 1 --no-cpu-baseline --no-parity "$@" > "$RAW/$C.json" 2> "$RAW/$C.err"; then echo "[dram] $C done"; else echo "[dram] $C FAILED: $(tail -2 "$RAW/$C.err")"; fi
+      --blocks 1 --no-cpu-baseline --legs none --no-parity "$@" > "$RAW/$C.json" 2> "$RAW/$C.err"; then echo "[dram] $C done"; else echo "[dram] $C FAILED: $(tail -2 "$RAW/$C.err")"; fi
 done
 python3 - "$RAW" "$W" "$TAG" "$R/gpurun_out/profiles" <<'PY'
 import collections, csv, glob, os, sys

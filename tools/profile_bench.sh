@@ -13,13 +13,13 @@ R="$(cd "$(dirname "$0")/.." && pwd)"
 RAW="/tmp/clane_prof_${TAG}_${W}"; rm -rf "$RAW"; mkdir -p "$RAW" "$R/gpurun_out/profiles"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -- python3 "$R/bench.py" --workload $W --steps 20 \
-    --warmup 5 --blocks 2 --no-cpu-baseline "$@" > "$RAW/bench_stats.json" 2> "$RAW/bench_stats.err" || { tail -20 "$RAW/bench_stats.err"; exit 1; }
+    --warmup 5 --blocks 2 --no-cpu-baseline --legs none "$@" > "$RAW/bench_stats.json" 2> "$RAW/bench_stats.err" || { tail -20 "$RAW/bench_stats.err"; exit 1; }
 echo "[profile] stats pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$RAW/fetch" -- python3 "$R/bench.py" --workload $W --steps 10 \
-    --warmup 2 --blocks 2 --no-cpu-baseline --calibrate "$@" > "$RAW/bench_fetch.json" 2> "$RAW/bench_fetch.err" || { tail -20 "$RAW/bench_fetch.err"; exit 1; }
+    --warmup 2 --blocks 2 --no-cpu-baseline --legs none --calibrate "$@" > "$RAW/bench_fetch.json" 2> "$RAW/bench_fetch.err" || { tail -20 "$RAW/bench_fetch.err"; exit 1; }
 echo "[profile] FETCH_SIZE pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$RAW/write" -- python3 "$R/bench.py" --workload $W --steps 10 \
-    --warmup 2 --blocks 2 --no-cpu-baseline --calibrate "$@" > "$RAW/bench_write.json" 2> "$RAW/bench_write.err" || { tail -20 "$RAW/bench_write.err"; exit 1; }
+    --warmup 2 --blocks 2 --no-cpu-baseline --legs none --calibrate "$@" > "$RAW/bench_write.json" 2> "$RAW/bench_write.err" || { tail -20 "$RAW/bench_write.err"; exit 1; }
 echo "[profile] WRITE_SIZE pass done"
 python3 "$R/tools/pmc_summary.py" "$RAW/fetch" "$RAW/write" --tag $TAG --workload ${KEY} \
     --bench-json "$RAW/bench_fetch.json" --stats "$RAW/stats" --out "$R/gpurun_out/profiles"

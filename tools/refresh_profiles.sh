@@ -30,7 +30,7 @@ if [ "$PART" = bench ] || [ "$PART" = all ]; then
   python3 bench.py --workload rmat200k --steps 200 --warmup 20       > "$P/${TAG}_bench_rmat200k_n1.json"        2>/dev/null
   python3 bench.py --workload powerlaw10m --steps 20 --warmup 5 --iterate > "$P/${TAG}_bench_powerlaw10m_n1.json" 2>/dev/null
   python3 bench.py --workload rmat16m --steps 10 --warmup 3          > "$P/${TAG}_bench_rmat16m_n1.json"         2>/dev/null
-  python3 bench.py --steps 20 --warmup 5 --iterate --no-cpu-baseline > "$P/${TAG}_bench_iterate_rmat2m_n1.json"  2>/dev/null
+  python3 bench.py --steps 20 --warmup 5 --iterate --no-cpu-baseline --legs none > "$P/${TAG}_bench_iterate_rmat2m_n1.json"  2>/dev/null
   for f in rmat2m uniform2m rmat200k powerlaw10m rmat16m iterate_rmat2m; do
     python3 - "$P/${TAG}_bench_${f}_n1.json" <<'PY'
 import json, sys

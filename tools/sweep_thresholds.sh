@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 for spec in "32 32" "48 48" "64 64" "24 24" "16 16" "32 128" "32 256" "64 128" "96 96" "128 128"; do
   set -- $spec
-  timeout -k 10 120 python bench.py --no-cpu-baseline --steps 30 --warmup 5 --long-threshold $1 --hub-threshold $2 2>/dev/null |
+  timeout -k 10 120 python bench.py --no-cpu-baseline --legs none --steps 30 --warmup 5 --long-threshold $1 --hub-threshold $2 2>/dev/null |
     python -c "
 import json,sys
 j=json.loads(sys.stdin.read()); r=j['roofline']
