@@ -162,6 +162,9 @@ def make_parser():
                          "north_star_literal block with its in-place all-gathers -- goes through the real library (each "
                          "collective is the identity on one rank).  Shows no scaling; catches API, dtype and stream "
                          "mistakes that the gloo rehearsals cannot.  Not a headline number.")
+    ap.add_argument("--no-fabric-probe", action="store_true",
+                    help="N > 1: skip tools/fabric_probe.py (child processes that time the all-gather / direct exchange of "
+                         "a rank's slice of Z and log RCCL's algorithm / protocol / channels before the timed run)")
     ap.add_argument("--no-delta-stream-ab", action="store_true",
                     help="N > 1: skip the extra timed blocks with the delta's all-reduce on its own stream (comm.delta_stream_ab)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -199,8 +202,9 @@ def make_parser():
 class Ranks:
     """The process group as bench.py uses it (a no-op on one GPU)."""
 
-    def __init__(self, world, rank, dev, pg, rehearsal=False):
+    def __init__(self, world, rank, dev, pg, rehearsal=False, fabric_probe=None):
         self.world, self.rank, self.dev, self.pg = world, rank, dev, pg
+        self.fabric_probe = fabric_probe          # rank 0: what tools/fabric_probe.py measured before the GPUs were touched
         # `grouped`: there is a process group and every collective is really issued -- N > 1, or the one-rank RCCL
         # rehearsal (--rehearse-rccl), where each is the identity but goes through the real library
         self.rehearsal = bool(rehearsal)
@@ -445,7 +449,10 @@ def comm_block(args, ranks: Ranks, m) -> dict:
                                          "per-chunk overlap did not hide) + the all-reduce of the delta scalar"},
             "ms_per_step_by_rank": per_rank, "ms_per_step_rank_min": min(per_rank), "ms_per_step_rank_max": max(per_rank),
             "collectives_issued": dict(eng.comm.calls) if hasattr(eng.comm, "calls") else None,
-            "delta_stream_ab": m.get("delta_stream_ab")}
+            "delta_stream_ab": m.get("delta_stream_ab"),
+            # what RCCL chose and what a link delivers at the literal plan's message size (ring vs direct),
+            # measured by child processes before the timed run (tools/fabric_probe.py); None off rank 0 / --no-fabric-probe
+            "fabric_probe": ranks.fabric_probe}
 
 
 def describe_parallelism(args, world, eng, X, E) -> str:
@@ -535,6 +542,20 @@ def start_ranks(args) -> Ranks:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     if world > 1:       # torchrun starts every rank with OMP_NUM_THREADS=1: give each rank its share of the host cores
         torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
+    probe = None
+    if (world > 1 or args.rehearse_rccl) and not args.no_fabric_probe:
+        # BEFORE this process touches its GPU: child processes measure what RCCL and the links do with the literal
+        # plan's message (this rank's slice of Z) and log RCCL's choices; the timed run below never logs
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("clane_fabric_probe", ROOT / "tools" / "fabric_probe.py")
+        fp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(fp)
+        _, V_, _, d_, dname_, _, _ = WORKLOADS[args.workload]
+        es = torch.empty(0, dtype=DTYPES[dname_]).element_size()
+        t0 = time.perf_counter()
+        probe = fp.run(world, rank, local_rank, slice_bytes=max(16, V_ * d_ * es // max(world, 1)),
+                       backend="nccl" if args.rehearse_rccl else args.backend, share_gpu=args.share_gpu)
+        TIMELINE["fabric_probe_s"] = time.perf_counter() - t0
     n_dev = torch.cuda.device_count()
     if world > 1 and not args.share_gpu and n_dev not in (1, world) and n_dev < world:
         raise SystemExit(f"--gpus {world} but this box shows {n_dev} GPU(s); a rehearsal on fewer GPUs needs "
@@ -568,7 +589,7 @@ def start_ranks(args) -> Ranks:
         else:
             dist.init_process_group("gloo", timeout=patience)
         pg = dist.group.WORLD
-    return Ranks(world, rank, dev, pg, rehearsal=args.rehearse_rccl)
+    return Ranks(world, rank, dev, pg, rehearsal=args.rehearse_rccl, fabric_probe=probe)
 
 
 def main_record(args, ranks: Ranks, m, X, E) -> dict:
@@ -793,6 +814,8 @@ def division_block(args, ranks: Ranks, csr, X, E, exchange: str, main_division: 
 
 
 T_START = time.perf_counter()
+TIMELINE = {}           # seconds spent per phase of this command (N > 1: reported as time_plan.spent_s)
+DRIVER_LIMIT_S = 600.0
 
 
 def main():
@@ -808,18 +831,32 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["CLANE_BENCH_WATCHDOG_S"]), repeat=True, file=sys.stderr)
 
     import torch.distributed as dist
+    n_also = 0 if args.also_exchange == "none" else len([x for x in args.also_exchange.split(",") if x])
+    plan = {"driver_limit_s": DRIVER_LIMIT_S, "fabric_probe_s_at_most": 120.0 if args.gpus > 1 and not args.no_fabric_probe else 0.0,
+            "generation_and_main_division_s_estimate": 60.0,
+            "each_division_after_the_main_one_s_at_most": LITERAL_DEADLINE_S, "divisions_after_the_main_one": n_also if args.gpus > 1 else 0}
+    plan["worst_case_s"] = (plan["fabric_probe_s_at_most"] + plan["generation_and_main_division_s_estimate"]
+                            + plan["divisions_after_the_main_one"] * LITERAL_DEADLINE_S)
+    if args.gpus > 1:
+        log(f"time plan: {json.dumps(plan)} -- the main division's record goes to stderr as soon as it is measured and is "
+            f"the ONE stdout line whatever happens to the divisions after it")
     ranks = start_ranks(args)
     rank = ranks.rank
     V, d = WORKLOADS[args.workload][1], WORKLOADS[args.workload][3]
     t0 = time.perf_counter()
     csr, X = generate_input(args, ranks)
     E = csr.num_edges
+    TIMELINE["generation_s"] = time.perf_counter() - t0
     log(f"{args.workload}: |V|={V} |E|={E} d={d} max outdeg={int(np.diff(csr.rowptr).max())} "
         f"generated in {time.perf_counter() - t0:.1f}s")
 
+    t0 = time.perf_counter()
     m = measure_division(args, ranks, csr, X, args.exchange, time_kernels=True)
+    TIMELINE["main_division_s"] = time.perf_counter() - t0
     eng = m["eng"]
     result = main_record(args, ranks, m, X, E)
+    if ranks.grouped:
+        result["time_plan"] = dict(plan, spent_s=TIMELINE)
 
     Z1_oracle, failed = None, False
     if not args.no_parity:
@@ -916,7 +953,9 @@ def main():
             timer = threading.Timer(LITERAL_DEADLINE_S, give_up)
             timer.daemon = True
             timer.start()
+            t_div = time.perf_counter()
             block, bad = division_block(args, ranks, csr, X, E, exchange, main_division, main_value, Z1_oracle)
+            TIMELINE[f"division_{exchange}_s"] = time.perf_counter() - t_div
             state["failed"] = state["failed"] or bad
             with lock:
                 if exchange == "allgather_all":
@@ -925,6 +964,7 @@ def main():
                     result.setdefault("other_divisions", {})[exchange] = block
         if timer is not None:               # every block is stored: the deadline of the last division is over
             timer.cancel()
+    TIMELINE["total_s"] = time.perf_counter() - T_START
     emit()
     if ranks.grouped:
         # leave together.  A rank that fell out of a block above on its own (an exception the others did not have)

@@ -109,3 +109,71 @@ def test_torch_baseline_sampled_and_full(monkeypatch):
             ratio = max(ratio, again["value"] / again["one_thread"]["value"])
         assert ratio > 1.2, ratio
     assert torch.get_num_threads() == out["cores"]                      # thread count restored
+
+
+def _fabric_probe():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("clane_fabric_probe", ROOT / "tools" / "fabric_probe.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_fabric_probe_reads_rccl_logs_and_the_link_matrix():
+    """tools/fabric_probe.py's parsers on the line formats RCCL / rocm-smi print (the probe itself needs GPUs): algorithm
+    and protocol per collective and size, channels, ring orders, the graph search's bandwidth, the link-type matrix."""
+    fp = _fabric_probe()
+    log = "\n".join([
+        "host:123:123 [0] NCCL INFO RCCL version 2.22.3+hip7.0 HEAD:abcdef",
+        "host:123:130 [0] NCCL INFO Pattern 4, crossNic 0, nChannels 16, bw 48.000000/48.000000, type XGMI/PIX, sameChannels 1",
+        "host:123:130 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7",
+        "host:123:130 [0] NCCL INFO Channel 01/16 :    0   2   4   6   1   3   5   7",
+        "host:123:130 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer",
+        "host:123:130 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 busId c000 commId 0x1 - Init COMPLETE",
+        "host:123:123 [0] NCCL INFO AllGather: 2147483648 Bytes -> Algo 1 proto 2 time 31234.500000",
+        "host:123:123 [0] NCCL INFO AllGather: 2147483648 Bytes -> Algo 1 proto 2 time 31234.500000",
+        "host:123:123 [0] NCCL INFO AllReduce: 8 Bytes -> Algo 0 proto 0 time 14.200000",
+        "host:123:123 [0] NCCL INFO AllGather: 1048576 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..15}"])
+    got = fp.parse_rccl_log(log)
+    assert got["version"].startswith("RCCL version 2.22.3") and got["init"] == {"nranks": 8}
+    assert got["channels"] == {"coll": 16, "p2p": 16, "p2p_per_peer": 2}
+    assert [r["order"] for r in got["rings"]] == [[0, 1, 2, 3, 4, 5, 6, 7], [0, 2, 4, 6, 1, 3, 5, 7]]
+    assert got["graphs"][0]["nChannels"] == 16 and got["graphs"][0]["bw_intra"] == 48.0 and got["graphs"][0]["type"] == "XGMI/PIX"
+    assert got["tuning"] == [
+        {"collective": "AllGather", "bytes": 2147483648, "algo": "Ring", "proto": "Simple", "model_time_us": 31234.5},
+        {"collective": "AllReduce", "bytes": 8, "algo": "Tree", "proto": "LL", "model_time_us": 14.2},
+        {"collective": "AllGather", "bytes": 1048576, "algo": "Ring", "proto": "Simple", "channels": [0, 15]}]
+    topo = "\n".join([
+        "============================ ROCm System Management Interface ============================",
+        "================================ Weight between two GPUs =================================",
+        "       GPU0         GPU1         ", "GPU0   0            15           ", "GPU1   15           0            ",
+        "================================= Hops between two GPUs ==================================",
+        "       GPU0         GPU1         ", "GPU0   0            1            ", "GPU1   1            0            ",
+        "=============================== Link Type between two GPUs ===============================",
+        "       GPU0         GPU1         ", "GPU0   0            XGMI         ", "GPU1   XGMI         0            ",
+        "======================================= Numa Nodes =======================================",
+        "GPU[0]          : (Topology) Numa Node: 0"])
+    m = fp.parse_showtopo(topo)
+    assert m["weight"] == [["0", "15"], ["15", "0"]] and m["hops"] == [["0", "1"], ["1", "0"]]
+    assert m["link_type"] == [["0", "XGMI"], ["XGMI", "0"]]
+    assert fp.parse_rccl_log("nothing of interest") == {"tuning": [], "channels": None, "rings": [], "graphs": [],
+                                                         "init": None, "version": None}
+
+
+def test_rehearsed_multi_rank_record_explains_itself():
+    """The committed four-rank rehearsal of `bench.py --gpus 4` (gloo, every rank on the box's one GPU: the flow, not
+    a scaling number) carries what the first real 8-GPU record must carry: the wall-time plan with what was spent, the
+    fabric probe (microbench of the literal plan's message, RCCL log = None under gloo, the link matrix), the comm
+    block, north_star's literal division beside the main one."""
+    rec = json.loads((ROOT / "profiles" / "r05_bench_rmat200k_n4_gloo_shared_gpu.json").read_text().strip().splitlines()[-1])
+    assert rec["n_gpus"] == 4 and rec["comm"]["backend"] == "gloo" and rec["comm"]["shared_gpu_rehearsal"]
+    plan = rec["time_plan"]
+    assert plan["worst_case_s"] < plan["driver_limit_s"] and plan["spent_s"]["total_s"] < plan["driver_limit_s"]
+    assert {"fabric_probe_s", "generation_s", "main_division_s"} <= set(plan["spent_s"])
+    probe = rec["comm"]["fabric_probe"]
+    assert "rccl_log" in probe and "topology" in probe and probe["microbench"]["world"] == 4
+    for name in ("all_gather_into_tensor", "send_recv_every_peer", "all_to_all_single", "all_reduce_8_bytes"):
+        assert name in probe["microbench"]
+    assert probe["microbench"]["all_gather_correct"] is True
+    assert rec["north_star_literal"]["exchange"] == "allgather_all"
+    assert rec["north_star_literal"]["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-4
