@@ -32,136 +32,18 @@ import torch
 
 from . import _hip
 from .comm import TorchComm
+from .diagnostics import DiagnosticsMixin
 from .halo import build_halo_layout
 from .partition import Block, HostCSR, LocalCSR, RowPartition, localize
+from .plan import (HEAVY_ROW_EDGES, HUB_FACTOR, INFINITY_CACHE_BYTES, L2_BYTES_ALL_XCDS,            # noqa: F401 (re-exported)
+                   LONG_THRESHOLD_BY_ROWS_PER_WAVE, MIN_HOT_READ_SHARE, MIN_SEGMENT_EDGES, MIN_SLICE_ROW_BYTES,
+                   SOFTMAX_EDGES_PER_WORKGROUP, SPLIT_EDGES, TARGET_SEGMENTS, UNSKEWED_LONG_THRESHOLD, _round_up,
+                   column_slice, hot_read_share, lanes_per_row, pick_exchange)
+from .staging import StagedZ, StagingMixin, place_piece                                                # noqa: F401 (re-exported)
 from .xcd import (CLASS_CHUNK, CLASS_THRESHOLD_BY_ROWS_PER_WAVE, PHASE_THRESHOLD, PHASES_BY_ROWS_PER_WAVE,
                   class_items)
 
-# Rows are binned by out-degree once per graph (profiles/r01_threshold_sweep.md, r02_class_threshold_sweep.md):
-#   deg <= T                 one (sub-)wave per row, rows claimed dynamically inside a workgroup
-#                            (spmm_update_kernel when a row fills a wave, spmm_update_subrow_kernel otherwise)
-#   deg >  class threshold   XCD-affine chunks + fixed-order combine (spmm_class_chunk_kernel; below)
-#   in between               16-wave workgroup per row, 64-aligned slices, idle waves exit at once (spmm_long_kernel);
-#                            rows above SPLIT_EDGES cut into segments -- only without the class pass
-# The thresholds below are those of the row kernels on their own (class pass off):
-# Measured on MI355X: a single wave walking a 65..1024-edge row of 1-KiB rows streams at a fraction of
-# what the multi-wave kernel reaches, so T is small when a row fills a wave (d=256 fp32: T=32); with
-# narrow rows (d=128 bf16: 4 rows per wave-instruction) the sub-wave kernel is the efficient one and a
-# workgroup per 100-edge row is not, so T grows with the rows a wave covers per instruction.  Since every
-# sub-wave claims its own rows the optimum is ~1024 (R-MAT 2M/40M: 2 rows/wave 2.82 ms at T=64 -> 2.58 at 1024;
-# 4 rows/wave 1.40 at 384 -> 1.31 at 1024; the 10M-vertex power-law graph prefers 384..1024 and loses 5-19 % at
-# 2048: a 2000-edge row walked by 8 lanes is the tail of its launch).
-# A 4-wave bin (T < deg <= hub_threshold) exists in the ABI; it did not pay.
-LONG_THRESHOLD_BY_ROWS_PER_WAVE = {1: 32, 2: 1024, 4: 1024, 8: 512}
-HUB_FACTOR = 1
-# Rows above SPLIT_EDGES edges are cut into segments, one 16-wave workgroup each: a 70k-edge hub done by ONE
-# workgroup is a ~0.25 ms tail on every launch.  Segments are 4096 edges (256 per wave) when there are plenty of
-# hub edges, down to 1024 when a rank holds few (8 GPUs: ~30 hub rows per rank would give < 100 workgroups).
-SPLIT_EDGES = 4096
-MIN_SEGMENT_EDGES = 1024
-TARGET_SEGMENTS = 512                   # two workgroups per CU
-# The XCD-affine pass buys L2 hits; it has something to buy only when the gathers are SKEWED -- when the rows the
-# eight 4-MiB L2s can hold between them take a real share of all edge reads (config 3: 61 %, config 4's shape: ~65 %).
-# On a graph whose destinations are spread evenly (a near-regular or uniform random graph: that share is the rows'
-# share of the table, 1.6 % at 2M x 1 KiB) cutting a 70-edge row into 8 class pieces is pure overhead: measured 25.7 ms
-# against 20.7 on a near-regular 2M / 128M graph (profiles/r03_threshold_robustness.md).  Below MIN_HOT_READ_SHARE only
-# rows that need their work spread anyway (above HEAVY_ROW_EDGES: the class pass doubles as the hub splitter, a
-# 2M-edge row scored by ONE workgroup took build_P from 6.6 to 29 ms) take the pass.
-SOFTMAX_EDGES_PER_WORKGROUP = 1 << 17     # build_P: edges of one class row that one workgroup of the rescale pass takes
-L2_BYTES_ALL_XCDS = 8 * 4 * 1024 * 1024
-INFINITY_CACHE_BYTES = 256 * 1024 * 1024
-MIN_HOT_READ_SHARE = 0.2
-HEAVY_ROW_EDGES = 4096
-UNSKEWED_LONG_THRESHOLD = 128
-
-
-def hot_read_share(csr: HostCSR, row_bytes: int) -> float:
-    """Share of all edge reads that go to the rows the eight L2s can hold between them (the most-read rows first) --
-    what XCD affinity can turn into L2 hits at best.  The same number on every rank (global in-degrees)."""
-    V, E = csr.num_vertices, csr.num_edges
-    k = L2_BYTES_ALL_XCDS // max(int(row_bytes), 1)
-    if E == 0 or k >= V:
-        return 1.0
-    indeg = csr.indeg()
-    return float(np.partition(indeg, V - k)[V - k:].sum(dtype=np.int64)) / E
-
-
-def lanes_per_row(d: int, dtype: torch.dtype) -> int:
-    """Lanes that cover one row with 16-byte packs (mirrors pick_layout in csrc/clane_abi.hip)."""
-    packs = -(-d // _hip.VEC_ELEMS[dtype])
-    return 8 if packs <= 8 else 16 if packs <= 16 else 32 if packs <= 32 else 64
-
-
-def _round_up(a: int, b: int) -> int:
-    return -(-a // b) * b
-
-
-MIN_SLICE_ROW_BYTES = 64
-
-
-def pick_exchange(d: int, dtype: torch.dtype, world: int) -> str:
-    """The division ``exchange="auto"`` takes.  Column split while a rank's slice of a row is at least
-    MIN_SLICE_ROW_BYTES (HBM is fetched in 64/128-byte lines: below that every gather drags in bytes of columns the rank
-    does not own -- measured on the 10M-vertex bf16 graph); else divide the rows and exchange halo rows.
-    (A 2-D division -- R row groups x C column groups -- was built and measured in round 4 and removed in round 5: on a
-    fully connected fabric it loses to the halo division, because a column group's row exchange runs over R - 1 of a
-    GPU's 7 links instead of all of them; numbers in profiles/HISTORY.md, profiles/r04_rank_compute_grid_powerlaw10m.jsonl.)"""
-    row_bytes = d * torch.empty(0, dtype=dtype).element_size()
-    return "columns" if row_bytes // max(world, 1) >= MIN_SLICE_ROW_BYTES else "halo"
-
-
-def column_slice(d: int, dtype: torch.dtype, world: int, rank: int):
-    """Columns [c0, c1) of the embedding matrix held by `rank` in a column-split run: contiguous, in whole
-    16-byte packs, as even as the pack count allows (a rank may hold none when d is tiny)."""
-    vec = _hip.VEC_ELEMS[dtype]
-    packs = -(-d // vec)
-    base, rem = divmod(packs, world)
-    p0 = rank * base + min(rank, rem)
-    p1 = p0 + base + (1 if rank < rem else 0)
-    return min(d, p0 * vec), min(d, p1 * vec)
-
-
-class StagedZ:
-    """The embeddings of one moment on their way to the host (``SweepEngine.stage_Z``): the sweeps go on while
-    the copy drains over PCIe; ``result()`` waits for it and returns a fresh ``[V, d]`` CPU tensor in vertex order.
-    On several GPUs (``stage_Z(pieces=True)``) every rank stages only what it holds -- its columns of all rows, or its
-    own rows -- and ``piece()`` returns that part with where it belongs (``place_piece`` puts parts together)."""
-
-    def __init__(self, engine=None, slot=None, ready: Optional[torch.Tensor] = None, where: Optional[dict] = None):
-        self._engine, self._slot, self._ready, self._where = engine, slot, ready, where
-
-    def _resolve(self) -> torch.Tensor:
-        if self._ready is None:
-            eng, slot = self._engine, self._slot
-            slot["done"].synchronize()
-            self._ready = slot["host"][:, :eng.d].clone()
-            eng._release_stage_slot(slot)
-            self._engine = self._slot = None
-        return self._ready
-
-    def result(self) -> torch.Tensor:
-        if self._where is not None:
-            raise RuntimeError("this copy holds one rank's part of the matrix: use piece() / place_piece()")
-        return self._resolve()
-
-    def piece(self) -> dict:
-        """{'kind': 'columns', 'c0', 'c1', 'Z': [V, c1 - c0]} or {'kind': 'rows', 'vertex': int64 [n], 'Z': [n, d]}."""
-        if self._where is None:
-            raise RuntimeError("this copy holds the whole matrix: use result()")
-        return dict(self._where, Z=self._resolve())
-
-
-def place_piece(out: torch.Tensor, piece: dict) -> None:
-    """Write one rank's part (``StagedZ.piece()``) into the full ``[V, d]`` matrix ``out``."""
-    c0, c1 = piece.get("c0", 0), piece.get("c1", out.shape[1])
-    if "vertex" not in piece:                           # every row, some columns
-        out[:, c0:c1] = piece["Z"]
-    else:
-        real = piece["vertex"] >= 0                     # padding rows of an equal-size row division hold no vertex
-        out[piece["vertex"][real], c0:c1] = piece["Z"][real]
-
-
-class SweepEngine:
+class SweepEngine(StagingMixin, DiagnosticsMixin):
     STAGE_SLOTS = 3          # copies of Z that may be in flight to the host at once (stage_Z)
     # Z tables.  Two do for the sweeps (read old / write new).  A third replaces the reference's
     # `prev_Z = graph.Z.clone()` (embedder.py:58): snapshot() PINS the current table instead of copying 2 GB, and the
@@ -691,68 +573,6 @@ class SweepEngine:
                 out[:, c0:c1] = everyone[c][:, :c1 - c0]
         return out.cpu()
 
-    def stage_Z(self, pieces: bool = False) -> StagedZ:
-        """Start copying the current embeddings to the host WITHOUT stalling the sweeps (``--save_history`` at
-        scale): a device-to-device copy (into vertex order) on the sweep stream (the ping-pong buffer is overwritten two
-        sweeps later, long before 2 GB have crossed PCIe), then an asynchronous D2H into pinned memory on a copy
-        stream.  At most STAGE_SLOTS copies are in flight; with none free this call waits for ``result()`` of an
-        earlier one (possibly on another thread).
-        Several GPUs: ``pieces=True`` stages only what THIS rank holds -- its column slice of every row (column
-        split) or its own rows (row splits) -- the same way and with no collective: N PCIe links drain in parallel and
-        whoever wants the whole matrix puts the ranks' pieces together on the host (``StagedZ.piece``,
-        ``place_piece``; ``Embedder`` does, through files).  Without ``pieces`` a multi-GPU run gathers synchronously
-        (``get_Z``: collective), as a host-memory engine does."""
-        if self.world > 1 and not pieces:
-            return StagedZ(ready=self.get_Z())
-        by_rows = self.row_world > 1            # this rank's own rows; else all rows (of its columns)
-        cols = {"c0": self.col0, "c1": self.col1} if self.columns else {}
-        if self.device.type != "cuda":          # host-memory engine (the CPU suite's test double): nothing to overlap
-            if self.world == 1:
-                return StagedZ(ready=self.get_Z())
-            if by_rows:
-                own = torch.cat([self._zrows(self.Zcur, b)[:, :self.d] for b in self.blocks]).clone()
-                return StagedZ(ready=own, where=dict(cols, kind="rows",
-                                                     vertex=torch.from_numpy(self.local.vertex.astype(np.int64))))
-            return StagedZ(ready=self.Zcur[self.pos, :self.d].clone(), where=dict(cols, kind="columns"))
-        n_rows = self.part.n_local if by_rows else self.V
-        with self._stage_cv:
-            if self._stage_free is None:
-                self._stage_free, self._stage_made = [], 0
-                self._copy_stream = torch.cuda.Stream(self.device)
-            while not self._stage_free and self._stage_made >= self.STAGE_SLOTS:
-                self._stage_cv.wait()
-            if self._stage_free:
-                slot = self._stage_free.pop()
-            else:
-                self._stage_made += 1
-                slot = {"dev": torch.empty(n_rows, self.ld, dtype=self.dtype, device=self.device),
-                        "host": torch.empty(n_rows, self.ld, dtype=self.dtype, pin_memory=True),
-                        "done": torch.cuda.Event()}
-        main = torch.cuda.current_stream(self.device)
-        where = None
-        if by_rows:                                             # own rows, block by block (local row order)
-            for b in self.blocks:
-                slot["dev"][self._rows(b)].copy_(self._zrows(self.Zcur, b))
-            if self._own_vertex is None:
-                self._own_vertex = torch.from_numpy(self.local.vertex.astype(np.int64))
-            where = dict(cols, kind="rows", vertex=self._own_vertex)
-        else:
-            torch.index_select(self.Zcur, 0, self.pos, out=slot["dev"])     # vertex order, on the sweep stream
-            if self.world > 1:
-                where = dict(cols, kind="columns")
-        copied = torch.cuda.Event()
-        copied.record(main)
-        self._copy_stream.wait_event(copied)
-        with torch.cuda.stream(self._copy_stream):
-            slot["host"].copy_(slot["dev"], non_blocking=True)
-            slot["done"].record(self._copy_stream)
-        return StagedZ(self, slot, where=where)
-
-    def _release_stage_slot(self, slot) -> None:
-        with self._stage_cv:
-            self._stage_free.append(slot)
-            self._stage_cv.notify()
-
     def _sync_quiet_rows(self) -> None:
         """Quiet rows (no out-edges, or never read) are not exchanged during sweeps; bring the other
         ranks' copies up to date before the matrix leaves the engine."""
@@ -1010,87 +830,6 @@ class SweepEngine:
         overwrites; rows without out-edges were not touched by it either.  (One launch can be taken back, not two.)"""
         self.cur = self._prev_cur
         self.sweeps_done -= 1
-
-    def kernel_times_ms(self):
-        """{'split','hub','mid','main'} -> ms per SWEEP (summed over the blocks, averaged over the recorded
-        sweeps); call after a synchronize.  Event order per block: 0 start, 4 after split, 1 after hub, 2 after mid,
-        3 after main."""
-        t = np.array([(e0.elapsed_time(e4), e4.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3))
-                      for _, e0, e1, e2, e3, e4 in self.kernel_events]).reshape(-1, 4)
-        self.kernel_events = []
-        if not len(t):
-            return {}
-        per_sweep = t.reshape(-1, len(self.blocks), 4).sum(1).mean(0)
-        return dict(zip(("split", "hub", "mid", "main"), per_sweep.tolist()))
-
-    def collective_times_ms(self):
-        """{'exchange_exposed', 'allreduce'} -> ms per sweep seen from the sweep's stream (averaged over the recorded
-        sweeps; call after a synchronize): how long it waited for the row exchange after its own kernels were done, and
-        for the all-reduce of the delta.  Empty when nothing was recorded (one GPU, or time_collectives off)."""
-        ev, self.collective_events = self.collective_events, []
-        if not ev:
-            return {}
-        t = np.array([(a.elapsed_time(b), b.elapsed_time(c)) for a, b, c in ev])
-        return {"exchange_exposed": float(t[:, 0].mean()), "allreduce": float(t[:, 1].mean()), "sweeps_timed": len(ev)}
-
-    def kernel_bytes(self):
-        """Algorithmic bytes per SWEEP of each K3 kernel (SURVEY.md section 8d gather model, split by the
-        rows each kernel owns): per row  deg*(d*s + 4 + sizeof P) + 3*d*s + 8;  rows without out-edges: 8."""
-        s, ps = self.Zcur.element_size(), self.P.element_size()
-        deg = np.diff(self.local.rowptr)
-        per_row = deg * (self.d * s + 4 + ps) + np.where(deg > 0, 3 * self.d * s, 0) + 8   # sinks: rowptr only
-        is_long = deg > self.long_threshold if self.long_threshold > 0 else np.zeros_like(deg, dtype=bool)
-        is_class = deg > self.class_threshold if self.class_threshold > 0 else np.zeros_like(deg, dtype=bool)
-        is_long = is_long | is_class
-        is_split = (is_long & (deg > self.split_edges) if self.split_edges > 0 else np.zeros_like(is_long)) & ~is_class
-        is_hub = is_long & (deg > self.hub_threshold) & ~is_split & ~is_class
-        return {"main": int(per_row[~is_long].sum()) + 8,
-                "mid": int(per_row[is_long & ~is_hub & ~is_split & ~is_class].sum()),
-                "hub": int(per_row[is_hub].sum()), "split": int(per_row[is_split | is_class].sum())}
-
-    def kernel_names(self):
-        """Names of the K3 kernels behind the keys of kernel_times_ms() / kernel_bytes()."""
-        narrow = self.d > 0 and lanes_per_row(self.d, self.dtype) < 64
-        return {"main": "spmm_update_subrow_kernel" if narrow else "spmm_update_kernel",
-                "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>",
-                "split": "spmm_class_chunk_kernel+combine" if self.class_threshold > 0
-                else "spmm_split_segment_kernel+combine"}
-
-    def estimated_sweep_seconds(self) -> float:
-        """Rough time of one sweep on this division, the SAME number on every rank (it feeds decisions all ranks
-        must take alike, e.g. whether the host check lags one sweep): the whole graph's gather-model bytes / ranks
-        at the HBM peak."""
-        s = self.Zcur.element_size()
-        d = self.d_full
-        total = self.E_total * (d * s + 8) + self.V * 3 * d * s
-        return total / max(self.world, 1) / 8e12
-
-    def kernel_config(self) -> dict:
-        """Everything that decides which K3 kernels a sweep launches over which rows, and with which compile-time
-        tuning: measurements of a kernel (profiles/traffic.json) are only valid for the configuration they were
-        taken with, and bench.py refuses to quote them for another."""
-        return {"build": self.k.build_info(), "dtype": str(self.dtype).replace("torch.", ""), "d": self.d,
-                "lanes_per_row": lanes_per_row(self.d, self.dtype) if self.d > 0 else 0,
-                "rows": int(self.part.n_local), "edges": int(self.E_loc), "launch_blocks": len(self.blocks),
-                "long_threshold": self.long_threshold, "score_threshold": self.score_threshold,
-                "hub_threshold": self.hub_threshold,
-                "split_edges": self.split_edges, "segment_edges": self.segment_edges,
-                "class_threshold": self.class_threshold, "class_chunk": self.class_chunk, "class_k1": self.class_k1,
-                "class_phases": self.class_phases, "phase_threshold": self.phase_threshold,
-                "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
-                "class_affinity": self.class_affinity, "mega_segment_edges": self.mega_segment_edges,
-                "class_items_per_block": [c[6] for c in self.class_rows if c is not None][:1],
-                "hot_rows_first": self.hot_rows_first, "exchange": self.exchange,
-                }
-
-    def exchange_bytes_per_sweep(self) -> int:
-        """Bytes this rank RECEIVES per sweep (all-gather of the live spans)."""
-        s = self.Zcur.element_size()
-        if self.halo:
-            return self.part.recv_rows_per_sweep() * self.ld * s
-        if self.columns:
-            return 0
-        return sum((b.span[1] - b.span[0] - b.nrows) * self.ld * s for b in self.blocks if b.span is not None)
 
     # ---- outer-loop delta (embedder.py:58-60) -------------------------------------------
     def snapshot(self) -> None:
