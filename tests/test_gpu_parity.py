@@ -341,6 +341,30 @@ def test_class_pass_random_engines(dev, case):
         del eng
 
 
+def test_set_cosine_mode_switches_the_scores_of_a_live_engine(dev):
+    """SweepEngine.set_cosine_mode (bench.py's non-degenerate full-size check of K1 uses it): the same engine scores in
+    per-edge mode, then in reference mode again -- each time the P of a fresh engine of that mode, bit for bit, and the
+    oracle's (similarity.py:35-37 vs the cosine its docstring describes); sweeps refuse to run on a P of the other mode."""
+    csr = synth.rmat_csr(30_000, 600_000, seed=3)
+    X = synth.gaussian_X(30_000, 64, seed=4)
+    eng = SweepEngine(csr, X, dev)
+    eng.build_P()
+    P_ref = eng.P.clone()
+    eng.set_cosine_mode("per_edge")
+    with pytest.raises(RuntimeError, match="before build_P"):
+        eng.sweep(0.5)
+    eng.build_P()
+    fresh = SweepEngine(csr, X, dev, cosine_mode="per_edge")
+    fresh.build_P()
+    assert torch.equal(eng.P, fresh.P) and not torch.equal(eng.P, P_ref)
+    assert rel(eng.P_global(), O.build_P_values(csr.rowptr, csr.colidx, X, mode="per_edge")) < 5e-6
+    eng.set_cosine_mode("reference")
+    eng.build_P()
+    assert torch.equal(eng.P, P_ref)
+    with pytest.raises(ValueError, match="cosine_mode"):
+        eng.set_cosine_mode("cosine")
+
+
 def assert_norms_are_k0s(eng, tag=""):
     """The squared row norms the outer-delta pass leaves behind (SweepEngine.sq_pp) are BIT FOR BIT what
     row_sqnorm_kernel (K0) computes from the same table -- for every owned row, sinks included."""
