@@ -112,6 +112,7 @@ def traffic_entry(workload: str, world: int, eng, dom: str, slice_of=None):
     then = entry.get("kernel_config")
     if then is None:
         return None, f"{key}: measured before kernel configurations were recorded -- treated as stale"
+    then = dict({"column_tiles": 1}, **then)        # entries from before column tiles existed: one tile
     diff = sorted(k for k in set(live) | set(then) if live.get(k) != then.get(k) and k != "exchange")
     if diff:
         return None, f"{key}: stale, measured with another kernel configuration (differs in {', '.join(diff)})"
@@ -137,6 +138,8 @@ def make_parser():
     ap.add_argument("--class-threshold", type=int, default=None,
                     help="rows above this many edges take the XCD-affine pass (0 = off; default: by row width)")
     ap.add_argument("--class-chunk", type=int, default=256)
+    ap.add_argument("--column-tiles", type=int, default=None,
+                    help="one GPU: a sweep as T passes over T column ranges of the tables (default: the engine's rule)")
     ap.add_argument("--no-split-hubs", action="store_true", help="hub rows by one workgroup each (no segment split)")
     ap.add_argument("--natural-order", action="store_true", help="keep vertex order (default: hot rows first)")
     ap.add_argument("--exchange", default="auto",
@@ -360,7 +363,7 @@ def measure_division(args, ranks: Ranks, csr, X, exchange: str, time_kernels: bo
     eng = SweepEngine(csr, X, dev, process_group=ranks.pg, comm=comm, chunks=args.chunks,
                       long_threshold=args.long_threshold, hub_threshold=args.hub_threshold, exchange=exchange,
                       hot_rows_first=not args.natural_order, split_hubs=not args.no_split_hubs,
-                      class_threshold=args.class_threshold, class_chunk=args.class_chunk)
+                      class_threshold=args.class_threshold, class_chunk=args.class_chunk, column_tiles=args.column_tiles)
     torch.cuda.synchronize()
     log(f"engine up in {time.perf_counter() - t0:.1f}s ({eng.exchange}); rank rows={eng.part.n_local} edges={eng.E_loc} "
         f"rows/kernel: mid(4 waves)={sum(0 if l is None else l.numel() for l in eng.mid_rows)} "
@@ -461,7 +464,9 @@ def describe_parallelism(args, world, eng, X, E) -> str:
         return (f"REHEARSAL on 1 GPU of one rank of the column split x{args.column_slice_of}: columns "
                 f"[0:{X.shape[1]}) of X and Z, whole graph; not a headline number")
     if world == 1 and eng.exchange == "none":
-        return f"1 GPU, {chunks} launch block(s)/sweep"
+        tiles = (f", {len(eng.tiles)} column tiles per sweep ({', '.join(f'[{a}:{b})' for a, b in eng.tiles)}: the update "
+                 f"is independent per column, embedder.py:92)") if len(eng.tiles) > 1 else ""
+        return f"1 GPU, {chunks} launch block(s)/sweep{tiles}"
     if eng.columns:
         return (f"column split x{world}: every GPU holds the whole graph and columns [{eng.col0}:{eng.col1}) "
                 f"(rank 0) of X and Z; no exchange per sweep, one scalar all-reduce (RCCL); build_P all-reduces "
@@ -478,7 +483,7 @@ def roofline_block(args, world, m) -> dict:
     bytes per sweep / chunks (SURVEY.md section 8d gather model).  The fraction is quoted from the SMALLER of
     (algorithmic, measured) bytes and never above the roof, so that cache hits cannot inflate it."""
     eng, ktimes = m["eng"], m["ktimes"]
-    chunks = len(eng.blocks)          # launches of each kernel per sweep
+    chunks = eng.launches_per_sweep()     # launches of each kernel per sweep (launch blocks x column tiles)
     kbytes = eng.kernel_bytes()
     per_kernel = {}
     names = eng.kernel_names()

@@ -47,9 +47,13 @@ class DiagnosticsMixin:
                 "mid": int(per_row[is_long & ~is_hub & ~is_split & ~is_class].sum()),
                 "hub": int(per_row[is_hub].sum()), "split": int(per_row[is_split | is_class].sum())}
 
+    def launches_per_sweep(self) -> int:
+        """Launches of each K3 kernel per sweep: one per launch block and column tile."""
+        return len(self.blocks) * len(self.tiles)
+
     def kernel_names(self):
         """Names of the K3 kernels behind the keys of kernel_times_ms() / kernel_bytes()."""
-        narrow = self.d > 0 and lanes_per_row(self.d, self.dtype) < 64
+        narrow = self.d > 0 and lanes_per_row(self.d_plan if len(self.tiles) > 1 else self.d, self.dtype) < 64
         return {"main": "spmm_update_subrow_kernel" if narrow else "spmm_update_kernel",
                 "mid": "spmm_long_kernel<4 waves>", "hub": "spmm_long_kernel<16 waves>",
                 "split": "spmm_class_chunk_kernel+combine" if self.class_threshold > 0
@@ -79,6 +83,7 @@ class DiagnosticsMixin:
                 "class_of_row": "xor-fold of 3-bit groups" if self.class_threshold else None,
                 "class_affinity": self.class_affinity, "mega_segment_edges": self.mega_segment_edges,
                 "class_items_per_block": [c[6] for c in self.class_rows if c is not None][:1],
+                "column_tiles": len(self.tiles),
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange,
                 }
 

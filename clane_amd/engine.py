@@ -64,7 +64,7 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
                  overlap_chunks: bool = True, fused_pack: bool = True, class_threshold: Optional[int] = None,
                  class_chunk: int = CLASS_CHUNK, class_k1: bool = True, class_phases: Optional[int] = None,
                  phase_threshold: int = PHASE_THRESHOLD, delta_stream: bool = False, table_skew=None,
-                 table_alloc: str = "torch"):
+                 table_alloc: str = "torch", column_tiles: Optional[int] = None):
         """``exchange`` (N > 1 only) -- how the sweep is divided over the GPUs:
         "auto" (default) -- "columns" while a rank's slice of a row is >= 64 bytes, else "halo" (pick_exchange).
         "columns" -- every GPU holds the whole graph and d/N COLUMNS of X and Z.  ``Z[:, c] = X[:, c] + gamma P Z[:, c]``
@@ -92,6 +92,7 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
         if table_alloc not in ("torch", "contiguous"):
             raise ValueError("table_alloc must be 'torch' or 'contiguous'")
         self.table_alloc, self._own_tables, self.table_alloc_note = table_alloc, [], None
+        self._column_tiles_asked = column_tiles
         X = self._choose_division(csr, X, process_group, comm, exchange)
         self._choose_class_pass(csr, class_threshold, class_chunk, class_k1, class_phases, phase_threshold)
         self._build_layout(csr, chunks, shuffle, seed, hot_rows_first)
@@ -148,9 +149,38 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
         if self.columns:
             c0, c1 = column_slice(self.d_full, X.dtype, self.C, 0)
             self.d_plan = c1 - c0
+        # COLUMN TILES (one GPU): a sweep as T passes over T column ranges of the same tables -- the update is independent
+        # per column (embedder.py:92: P mixes rows, never columns), and with rows of T-th the width the L2s and the
+        # Infinity Cache hold T times as many of the hot rows per pass; colidx / P are read T times.  See `_pick_tiles`.
+        T = self._pick_tiles(csr, X.dtype) if not divided else 1
+        cuts = [column_slice(self.d, X.dtype, T, t) for t in range(T)] if self.d > 0 else [(0, 0)]
+        self.tiles = [c for c in cuts if c[1] > c[0]] or [(0, self.d)]
+        if len(self.tiles) > 1:
+            self.d_plan = max(c1 - c0 for c0, c1 in self.tiles)
         self.ld_plan = _round_up(self.d_plan, _hip.VEC_ELEMS[X.dtype])
         self.rows_per_wave = 64 // lanes_per_row(self.d_plan, X.dtype) if self.d_plan > 0 else 1
         return X
+
+    def _pick_tiles(self, csr: HostCSR, dtype: torch.dtype) -> int:
+        """Column tiles of a one-GPU sweep (``column_tiles``; None = the rule below).  Measured, sweep ms with 1 / 2
+        tiles (profiles/r05_column_tiles_ab.md): config 3 (1-KiB rows, skewed reads, 2 GB table) 3.93 -> 3.79 (4 tiles:
+        4.08; build_P, which keeps the full width on the tiles' layout, 3.70 -> 3.85); the 16M-vertex run 38.6 -> 38.1;
+        uniform-random pairs 7.45 -> 7.63 (nothing to keep in a cache: colidx / P read twice for nothing); 512-byte rows
+        lose (cache-resident config 2: 0.187 -> 0.211; config 4's bf16 rows: 7.04 -> 8.08).  Hence: two tiles when a
+        row fills a wave (>= 1 KiB), the reads are skewed and the table is well beyond the Infinity Cache."""
+        asked = self._column_tiles_asked
+        if asked is not None:
+            if asked < 1:
+                raise ValueError("column_tiles must be >= 1")
+            return int(asked)
+        es = torch.empty(0, dtype=dtype).element_size()
+        row_bytes = self.ld * es
+        if self.d <= 0 or lanes_per_row(self.d, dtype) < 64 or row_bytes < 1024:
+            return 1
+        if csr.num_vertices * row_bytes <= 2 * INFINITY_CACHE_BYTES:
+            return 1
+        half = _round_up(-(-self.d // 2), _hip.VEC_ELEMS[dtype]) * es           # skewed at the tile's row width?
+        return 2 if hot_read_share(csr, half) >= MIN_HOT_READ_SHARE else 1
 
     def _choose_class_pass(self, csr: HostCSR, class_threshold, class_chunk, class_k1, class_phases,
                            phase_threshold) -> None:
@@ -322,11 +352,12 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
             else:
                 self.split_rows.append(None)
             self.partial_off.append(self.partial_off[-1] + self.k.spmm_partials_len(b.nrows, int(is_long.sum())))
-        self.partials = torch.zeros(self.partial_off[-1], dtype=torch.float64, device=dev)
+        # one set of fixed-order delta partials per column tile, summed together by the sweep's final reduction
+        self.partials = torch.zeros(self.partial_off[-1] * len(self.tiles), dtype=torch.float64, device=dev)
         # segment sums of the split hub rows: one slab per launch stream (blocks on a stream run in order)
-        slab_len = max(1, self.k.spmm_split_slab_len(max_segments, max(self.d, 1)))
+        slab_len = max(1, self.k.spmm_split_slab_len(max_segments, max(self.d_plan, 1)))
         if max_slots:
-            slab_len = max(slab_len, self.k.spmm_class_slab_len(max_slots, self.d), 2 * max_slots)   # K1: 2 stats per slot
+            slab_len = max(slab_len, self.k.spmm_class_slab_len(max_slots, max(self.d_plan, 1)), 2 * max_slots)   # K1: 2 stats per slot
         # one slab per launch stream: blocks alternate between two side streams when there are several
         self.slabs = [torch.zeros(slab_len, dtype=self.acc_dtype, device=dev)
                       for _ in range(2 if len(self.blocks) > 1 else 1)]
@@ -689,28 +720,43 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
                 if self.d == 0:              # column-split rank without columns: nothing to launch, delta stays 0
                     per_block.append(steps + [("event", i, e) for e in (4, 1, 2, 3)])
                     continue
-                if self.class_rows[i] is not None:
-                    rows_c, slot_ptr, it_e0, it_len, it_slot, _, ipb = self.class_rows[i]
-                    steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
-                                                     ipb, rows_c, slot_ptr, b.row0, Zold, Xb, gamma,
-                                                     Zn, self.d, self.slabs[i % len(self.slabs)], self.partials[po_class:], mirror=mir)))
-                if self.split_rows[i] is not None:
-                    rows_s, seg_ptr, seg_row = self.split_rows[i]
-                    steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
-                                                     seg_row, self.segment_edges, b.row0, Zold, Xb, gamma, Zn, self.d,
-                                                     self.slabs[i % len(self.slabs)], self.partials[po_split:], mirror=mir)))
+                # one launch per kernel and COLUMN TILE (one tile unless column_tiles > 1): views of the same tables
+                T = len(self.tiles)
+                cut = (lambda M, t: M) if T == 1 else (lambda M, t: M[:, self.tiles[t][0]:self.tiles[t][1]])
+                width = (lambda t: self.d) if T == 1 else (lambda t: self.tiles[t][1] - self.tiles[t][0])
+                part = lambda off, t: self.partials[t * self.partial_off[-1] + off:]      # noqa: E731
+                if mir is not None and T > 1:
+                    raise AssertionError("column tiles and mirrored launches do not combine")
+                for t in range(T):
+                    if self.class_rows[i] is not None:
+                        rows_c, slot_ptr, it_e0, it_len, it_slot, _, ipb = self.class_rows[i]
+                        steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
+                                                         ipb, rows_c, slot_ptr, b.row0, cut(Zold, t), cut(Xb, t), gamma,
+                                                         cut(Zn, t), width(t), self.slabs[i % len(self.slabs)],
+                                                         part(po_class, t), mirror=mir)))
+                    if self.split_rows[i] is not None:
+                        rows_s, seg_ptr, seg_row = self.split_rows[i]
+                        steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
+                                                         seg_row, self.segment_edges, b.row0, cut(Zold, t), cut(Xb, t), gamma,
+                                                         cut(Zn, t), width(t), self.slabs[i % len(self.slabs)],
+                                                         part(po_split, t), mirror=mir)))
                 steps.append(("event", i, 4))
-                if self.hub_rows[i] is not None:
-                    steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
-                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_hub:], mirror=mir)))
+                for t in range(T):
+                    if self.hub_rows[i] is not None:
+                        steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.hub_rows[i], 16,
+                                                         b.row0, cut(Zold, t), cut(Xb, t), gamma, cut(Zn, t), width(t),
+                                                         part(po_hub, t), mirror=mir)))
                 steps.append(("event", i, 1))
-                if self.mid_rows[i] is not None:
-                    steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.mid_rows[i], 4,
-                                                     b.row0, Zold, Xb, gamma, Zn, self.d, self.partials[po_mid:], mirror=mir)))
+                for t in range(T):
+                    if self.mid_rows[i] is not None:
+                        steps.append(("call", self._bind("spmm_update_long", rp, self.colidx, self.P, self.mid_rows[i], 4,
+                                                         b.row0, cut(Zold, t), cut(Xb, t), gamma, cut(Zn, t), width(t),
+                                                         part(po_mid, t), mirror=mir)))
                 steps.append(("event", i, 2))
-                steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, Zold, Xb,
-                                                 gamma, Zn, self.d, self.long_threshold, self.partials[po:],
-                                                 sinks_untouched=True, mirror=mir)))
+                for t in range(T):
+                    steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, cut(Zold, t),
+                                                     cut(Xb, t), gamma, cut(Zn, t), width(t), self.long_threshold,
+                                                     part(po, t), sinks_untouched=True, mirror=mir)))
                 steps.append(("event", i, 3))
                 if b.span is not None:
                     steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))

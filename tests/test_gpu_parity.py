@@ -341,6 +341,42 @@ def test_class_pass_random_engines(dev, case):
         del eng
 
 
+@pytest.mark.parametrize("dtype,d,tiles", [(torch.float32, 256, 2), (torch.float32, 100, 3), (torch.float64, 64, 2),
+                                           (torch.bfloat16, 512, 2), (torch.float32, 1433, 4)])
+def test_column_tiles_on_the_gpu(dev, dtype, d, tiles):
+    """SweepEngine(column_tiles=T) with the real kernels: the same tables swept as T column ranges (strided views: rows of
+    T-th the width, embedder.py:92 column by column) == the oracle and the untiled engine up to summation order; bitwise
+    repeatable; build_P, snapshot / outer delta and get_Z see whole rows."""
+    csr = ragged_csr(6000, seed=21, max_deg=40, hubs=(5000, 900, 300, 129, 65, 64, 33))
+    X = synth.gaussian_X(6000, d, seed=5).to(dtype)
+    acc = _hip.acc_dtype(dtype)
+    kw = dict(class_threshold=32, class_chunk=64)
+    plain = SweepEngine(csr, X, dev, column_tiles=1, **kw)
+    tiled = SweepEngine(csr, X, dev, column_tiles=tiles, **kw)
+    again = SweepEngine(csr, X, dev, column_tiles=tiles, **kw)
+    assert len(tiled.tiles) == tiles and tiled.tiles[0][0] == 0 and tiled.tiles[-1][1] == d
+    assert all(a[1] == b[0] for a, b in zip(tiled.tiles, tiled.tiles[1:]))
+    for eng in (plain, tiled, again):
+        eng.build_P()
+    P_or = O.build_P_values(csr.rowptr, csr.colidx, X.to(acc).double())
+    assert rel(tiled.P_global(), P_or) < (1e-12 if dtype == torch.float64 else 2e-5 if dtype == torch.bfloat16 else 5e-6)
+    Z = X.to(acc).double()
+    P_used = tiled.P_global().double()
+    tiled.snapshot()
+    for sweep in range(3):
+        dt, dp, da = tiled.sweep(0.7), plain.sweep(0.7), again.sweep(0.7)
+        assert dt == da and torch.equal(tiled.Zcur, again.Zcur)                 # bitwise repeatable
+        Zn, d_or = O.sweep(csr.rowptr, csr.colidx, P_used, X.to(acc).double(), Z, 0.7)
+        got = tiled.get_Z().double()
+        assert rel(got, Zn) < TOL[dtype] and rel(got, plain.get_Z().double()) < TOL[dtype]
+        assert dt == pytest.approx(float((got - Z).abs().sum()), rel=1e-5 if dtype != torch.bfloat16 else 2e-2)
+        assert dt == pytest.approx(dp, rel=1e-5 if dtype != torch.bfloat16 else 2e-2)
+        Z = got
+    moved = tiled.distance_from_snapshot()
+    assert moved == pytest.approx(float((Z - X.to(acc).double()).abs().sum()), rel=1e-5 if dtype != torch.bfloat16 else 2e-2)
+    assert_norms_are_k0s(tiled, "tiled engine, after the outer-delta pass")
+
+
 def test_set_cosine_mode_switches_the_scores_of_a_live_engine(dev):
     """SweepEngine.set_cosine_mode (bench.py's non-degenerate full-size check of K1 uses it): the same engine scores in
     per-edge mode, then in reference mode again -- each time the P of a fresh engine of that mode, bit for bit, and the

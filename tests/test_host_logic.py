@@ -963,3 +963,61 @@ def test_host_csr_validate():
     with pytest.raises(ValueError, match="colidx holds entries outside"):
         SweepEngine(HostCSR(3, np.array([0, 2, 2, 3], dtype=np.int64), np.array([1, 7, 0], dtype=np.int32)),
                     torch.zeros(3, 4), "cpu", kernels=object())
+
+
+def test_column_tiles_of_a_one_gpu_sweep(tmp_path, monkeypatch):
+    """SweepEngine(column_tiles=T): a sweep as T passes over T column ranges of the same tables (embedder.py:92 is
+    independent per column) -- same embeddings, deltas and Embedder decisions as the plain sweep for even and ragged
+    widths, with class rows; the default picks two tiles only where it was measured to win (rows that fill a wave,
+    skewed reads, a table well beyond the Infinity Cache: profiles/r05_column_tiles_ab.md)."""
+    from clane_amd import engine as E
+    gold = load_golden("g5_symkarate_d16_g0.76.npz")
+    k = load_golden("g2_karate_csr.npz")
+    src, dst = (gold["edge_src"], gold["edge_dst"]) if "edge_src" in gold.files else (k["edge_src"], k["edge_dst"])
+    vids = gold["vertex_ids"] if "vertex_ids" in gold.files else k["vertex_ids"]
+    root = write_data_root(tmp_path / "g", vids, src, dst, gold["X"])
+    for T in (2, 3):
+        g = Graph(root)
+        eng = SweepEngine(g.csr, g.X, "cpu", OracleKernels(), column_tiles=T, class_threshold=4, class_chunk=64)
+        g._attach_engine(eng)
+        assert len(eng.tiles) == T and eng.kernel_config()["column_tiles"] == T     # d = 16: four packs (2 + 2, 2 + 1 + 1)
+        assert eng.launches_per_sweep() == len(eng.blocks) * len(eng.tiles)
+        emb = Embedder(g, CosineSimilarity(), torch.device("cpu"), gamma=float(gold["gamma"]),
+                       tolerence=int(gold["tolerence"]), verbose=False)
+        emb.iterate()
+        assert O.rel_l2(g.Z, torch.from_numpy(gold["Z_final"])) < 1e-6
+    # ragged width, three tiles of 4 / 3 / 3 packs, deltas sweep by sweep
+    rng = np.random.default_rng(5)
+    V, d = 400, 40
+    deg = rng.integers(0, 30, size=V)
+    rowptr = np.zeros(V + 1, dtype=np.int64)
+    np.cumsum(deg, out=rowptr[1:])
+    cols = np.concatenate([np.sort(rng.choice(V, size=n, replace=False)) for n in deg]).astype(np.int32)
+    csr = HostCSR(V, rowptr, cols)
+    X = torch.from_numpy(rng.standard_normal((V, d)).astype(np.float32))
+    one = SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=1, class_threshold=8, class_chunk=64)
+    three = SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=3, class_threshold=8, class_chunk=64)
+    assert three.tiles == [(0, 16), (16, 28), (28, 40)] and one.tiles == [(0, 40)]
+    for eng in (one, three):
+        eng.build_P()
+    for _ in range(3):
+        a, b = one.sweep(0.8), three.sweep(0.8)
+        assert b == pytest.approx(a, rel=1e-6) and O.rel_l2(three.get_Z(), one.get_Z()) < 1e-6
+    with pytest.raises(ValueError, match="column_tiles"):
+        SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=0)
+    # the default: only where it pays (cache sizes scaled down 32x so that a 40 MB table stands in for a 1.3 GB one)
+    from clane_amd import plan
+    monkeypatch.setattr(E, "INFINITY_CACHE_BYTES", plan.INFINITY_CACHE_BYTES // 32)
+    monkeypatch.setattr(plan, "L2_BYTES_ALL_XCDS", plan.L2_BYTES_ALL_XCDS // 32)
+    V, E_ = 40_000, 640_000                      # 1-KiB rows; 16 edges a row
+    rowptr = np.arange(0, E_ + 1, 16, dtype=np.int64)
+    skewed = HostCSR(V, rowptr, rng.integers(0, 500, size=E_).astype(np.int32))
+    even = HostCSR(V, rowptr, rng.integers(0, V, size=E_).astype(np.int32))
+    Xz = torch.zeros(V, 256)
+    assert len(SweepEngine(skewed, Xz, "cpu", OracleKernels()).tiles) == 2
+    assert len(SweepEngine(even, Xz, "cpu", OracleKernels()).tiles) == 1                    # nothing to keep in a cache
+    assert len(SweepEngine(skewed, Xz, "cpu", OracleKernels(), column_tiles=1).tiles) == 1  # obeyed
+    assert len(SweepEngine(skewed, Xz[:, :128].contiguous(), "cpu", OracleKernels()).tiles) == 1   # 512-byte rows lose
+    small = HostCSR(10_000, rowptr[:10_001], skewed.colidx[:160_000])
+    assert len(SweepEngine(small, Xz[:10_000], "cpu", OracleKernels()).tiles) == 1            # fits the (scaled) Infinity Cache
+    assert E.MIN_HOT_READ_SHARE == 0.2
