@@ -112,7 +112,7 @@ def traffic_entry(workload: str, world: int, eng, dom: str, slice_of=None):
     then = entry.get("kernel_config")
     if then is None:
         return None, f"{key}: measured before kernel configurations were recorded -- treated as stale"
-    then = dict({"column_tiles": 1}, **then)        # entries from before column tiles existed: one tile
+    then, live = dict({"column_tiles": 1}, **then), dict({"column_tiles": 1}, **live)   # before tiles existed: one tile
     diff = sorted(k for k in set(live) | set(then) if live.get(k) != then.get(k) and k != "exchange")
     if diff:
         return None, f"{key}: stale, measured with another kernel configuration (differs in {', '.join(diff)})"
