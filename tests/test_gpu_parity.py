@@ -1182,7 +1182,7 @@ def test_bench_two_processes_on_one_gpu_match_one_process(tmp_path):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    common = ["--workload", "tiny", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    common = ["--workload", "tiny", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-fabric-probe"]
     one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"] + common, capture_output=True,
                          text=True, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -1256,7 +1256,7 @@ def test_bench_north_star_row_partition_two_processes(tmp_path):
     two = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
                           "--exchange", "allgather_all", "--also-exchange", "allgather", "--workload", "tiny", "--steps", "4",
                           "--warmup", "2", "--blocks", "2", "--no-cpu-baseline", "--host-sync", "every-sweep",
-                          "--no-delta-stream-ab"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+                          "--no-delta-stream-ab", "--no-fabric-probe"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert two.returncode == 0, two.stderr[-2000:]
     r2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
     assert "exchange=allgather_all over RCCL per chunk" in r2["config"]["parallelism"] and r2["n_gpus"] == 2
@@ -1282,7 +1282,7 @@ def test_bench_halo_p2p_two_processes_share_tables_through_ipc(tmp_path):
     # one timed block: the delta shrinks by gamma per sweep while Z does not, so after 5 x 6 more sweeps the two
     # divisions' different summation orders show in its 5th digit (seen: 1.37668 vs 1.37669 after 33 sweeps)
     common = ["--workload", "tiny", "--steps", "6", "--warmup", "2", "--blocks", "1", "--no-cpu-baseline",
-              "--also-exchange", "none", "--no-delta-stream-ab"]          # hipIpc is the point: no further divisions
+              "--also-exchange", "none", "--no-delta-stream-ab", "--no-fabric-probe"]   # hipIpc is the point: no further divisions
     one = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1"] + common, capture_output=True,
                          text=True, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]

@@ -647,6 +647,10 @@ def test_bench_four_ranks_share_one_gpu_with_an_idle_column_rank():
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r["n_gpus"] == 4 and r["blocks"] == 3 and "column split x4" in r["config"]["parallelism"]
+    probe = r["comm"]["fabric_probe"]               # four child processes measured the literal plan's message first
+    assert probe["microbench"]["world"] == 4 and probe["microbench"]["all_gather_correct"] and probe["rccl_log"] is None
+    assert "all_gather_vs_direct_exchange" in probe and "matrices" in probe["topology"]
+    assert r["time_plan"]["worst_case_s"] < r["time_plan"]["driver_limit_s"] and "total_s" in r["time_plan"]["spent_s"]
     assert r["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and r["parity_P_rel_l2_vs_oracle"] < 2e-6
     comm = r["comm"]
     assert comm["ranks_seen"] == 4 and len(comm["devices"]) == 4 and len(comm["ms_per_step_by_rank"]) == 4
@@ -713,7 +717,7 @@ def test_bench_main_record_survives_a_stuck_literal_block():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["CLANE_BENCH_LITERAL_DEADLINE_S"] = "0.001"
     run = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-                          "--workload", "tiny", "--steps", "3", "--warmup", "1", "--blocks", "2"],
+                          "--workload", "tiny", "--steps", "3", "--warmup", "1", "--blocks", "2", "--no-fabric-probe"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert run.returncode != 0, run.stderr[-3000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
@@ -750,6 +754,9 @@ def test_bench_n_gpu_flow_through_real_rccl_with_one_rank():
     assert "rehearsal" in r and r["n_gpus"] == 1 and "cpu_baseline" not in r
     comm = r["comm"]
     assert comm["backend"] == "nccl" and comm["ranks_seen"] == 1 and comm["exchange"] == "columns"
+    probe = comm["fabric_probe"]                    # RCCL's own log of the probe's one-rank group, parsed
+    assert probe["child_rc"] == 0 and probe["rccl_log"]["init"] == {"nranks": 1} and probe["rccl_log"]["channels"]["coll"] > 0
+    assert "RCCL" in probe["rccl_log"]["version"] and probe["microbench"]["all_gather_correct"]
     assert comm["collectives_issued"]["all_reduce"] > 10 and comm["collective_detail"]["sweeps_timed"] > 0
     assert r["parity_rel_l2_vs_oracle_after_1_sweep"] < 1e-5 and r["parity_P_rel_l2_vs_oracle"] < 2e-6
     assert r["last_delta"] == pytest.approx(r0["last_delta"], rel=5e-5)

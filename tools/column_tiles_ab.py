@@ -22,6 +22,10 @@ ap.add_argument("--tiles", type=int, nargs="+", default=[1, 2])
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--sweeps", type=int, default=40)
 ap.add_argument("--out", default=None)
+ap.add_argument("--class-threshold", type=int, default=None)
+ap.add_argument("--class-phases", type=int, default=None)
+ap.add_argument("--long-threshold", type=int, default=None)
+ap.add_argument("--class-chunk", type=int, default=256)
 args = ap.parse_args()
 gen, V, E, d, dname, gseed, xseed = bench.WORKLOADS[args.workload]
 dev = _hip.require_gpu("cuda:0")
@@ -30,7 +34,8 @@ X = synth.gaussian_X(V, d, seed=xseed).to(bench.DTYPES[dname])
 rec = {"workload": args.workload, "device": torch.cuda.get_device_name(dev), "tiles": {}}
 ref = None
 for T in args.tiles:            # one engine at a time (config 4 x 3 engines would not leave room), rounds inside
-    eng = SweepEngine(csr, X, dev, column_tiles=T)
+    eng = SweepEngine(csr, X, dev, column_tiles=T, class_threshold=args.class_threshold, class_phases=args.class_phases,
+                      long_threshold=args.long_threshold, class_chunk=args.class_chunk)
     t0 = time.perf_counter()
     eng.build_P()
     torch.cuda.synchronize()
