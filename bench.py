@@ -54,6 +54,11 @@ WORKLOADS = {
     # fraction with no cache caveat.  Same |V|, |E|, d as the headline.
     "uniform2m": ("uniform", 2_000_000, 40_000_000, 256, "f32", 12, 4),
     "rmat200k256": ("rmat", 200_000, 4_000_000, 256, "f32", 1, 2),    # config 2's graph at 1-KiB rows: a cache-resident table
+    # config 3's graph at other row widths: where do column tiles pay? (profiles/r05_column_tiles_ab.md)
+    "rmat2m512": ("rmat", 2_000_000, 40_000_000, 512, "f32", 3, 4),
+    "rmat2m384": ("rmat", 2_000_000, 40_000_000, 384, "f32", 3, 4),
+    "rmat2m1024": ("rmat", 2_000_000, 40_000_000, 1024, "f32", 3, 4),
+    "rmat2m512bf16": ("rmat", 2_000_000, 40_000_000, 512, "bf16", 3, 4),
     "tiny": ("rmat", 20_000, 200_000, 64, "f32", 7, 8),
     "tiny12": ("rmat", 20_000, 200_000, 12, "f32", 7, 8),             # 3 packs a row: more ranks than packs leaves idle column ranks
     # 8x config 3: a 16 GiB embedding matrix (byte offsets beyond 32 bits, ~85 GB of HBM in use) -- capacity check

@@ -162,25 +162,25 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
         return X
 
     def _pick_tiles(self, csr: HostCSR, dtype: torch.dtype) -> int:
-        """Column tiles of a one-GPU sweep (``column_tiles``; None = the rule below).  Measured, sweep ms with 1 / 2
-        tiles (profiles/r05_column_tiles_ab.md): config 3 (1-KiB rows, skewed reads, 2 GB table) 3.93 -> 3.79 (4 tiles:
-        4.08; build_P, which keeps the full width on the tiles' layout, 3.70 -> 3.85); the 16M-vertex run 38.6 -> 38.1;
-        uniform-random pairs 7.45 -> 7.63 (nothing to keep in a cache: colidx / P read twice for nothing); 512-byte rows
-        lose (cache-resident config 2: 0.187 -> 0.211; config 4's bf16 rows: 7.04 -> 8.08).  Hence: two tiles when a
-        row fills a wave (>= 1 KiB), the reads are skewed and the table is well beyond the Infinity Cache."""
+        """Column tiles of a one-GPU sweep (``column_tiles``; None = the rule below).  Measured on R-MAT 2M / 40M
+        (profiles/r05_column_tiles_ab.md), sweep ms untiled -> with tiles of 128 fp32 columns (512 bytes): d=256 3.92 ->
+        3.79 (2 tiles; 4 tiles of 64 columns: 4.08), d=384 6.40 -> 5.81 (3), d=512 8.70 -> 7.58 (4; 8 tiles of 64: 8.27),
+        d=1024 19.5 -> 15.4 (8); the 16M-vertex run 38.6 -> 38.1.  build_P, which keeps the full width on the tiles'
+        layout, pays 4-6 %; a propagate runs >= 11 sweeps per build_P.  Losses: uniform-random pairs 7.45 -> 7.63 (nothing
+        to keep in a cache: colidx / P read twice for nothing), rows below 1 KiB (cache-resident config 2 0.187 -> 0.211,
+        config 4's bf16 rows 7.04 -> 8.08), bf16 rows of 1 KiB (4.51 -> 4.72), tiles whose edges are not 128-byte
+        aligned (d=256 in 3 tiles: 5.11).  Hence: fp32, d a multiple of 128 and at least 256, tiles of 128 columns (at
+        most 8), skewed reads at the tile's width, a table well beyond the Infinity Cache."""
         asked = self._column_tiles_asked
         if asked is not None:
             if asked < 1:
                 raise ValueError("column_tiles must be >= 1")
             return int(asked)
-        es = torch.empty(0, dtype=dtype).element_size()
-        row_bytes = self.ld * es
-        if self.d <= 0 or lanes_per_row(self.d, dtype) < 64 or row_bytes < 1024:
+        if dtype != torch.float32 or self.d < 256 or self.d % 128:
             return 1
-        if csr.num_vertices * row_bytes <= 2 * INFINITY_CACHE_BYTES:
+        if csr.num_vertices * self.ld * 4 <= 2 * INFINITY_CACHE_BYTES:
             return 1
-        half = _round_up(-(-self.d // 2), _hip.VEC_ELEMS[dtype]) * es           # skewed at the tile's row width?
-        return 2 if hot_read_share(csr, half) >= MIN_HOT_READ_SHARE else 1
+        return min(8, self.d // 128) if hot_read_share(csr, 512) >= MIN_HOT_READ_SHARE else 1
 
     def _choose_class_pass(self, csr: HostCSR, class_threshold, class_chunk, class_k1, class_phases,
                            phase_threshold) -> None:

@@ -1018,6 +1018,10 @@ def test_column_tiles_of_a_one_gpu_sweep(tmp_path, monkeypatch):
     assert len(SweepEngine(even, Xz, "cpu", OracleKernels()).tiles) == 1                    # nothing to keep in a cache
     assert len(SweepEngine(skewed, Xz, "cpu", OracleKernels(), column_tiles=1).tiles) == 1  # obeyed
     assert len(SweepEngine(skewed, Xz[:, :128].contiguous(), "cpu", OracleKernels()).tiles) == 1   # 512-byte rows lose
+    assert len(SweepEngine(skewed, Xz[:, :200].contiguous(), "cpu", OracleKernels()).tiles) == 1   # tiles would not be 128 columns
+    assert len(SweepEngine(skewed, Xz.bfloat16(), "cpu", OracleKernels()).tiles) == 1              # measured for fp32 only
+    wide = SweepEngine(skewed, torch.zeros(V, 512), "cpu", OracleKernels())
+    assert wide.tiles == [(0, 128), (128, 256), (256, 384), (384, 512)]                             # tiles of 128 columns
     small = HostCSR(10_000, rowptr[:10_001], skewed.colidx[:160_000])
     assert len(SweepEngine(small, Xz[:10_000], "cpu", OracleKernels()).tiles) == 1            # fits the (scaled) Infinity Cache
     assert E.MIN_HOT_READ_SHARE == 0.2
