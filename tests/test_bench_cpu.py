@@ -42,7 +42,8 @@ def _fake_engine(**over):
 
 
 def test_traffic_is_only_quoted_for_the_configuration_it_was_measured_with(tmp_path, monkeypatch):
-    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    from benchkit import common
+    monkeypatch.setattr(common, "ROOT", tmp_path)
     (tmp_path / "profiles").mkdir()
     eng, cfg = _fake_engine()
     table = {"w_n1": {"source": "profiles/x.md", "kernel_config": cfg, "k": {"bytes_per_launch": 123.0, "avg_us_under_pmc": 7.5}},
