@@ -144,10 +144,13 @@ def main():
     import torch.distributed as dist
     n_also = 0 if args.also_exchange == "none" else len([x for x in args.also_exchange.split(",") if x])
     plan = {"driver_limit_s": DRIVER_LIMIT_S, "fabric_probe_s_at_most": 120.0 if args.gpus > 1 and not args.no_fabric_probe else 0.0,
-            "generation_and_main_division_s_estimate": 60.0,
-            "each_division_after_the_main_one_s_at_most": LITERAL_DEADLINE_S, "divisions_after_the_main_one": n_also if args.gpus > 1 else 0}
+            "generation_and_main_division_s_estimate": 60.0, "divisions_after_the_main_one": n_also if args.gpus > 1 else 0}
+    # every division after the main one gets the same share of what the driver's limit leaves (at most LITERAL_DEADLINE_S)
+    division_deadline = min(LITERAL_DEADLINE_S, (DRIVER_LIMIT_S - 30.0 - plan["fabric_probe_s_at_most"]
+                                                 - plan["generation_and_main_division_s_estimate"]) / max(1, n_also))
+    plan["each_division_after_the_main_one_s_at_most"] = division_deadline
     plan["worst_case_s"] = (plan["fabric_probe_s_at_most"] + plan["generation_and_main_division_s_estimate"]
-                            + plan["divisions_after_the_main_one"] * LITERAL_DEADLINE_S)
+                            + plan["divisions_after_the_main_one"] * division_deadline)
     if args.gpus > 1:
         log(f"time plan: {json.dumps(plan)} -- the main division's record goes to stderr as soon as it is measured and is "
             f"the ONE stdout line whatever happens to the divisions after it")
@@ -245,7 +248,7 @@ def main():
             # the main record still comes out, but the process leaves NON-ZERO: a hang is a failure the launcher and
             # the driver must see (1 if a parity check had already failed, else 3); never re-exec, never retry
             extra = {"also_exchange_error": (f"a division measured after the main one gave no result within "
-                                             f"{LITERAL_DEADLINE_S:.0f} s: printed as far as it got")}
+                                             f"{division_deadline:.0f} s: printed as far as it got")}
             if "north_star_literal" not in result:
                 extra["north_star_literal"] = {"exchange": "allgather_all"}
             emit(extra)
@@ -261,7 +264,7 @@ def main():
         for exchange in also:
             if timer is not None:
                 timer.cancel()
-            timer = threading.Timer(LITERAL_DEADLINE_S, give_up)
+            timer = threading.Timer(division_deadline, give_up)
             timer.daemon = True
             timer.start()
             t_div = time.perf_counter()
@@ -281,7 +284,7 @@ def main():
         # leave together.  A rank that fell out of a block above on its own (an exception the others did not have)
         # must not wait for ever for ranks stuck in a collective: the record is out, so past this deadline just leave,
         # non-zero.
-        last = threading.Timer(LITERAL_DEADLINE_S, lambda: os._exit(1 if state["failed"] else 3))
+        last = threading.Timer(division_deadline, lambda: os._exit(1 if state["failed"] else 3))
         last.daemon = True
         last.start()
         dist.barrier()
