@@ -8,7 +8,7 @@ import torch
 
 from .common import PARITY_P_TOL, PARITY_TOL, WORKLOADS
 from .measure import measure_division, run_iterate
-from .parity import check_parity
+from .parity import check_parity, per_edge_parity
 from .ranks import Ranks, generate_input
 from .record import comm_block, describe_parallelism, main_record
 
@@ -38,6 +38,8 @@ def workload_leg(args, ranks: Ranks, name: str) -> dict:
     eng = m["eng"]
     rec = main_record(la, ranks, m, X, csr.num_edges)
     _, failed = check_parity(la, ranks, eng, m, csr, X, rec, baselines=False)
+    if not failed and rec["dtype"] != "f64":        # all of P once more with per-edge cosine scores (not 1/deg)
+        failed = per_edge_parity(la, ranks, eng, csr, X, rec)
     roof = rec["roofline"]
     out = {"what": LEG_WHAT[name], "workload": rec["config"]["workload"], "value": rec["value"], "unit": rec["unit"],
            "ms_per_step": rec["ms_per_step"], "ms_per_step_min": rec["ms_per_step_min"],
@@ -46,6 +48,7 @@ def workload_leg(args, ranks: Ranks, name: str) -> dict:
            "build_P_ms": rec["build_P_ms"], "build_P_cold_ms": rec["build_P_cold_ms"],
            "parity_rel_l2_vs_oracle_after_1_sweep": rec.get("parity_rel_l2_vs_oracle_after_1_sweep"),
            "parity_P_rel_l2_vs_oracle": rec.get("parity_P_rel_l2_vs_oracle"),
+           "parity_P_per_edge_rel_l2_vs_oracle": rec.get("parity_P_per_edge_rel_l2_vs_oracle"),
            "parity_tolerance": {"Z1": PARITY_TOL[rec["dtype"]], "P": PARITY_P_TOL[rec["dtype"]]},
            "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
                                                  "traffic_over_algorithmic", "achieved_algorithmic",
