@@ -29,7 +29,8 @@ def traffic_entry(workload: str, world: int, eng, dom: str, slice_of=None):
     then = entry.get("kernel_config")
     if then is None:
         return None, f"{key}: measured before kernel configurations were recorded -- treated as stale"
-    then, live = dict({"column_tiles": 1}, **then), dict({"column_tiles": 1}, **live)   # before tiles existed: one tile
+    older = {"column_tiles": 1, "fewer_loads_in_flight": False}     # entries from before these keys existed
+    then, live = dict(older, **then), dict(older, **live)
     diff = sorted(k for k in set(live) | set(then) if live.get(k) != then.get(k) and k != "exchange")
     if diff:
         return None, f"{key}: stale, measured with another kernel configuration (differs in {', '.join(diff)})"

@@ -24,6 +24,7 @@ ABI_VERSION = 4
 
 SCORE_REFERENCE, SCORE_PER_EDGE, SCORE_RAW_DOT = 0, 1, 2
 SPMM_SINKS_UNTOUCHED = 1
+SPMM_TABLE_BEYOND_CACHE = 2
 SCORE_FUSE_SOFTMAX = 1
 SCORE_MODES = {"reference": SCORE_REFERENCE, "per_edge": SCORE_PER_EDGE, "raw_dot": SCORE_RAW_DOT}
 
@@ -63,7 +64,7 @@ for _s in ("f32", "f64", "bf16"):
         [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_spmm_update_class_{_s}"] = (
         C.c_int,
-        [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _p, _p, _p, _p])
+        [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _g, _p, _i64, _i32, _i32, _p, _p, _p, _p])
     SIGNATURES[f"clane_edge_score_class_{_s}"] = (
         C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p])
     SIGNATURES[f"clane_gather_rows_{_s}"] = (C.c_int, [_p, _i64, _p, _i64, _i32, _p, _i64, _p])
@@ -289,7 +290,7 @@ class KernelBackend(abc.ABC):
     # K3
     @abc.abstractmethod
     def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials,
-                    sinks_untouched=False, mirror=None): ...
+                    sinks_untouched=False, mirror=None, beyond_cache=False): ...
     @abc.abstractmethod
     def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row, row0, Z_old, X, gamma, Z_new, d, partials,
                          mirror=None): ...
@@ -298,7 +299,7 @@ class KernelBackend(abc.ABC):
                           gamma, Z_new, d, slab, partials, mirror=None): ...
     @abc.abstractmethod
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
-                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None): ...
+                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None, beyond_cache=False): ...
     @abc.abstractmethod
     def reduce_partials(self, partials, n, ws, out): ...
     @abc.abstractmethod
@@ -478,9 +479,11 @@ class HipKernels(KernelBackend):
         return None if sq is None else _vec(sq, acc_dtype(dtype), "sq_a")
 
     def spmm_update(self, rowptr, colidx, P, nrows: int, row0: int, Z_old, X, gamma: float, Z_new, d: int,
-                    long_threshold: int, partials, sinks_untouched: bool = False, mirror: Optional[Mirror] = None):
+                    long_threshold: int, partials, sinks_untouched: bool = False, mirror: Optional[Mirror] = None,
+                    beyond_cache: bool = False):
         """Main pass: every row of <= long_threshold edges (0 = all rows).  With `sinks_untouched` rows
-        without out-edges are neither read nor written (caller keeps Z_new == Z_old there)."""
+        without out-edges are neither read nor written (caller keeps Z_new == Z_old there).  `beyond_cache`: the hint
+        CLANE_SPMM_TABLE_BEYOND_CACHE (the table is far beyond the caches; results do not depend on it)."""
         zo, ldz = _mat(Z_old, "Z_old")
         xp, ldx = _mat(X, "X")
         zn, ldo = _mat(Z_new, "Z_new")
@@ -489,7 +492,7 @@ class HipKernels(KernelBackend):
         self._invoke(self._fn("clane_spmm_update", Z_old.dtype), "clane_spmm_update",
                      _vec(rowptr, torch.int64, "rowptr"), _vec(colidx, torch.int32, "colidx"),
                      _vec(P, acc_dtype(Z_old.dtype), "P"), nrows, row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
-                     long_threshold, SPMM_SINKS_UNTOUCHED if sinks_untouched else 0,
+                     long_threshold, (SPMM_SINKS_UNTOUCHED if sinks_untouched else 0) | (SPMM_TABLE_BEYOND_CACHE if beyond_cache else 0),
                      _mirror_arg(mirror, Z_new.dtype), _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 
     def spmm_update_long(self, rowptr, colidx, P, long_rows, waves_per_row: int, row0: int, Z_old, X, gamma: float,
@@ -530,7 +533,7 @@ class HipKernels(KernelBackend):
 
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block: int, class_rows, slot_ptr,
                           row0: int, Z_old, X, gamma: float, Z_new, d: int, slab, partials,
-                          mirror: Optional[Mirror] = None):
+                          mirror: Optional[Mirror] = None, beyond_cache: bool = False):
         """XCD-affine pass over the listed long rows (edges sorted by (XCD class of the column, column), cut into items; item
         blocks of class b at block index 8 j + b) + fixed-order combine; writes class_rows.numel() partials."""
         zo, ldz = _mat(Z_old, "Z_old")
@@ -545,6 +548,7 @@ class HipKernels(KernelBackend):
                      _vec(item_slot, torch.int32, "item_slot"), n_items // items_per_block, items_per_block,
                      _vec(class_rows, torch.int32, "class_rows"), _vec(slot_ptr, torch.int64, "slot_ptr"),
                      class_rows.numel(), row0, zo, ldz, xp, ldx, gamma, zn, ldo, d,
+                     SPMM_TABLE_BEYOND_CACHE if beyond_cache else 0,
                      _vec(slab, acc_dtype(Z_old.dtype), "slab"), _mirror_arg(mirror, Z_new.dtype),
                      _vec(partials, torch.float64, "partials"), self._stream(Z_old))
 

@@ -39,6 +39,12 @@ constexpr int64_t kReduceWs = 2 * kReduceGrid + 2;  // + the two finished sums
 #ifndef CLANE_LONG_U
 #define CLANE_LONG_U CLANE_SPMM_U    // neighbour-row loads in flight per wave of the workgroup-per-row kernels
 #endif
+#ifndef CLANE_SUBROW_U32
+#define CLANE_SUBROW_U32 4        // CLANE_SPMM_TABLE_BEYOND_CACHE: row loads in flight in spmm_update_subrow_kernel, two fp32 rows per instruction
+#endif
+#ifndef CLANE_CLASS_U32
+#define CLANE_CLASS_U32 6         // ... and in spmm_class_chunk_kernel (72 registers: 7 waves per SIMD instead of 5)
+#endif
 #ifndef CLANE_LONG_WAVES
 #define CLANE_LONG_WAVES 16         // waves of the workgroup-per-row kernels (A/B builds: 8)
 #endif
@@ -287,6 +293,18 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_SPMM_U : 4;
         auto launch = [&]<bool MIRRORED>() {          // the mirrored instances prefetch a row's places (spmm_update.h)
+            if constexpr (LPR == 32 && VEC == 4 && sizeof(T) == 4) {
+                // two fp32 rows per instruction (512-byte rows: the column tiles, config 2, the N = 2 column slices): with the
+                // table far beyond the caches 4 row loads in flight and 8 waves per SIMD beat 8 and 6 (config 3 in two
+                // tiles: row pass 1.58 -> 1.52 ms); a cache-resident table wants the 8 (config 2: 0.103 vs 0.120 ms)
+                if (flags & CLANE_SPMM_TABLE_BEYOND_CACHE) {
+                    spmm_update_subrow_kernel<T, PT, VEC, LPR, CLANE_SUBROW_U32, MIRRORED>
+                        <<<grid, kBlock, 0, (hipStream_t)stream>>>(
+                            rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
+                            (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, delta_partials);
+                    return;
+                }
+            }
             if constexpr (LPR < kWave && VEC > 1)      // short rows of narrow matrices: one sub-wave per row
                 spmm_update_subrow_kernel<T, PT, VEC, LPR, U, MIRRORED><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                     rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
@@ -368,7 +386,7 @@ template <typename T, typename PT>
 int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0, const int32_t *item_len,
                       const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block, const int32_t *class_rows,
                       const int64_t *slot_ptr, int64_t n_rows, int64_t row0, const T *Z_old, int64_t ldz, const T *X,
-                      int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d,
+                      int64_t ldx, typename Elem<T>::acc_t gamma, T *Z_new, int64_t ldo, int32_t d, int32_t flags,
                       typename Elem<T>::acc_t *slab, const clane_mirror_t *mirror, double *delta_partials,
                       void *stream) {
     REQUIRE(mirror_ok(mirror, d), "spmm_update_class: incomplete mirror descriptor");
@@ -389,7 +407,12 @@ int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0
     const Mirror<T> mir = make_mirror<T>(mirror);
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_LONG_U : 4;
-        if (n_blocks > 0)
+        constexpr bool kTwoRows = LPR == 32 && VEC == 4 && sizeof(T) == 4;      // see spmm_update: fewer loads, more waves
+        if (n_blocks > 0 && kTwoRows && (flags & CLANE_SPMM_TABLE_BEYOND_CACHE))
+            spmm_class_chunk_kernel<T, PT, VEC, LPR, kTwoRows ? CLANE_CLASS_U32 : U>
+                <<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
+                    colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab);
+        else if (n_blocks > 0)
             spmm_class_chunk_kernel<T, PT, VEC, LPR, U><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
                 colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab);
         spmm_class_combine_kernel<T, VEC><<<unsigned(n_rows), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
@@ -467,7 +490,7 @@ const char *clane_build_info(void) {
     return "arch=gfx950;SPMM_U=" CLANE_STR(CLANE_SPMM_U) ";LONG_U=" CLANE_STR(CLANE_LONG_U) ";LONG_WAVES=" CLANE_STR(
         CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM)
         ";TARGET_GRID=" CLANE_STR(CLANE_TARGET_GRID) ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH)
-        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";COMBINE_LOADS=" CLANE_STR(CLANE_COMBINE_LOADS);
+        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";COMBINE_LOADS=" CLANE_STR(CLANE_COMBINE_LOADS) ";SUBROW_U32=" CLANE_STR(CLANE_SUBROW_U32) ";CLASS_U32=" CLANE_STR(CLANE_CLASS_U32);
 }
 
 int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *stream) {
@@ -638,12 +661,12 @@ CLANE_SPLIT_WRAPPER(bf16, uint16_t, bf16_t, float, float)
                                       const int32_t *item_len, const int32_t *item_slot, int64_t n_blocks,            \
                                       int32_t items_per_block, const int32_t *class_rows, const int64_t *slot_ptr,    \
                                       int64_t n_rows, int64_t row0, const CT *Z_old, int64_t ldz, const CT *X,        \
-                                      int64_t ldx, GT gamma, CT *Z_new, int64_t ldo, int32_t d, GT *slab,             \
-                                      const clane_mirror_t *mirror, double *delta_partials, void *stream) {           \
+                                      int64_t ldx, GT gamma, CT *Z_new, int64_t ldo, int32_t d, int32_t flags,        \
+                                      GT *slab, const clane_mirror_t *mirror, double *delta_partials, void *stream) { \
         return spmm_update_class<T, PT>(colidx, P, item_e0, item_len, item_slot, n_blocks, items_per_block,           \
                                         class_rows, slot_ptr, n_rows, row0, reinterpret_cast<const T *>(Z_old), ldz,  \
                                         reinterpret_cast<const T *>(X), ldx, gamma, reinterpret_cast<T *>(Z_new),     \
-                                        ldo, d, slab, mirror, delta_partials, stream);                                \
+                                        ldo, d, flags, slab, mirror, delta_partials, stream);                         \
     }
 CLANE_CLASS_WRAPPER(f32, float, float, float, float)
 CLANE_CLASS_WRAPPER(f64, double, double, double, double)

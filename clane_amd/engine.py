@@ -157,6 +157,9 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
         self.tiles = [c for c in cuts if c[1] > c[0]] or [(0, self.d)]
         if len(self.tiles) > 1:
             self.d_plan = max(c1 - c0 for c0, c1 in self.tiles)
+        # a hint for the kernels (CLANE_SPMM_TABLE_BEYOND_CACHE): with the table far beyond the Infinity Cache the
+        # 512-byte-row instances keep fewer row loads in flight per wave and run more waves (csrc/clane_abi.hip)
+        self.beyond_cache = csr.num_vertices * self.ld * torch.empty(0, dtype=X.dtype).element_size() > 2 * INFINITY_CACHE_BYTES
         self.ld_plan = _round_up(self.d_plan, _hip.VEC_ELEMS[X.dtype])
         self.rows_per_wave = 64 // lanes_per_row(self.d_plan, X.dtype) if self.d_plan > 0 else 1
         return X
@@ -733,7 +736,7 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
                         steps.append(("call", self._bind("spmm_update_class", self.colidx, self.P, it_e0, it_len, it_slot,
                                                          ipb, rows_c, slot_ptr, b.row0, cut(Zold, t), cut(Xb, t), gamma,
                                                          cut(Zn, t), width(t), self.slabs[i % len(self.slabs)],
-                                                         part(po_class, t), mirror=mir)))
+                                                         part(po_class, t), mirror=mir, beyond_cache=self.beyond_cache)))
                     if self.split_rows[i] is not None:
                         rows_s, seg_ptr, seg_row = self.split_rows[i]
                         steps.append(("call", self._bind("spmm_update_split", rp, self.colidx, self.P, rows_s, seg_ptr,
@@ -756,7 +759,8 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
                 for t in range(T):
                     steps.append(("call", self._bind("spmm_update", rp, self.colidx, self.P, b.nrows, b.row0, cut(Zold, t),
                                                      cut(Xb, t), gamma, cut(Zn, t), width(t), self.long_threshold,
-                                                     part(po, t), sinks_untouched=True, mirror=mir)))
+                                                     part(po, t), sinks_untouched=True, mirror=mir,
+                                                     beyond_cache=self.beyond_cache)))
                 steps.append(("event", i, 3))
                 if b.span is not None:
                     steps.append(("allgather", Znew[b.span[0]:b.span[1]], Zn))

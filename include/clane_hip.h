@@ -42,7 +42,8 @@ extern "C" {
                              * 3: clane_l1_distance_* takes `sq_a` (the rows' squared norms from the outer-delta pass: free),
                              *    clane_device_alloc_contiguous; every clane_spmm_update* took `sq_out` (the same norms out of K3)
                              * 4: `sq_out` is gone again: it cost every sweep 1.1-1.4 % to save one 0.34 ms pass per build_P, and a
-                             *    propagate runs >= 11 sweeps per build_P (profiles/r04_fused_norms_ab.jsonl) */
+                             *    propagate runs >= 11 sweeps per build_P (profiles/r04_fused_norms_ab.jsonl);
+                             *    clane_spmm_update_class_* takes `flags` (CLANE_SPMM_TABLE_BEYOND_CACHE, also a flag of clane_spmm_update_*) */
 
 #define CLANE_OK 0
 #define CLANE_ERR_INVALID_ARGUMENT (-1)
@@ -59,8 +60,14 @@ extern "C" {
  * listed row -- for graphs with rows of millions of edges; results do not depend on n; 0 means 1 */
 #define CLANE_SCORE_ROW_PARTS(n) (((n) & 0xff) << 8)
 
-/* flags of clane_spmm_update_* */
+/* flags of clane_spmm_update_* and clane_spmm_update_class_* */
 #define CLANE_SPMM_SINKS_UNTOUCHED 1
+/* A hint, never a change of results: the embedding table is far beyond the caches (the engine: more than twice the
+ * 256 MiB Infinity Cache).  The instances with two fp32 rows per instruction (512-byte rows: column tiles / slices)
+ * then keep 4 (row kernel) / 6 (class chunks) row loads in flight per wave instead of 8 and run 8 / 7 waves per SIMD
+ * instead of 6 / 5 -- config 3 in two column tiles 3.79 -> 3.71 ms per sweep; a cache-resident table (config 2) loses
+ * 18 % with it.  Other instances ignore it. */
+#define CLANE_SPMM_TABLE_BEYOND_CACHE 2
 
 /* Optional further destinations of the rows a clane_spmm_update* call finishes: row r (relative to the call's
  * first row) is also stored at the places slot[row_ptr[r] .. row_ptr[r+1]); a place is (buffer << 28 | row) into
@@ -289,25 +296,26 @@ int clane_edge_score_class_bf16(const int64_t *rowptr, const int32_t *colidx, co
  *                             working set at any moment is a fraction of its class (clane_amd/xcd.py).
  *                             class_rows[n_rows] local row ids; slot_ptr[n_rows+1]: the slots of
  *                             row i are [slot_ptr[i], slot_ptr[i+1]) and are added in that order (reproducible),
- *                             then the usual epilogue.  Writes n_rows doubles to delta_partials. */
+ *                             then the usual epilogue.  Writes n_rows doubles to delta_partials.
+ *                             flags: CLANE_SPMM_TABLE_BEYOND_CACHE or 0. */
 int64_t clane_spmm_class_slab_len(int64_t n_slots, int32_t d);
 int clane_spmm_update_class_f32(const int32_t *colidx, const float *P, const int64_t *item_e0, const int32_t *item_len,
                                 const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
                                 const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
                                 const float *Z_old, int64_t ldz, const float *X, int64_t ldx, float gamma, float *Z_new,
-                                int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
+                                int64_t ldo, int32_t d, int32_t flags, float *slab, const clane_mirror_t *mirror,
                                 double *delta_partials, void *stream);
 int clane_spmm_update_class_f64(const int32_t *colidx, const double *P, const int64_t *item_e0, const int32_t *item_len,
                                 const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
                                 const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
                                 const double *Z_old, int64_t ldz, const double *X, int64_t ldx, double gamma,
-                                double *Z_new, int64_t ldo, int32_t d, double *slab, const clane_mirror_t *mirror,
+                                double *Z_new, int64_t ldo, int32_t d, int32_t flags, double *slab, const clane_mirror_t *mirror,
                                 double *delta_partials, void *stream);
 int clane_spmm_update_class_bf16(const int32_t *colidx, const float *P, const int64_t *item_e0, const int32_t *item_len,
                                  const int32_t *item_slot, int64_t n_blocks, int32_t items_per_block,
                                  const int32_t *class_rows, const int64_t *slot_ptr, int64_t n_rows, int64_t row0,
                                  const uint16_t *Z_old, int64_t ldz, const uint16_t *X, int64_t ldx, float gamma,
-                                 uint16_t *Z_new, int64_t ldo, int32_t d, float *slab, const clane_mirror_t *mirror,
+                                 uint16_t *Z_new, int64_t ldo, int32_t d, int32_t flags, float *slab, const clane_mirror_t *mirror,
                                  double *delta_partials, void *stream);
 
 /* out[0] = sum of partials[0..n) in a fixed order (bitwise reproducible).  Finishes embedder.py:94 / :60.

@@ -144,7 +144,7 @@ class OracleKernels(KernelBackend):
         return total
 
     def spmm_update(self, rowptr, colidx, P, nrows, row0, Z_old, X, gamma, Z_new, d, long_threshold, partials,
-                    sinks_untouched=False, mirror=None):
+                    sinks_untouched=False, mirror=None, beyond_cache=False):
         rp = _np(rowptr[:nrows + 1])
         deg = np.diff(rp)
         sel = [r for r in range(nrows) if not (long_threshold > 0 and deg[r] > long_threshold)
@@ -172,7 +172,7 @@ class OracleKernels(KernelBackend):
         return n_slots * (-(-d // 8) * 8)
 
     def spmm_update_class(self, colidx, P, item_e0, item_len, item_slot, items_per_block, class_rows, slot_ptr, row0,
-                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None):
+                          Z_old, X, gamma, Z_new, d, slab, partials, mirror=None, beyond_cache=False):
         """The XCD-affine pass: partial sums per item into the slab, a row's slots added in order.  Also checks the
         layout contract the kernel relies on: whole blocks, every item of block w gathers only rows of XCD class w % 8."""
         e0, ln, sl = _np(item_e0), _np(item_len), _np(item_slot)

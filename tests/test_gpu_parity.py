@@ -377,6 +377,25 @@ def test_column_tiles_on_the_gpu(dev, dtype, d, tiles):
     assert_norms_are_k0s(tiled, "tiled engine, after the outer-delta pass")
 
 
+def test_table_beyond_cache_hint_changes_no_bit(dev, k):
+    """CLANE_SPMM_TABLE_BEYOND_CACHE picks other instances of the 512-byte-row kernels (fewer row loads in flight, more
+    waves) -- a speed hint: Z, deltas and partials are the same bits with and without it, for the instances it selects
+    (fp32, d = 128: two rows per instruction) and for those that ignore it."""
+    csr = ragged_csr(8000, seed=31, max_deg=50, hubs=(7000, 800, 129, 65))
+    for dtype, d in ((torch.float32, 128), (torch.float32, 100), (torch.float32, 256), (torch.bfloat16, 128)):
+        X = synth.gaussian_X(8000, d, seed=2).to(dtype)
+        a = SweepEngine(csr, X, dev, class_threshold=32, class_chunk=64)
+        b = SweepEngine(csr, X, dev, class_threshold=32, class_chunk=64)
+        assert not a.beyond_cache and not a.kernel_config()["fewer_loads_in_flight"]
+        b.beyond_cache = True                                  # (a small table: forced, before the launch lists are built)
+        assert b.kernel_config()["fewer_loads_in_flight"] == (dtype == torch.float32 and d in (128, 100))
+        for eng in (a, b):
+            eng.build_P()
+        for _ in range(3):
+            assert a.sweep(0.7) == b.sweep(0.7)
+            assert torch.equal(a.Zcur, b.Zcur) and torch.equal(a.partials, b.partials)
+
+
 def test_set_cosine_mode_switches_the_scores_of_a_live_engine(dev):
     """SweepEngine.set_cosine_mode (bench.py's non-degenerate full-size check of K1 uses it): the same engine scores in
     per-edge mode, then in reference mode again -- each time the P of a fresh engine of that mode, bit for bit, and the
