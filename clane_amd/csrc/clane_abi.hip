@@ -42,6 +42,9 @@ constexpr int64_t kReduceWs = 2 * kReduceGrid + 2;  // + the two finished sums
 #ifndef CLANE_SUBROW_U32
 #define CLANE_SUBROW_U32 4        // CLANE_SPMM_TABLE_BEYOND_CACHE: row loads in flight in spmm_update_subrow_kernel, two fp32 rows per instruction
 #endif
+#ifndef CLANE_CLASS_U16B
+#define CLANE_CLASS_U16B 4        // ... and in its instance with four bf16 rows per instruction (config 4)
+#endif
 #ifndef CLANE_CLASS_U32
 #define CLANE_CLASS_U32 6         // ... and in spmm_class_chunk_kernel (72 registers: 7 waves per SIMD instead of 5)
 #endif
@@ -407,9 +410,13 @@ int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0
     const Mirror<T> mir = make_mirror<T>(mirror);
     dispatch_layout<T>(L, [&]<int VEC, int LPR>() {
         constexpr int U = VEC > 1 ? CLANE_LONG_U : 4;
-        constexpr bool kTwoRows = LPR == 32 && VEC == 4 && sizeof(T) == 4;      // see spmm_update: fewer loads, more waves
-        if (n_blocks > 0 && kTwoRows && (flags & CLANE_SPMM_TABLE_BEYOND_CACHE))
-            spmm_class_chunk_kernel<T, PT, VEC, LPR, kTwoRows ? CLANE_CLASS_U32 : U>
+        // CLANE_SPMM_TABLE_BEYOND_CACHE: fewer row loads in flight, more waves -- where it was measured to pay (see
+        // spmm_update): two fp32 rows per instruction (6: config 3 in tiles), four bf16 rows (4: config 4's class pass
+        // 2.48 -> 2.36 ms, 98 -> 74 registers)
+        constexpr int kDeepU = (LPR == 32 && VEC == 4 && sizeof(T) == 4) ? CLANE_CLASS_U32
+                               : (LPR == 16 && VEC == 8 && sizeof(T) == 2) ? CLANE_CLASS_U16B : 0;
+        if (n_blocks > 0 && kDeepU > 0 && (flags & CLANE_SPMM_TABLE_BEYOND_CACHE))
+            spmm_class_chunk_kernel<T, PT, VEC, LPR, (kDeepU > 0 ? kDeepU : U)>
                 <<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
                     colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab);
         else if (n_blocks > 0)
@@ -490,7 +497,7 @@ const char *clane_build_info(void) {
     return "arch=gfx950;SPMM_U=" CLANE_STR(CLANE_SPMM_U) ";LONG_U=" CLANE_STR(CLANE_LONG_U) ";LONG_WAVES=" CLANE_STR(
         CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM)
         ";TARGET_GRID=" CLANE_STR(CLANE_TARGET_GRID) ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH)
-        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";COMBINE_LOADS=" CLANE_STR(CLANE_COMBINE_LOADS) ";SUBROW_U32=" CLANE_STR(CLANE_SUBROW_U32) ";CLASS_U32=" CLANE_STR(CLANE_CLASS_U32);
+        ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";COMBINE_LOADS=" CLANE_STR(CLANE_COMBINE_LOADS) ";SUBROW_U32=" CLANE_STR(CLANE_SUBROW_U32) ";CLASS_U32=" CLANE_STR(CLANE_CLASS_U32) ";CLASS_U16B=" CLANE_STR(CLANE_CLASS_U16B);
 }
 
 int clane_xcc_ids(int32_t *out, int64_t n_blocks, int32_t block_threads, void *stream) {

@@ -85,8 +85,8 @@ class DiagnosticsMixin:
                 "class_items_per_block": [c[6] for c in self.class_rows if c is not None][:1],
                 "column_tiles": len(self.tiles),
                 # CLANE_SPMM_TABLE_BEYOND_CACHE changes the instances only where two fp32 rows share an instruction
-                "fewer_loads_in_flight": bool(self.beyond_cache and self.d > 0 and str(self.dtype) == "torch.float32" and
-                                              lanes_per_row(self.d_plan if len(self.tiles) > 1 else self.d, self.dtype) == 32),
+                "fewer_loads_in_flight": bool(self.beyond_cache and self.d > 0 and (str(self.dtype), lanes_per_row(
+                    self.d_plan if len(self.tiles) > 1 else self.d, self.dtype)) in (("torch.float32", 32), ("torch.bfloat16", 16))),
                 "hot_rows_first": self.hot_rows_first, "exchange": self.exchange,
                 }
 
