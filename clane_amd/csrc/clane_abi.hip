@@ -304,18 +304,21 @@ int spmm_update(const int64_t *rowptr, const int32_t *colidx, const PT *P, int64
                     spmm_update_subrow_kernel<T, PT, VEC, LPR, CLANE_SUBROW_U32, MIRRORED>
                         <<<grid, kBlock, 0, (hipStream_t)stream>>>(
                             rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                            (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, delta_partials);
+                            (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir,
+                            (flags & CLANE_SPMM_TABLE_BEYOND_CACHE) != 0, delta_partials);
                     return;
                 }
             }
             if constexpr (LPR < kWave && VEC > 1)      // short rows of narrow matrices: one sub-wave per row
                 spmm_update_subrow_kernel<T, PT, VEC, LPR, U, MIRRORED><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                     rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, delta_partials);
+                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir,
+                            (flags & CLANE_SPMM_TABLE_BEYOND_CACHE) != 0, delta_partials);
             else
                 spmm_update_kernel<T, PT, VEC, LPR, U, MIRRORED><<<grid, kBlock, 0, (hipStream_t)stream>>>(
                     rowptr, colidx, P, nrows, row0, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, long_threshold,
-                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir, delta_partials);
+                    (flags & CLANE_SPMM_SINKS_UNTOUCHED) != 0, rows_per_block(nrows), mir,
+                            (flags & CLANE_SPMM_TABLE_BEYOND_CACHE) != 0, delta_partials);
         };
         if (mir.row_ptr != nullptr) launch.template operator()<true>();
         else launch.template operator()<false>();
@@ -380,7 +383,7 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
                 rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, Z_old, ldz, d, slab, ld_slab);
         // a row's segments sit in the slab like a class row's slots: the same fixed-order combine + epilogue
         spmm_class_combine_kernel<T, VEC><<<unsigned(n_split), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
-            split_rows, seg_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
+            split_rows, seg_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, false, delta_partials);
     });
     return check_launch("spmm_update_split");
 }
@@ -423,7 +426,8 @@ int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0
             spmm_class_chunk_kernel<T, PT, VEC, LPR, U><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
                 colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab);
         spmm_class_combine_kernel<T, VEC><<<unsigned(n_rows), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
-            class_rows, slot_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, delta_partials);
+            class_rows, slot_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir,
+            (flags & CLANE_SPMM_TABLE_BEYOND_CACHE) != 0, delta_partials);
     });
     return check_launch("spmm_update_class");
 }

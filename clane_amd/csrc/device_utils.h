@@ -63,10 +63,14 @@ __device__ __forceinline__ void store_pack(T *p, const Pack<T, VEC> &v) {
     *reinterpret_cast<Pack<T, VEC> *>(p) = v;
 }
 
-// Data touched once per sweep (a row's own x / z_old, the z_new it writes): with CLANE_NT_STREAM these accesses
-// are marked non-temporal so that they do not push gathered rows out of L2 / the Infinity Cache.
+// Data touched once per sweep (a row's own x / z_old, the z_new it writes) can be marked non-temporal so that it does
+// not push gathered rows out of the L2s / the Infinity Cache.  Measured with round 5's kernels
+// (profiles/r05_nt_streams.md): non-temporal LOADS gain everywhere (config 3 -0.7 %, config 4 -1.8 %, config 2 -1 %):
+// on by default (bit 0).  Non-temporal STORES of z_new gain on tables far beyond the caches (config 3 another -0.8 %,
+// the 16M-vertex run -1 %) and LOSE on a cache-resident table (config 2 +4 %: the next sweep gathers what this one
+// wrote): a run-time choice of the caller (`nt`: CLANE_SPMM_TABLE_BEYOND_CACHE), bit 1 forces them.
 #ifndef CLANE_NT_STREAM
-#define CLANE_NT_STREAM 0          // bit 0: streamed loads, bit 1: streamed stores
+#define CLANE_NT_STREAM 1          // bit 0: streamed loads non-temporal, bit 1: streamed stores always non-temporal
 #endif
 typedef uint32_t clane_u32x4 __attribute__((ext_vector_type(4)));
 template <typename T, int VEC>
@@ -81,14 +85,16 @@ __device__ __forceinline__ Pack<T, VEC> load_pack_stream(const T *p) {
     }
 }
 template <typename T, int VEC>
-__device__ __forceinline__ void store_pack_stream(T *p, const Pack<T, VEC> &v) {
-    if constexpr ((CLANE_NT_STREAM & 2) && sizeof(Pack<T, VEC>) == 16) {
-        clane_u32x4 w;
-        __builtin_memcpy(&w, &v, 16);
-        __builtin_nontemporal_store(w, reinterpret_cast<clane_u32x4 *>(p));
-    } else {
-        store_pack<T, VEC>(p, v);
+__device__ __forceinline__ void store_pack_stream(T *p, const Pack<T, VEC> &v, bool nt) {
+    if constexpr (sizeof(Pack<T, VEC>) == 16) {
+        if ((CLANE_NT_STREAM & 2) || nt) {           // `nt`: a kernel argument, uniform
+            clane_u32x4 w;
+            __builtin_memcpy(&w, &v, 16);
+            __builtin_nontemporal_store(w, reinterpret_cast<clane_u32x4 *>(p));
+            return;
+        }
     }
+    store_pack<T, VEC>(p, v);
 }
 
 // ---- wave64 cross-lane -------------------------------------------------------------------

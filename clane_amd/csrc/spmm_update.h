@@ -172,7 +172,7 @@ template <typename T, int VEC>
 __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC> &x, const Pack<T, VEC> &zo,
                                                                const typename Elem<T>::acc_t (&acc)[VEC],
                                                                typename Elem<T>::acc_t gamma, bool has_edges,
-                                                               T *__restrict__ dst, Pack<T, VEC> &out) {
+                                                               T *__restrict__ dst, Pack<T, VEC> &out, bool nt_store) {
     using A = typename Elem<T>::acc_t;
     A rsum = A(0);
 #pragma unroll
@@ -183,7 +183,7 @@ __device__ __forceinline__ typename Elem<T>::acc_t finish_pack(const Pack<T, VEC
         const A stored = Elem<T>::to_acc(out.v[k]);
         rsum += fabs(stored - zold);
     }
-    store_pack_stream<T, VEC>(dst, out);
+    store_pack_stream<T, VEC>(dst, out, nt_store);
     return rsum;
 }
 
@@ -254,7 +254,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, Mirror<T> mirror, bool nt_store, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ int64_t s_rowptr[kMaxRowsPerBlock + 1];
     __shared__ int64_t s_mptr[MIRRORED ? kMaxRowsPerBlock + 1 : 1];   // the block's slice of mirror.row_ptr
@@ -342,7 +342,7 @@ __global__ CLANE_SPMM_BOUNDS void spmm_update_kernel(
                 gather_accumulate<T, PT, VEC, LPR, U>(colidx, P, e0, e1, Zold + (col_ok ? c0 : 0), ldz, col_ok, acc, ch, true);
                 fold_subwaves<LPR>(acc);
                 Pack<T, VEC> out{};
-                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out);
+                if (writer) rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out, nt_store);
                 if constexpr (MIRRORED)
                     mirror_store_prefetched<T, VEC, kWave>(mirror, m0, m1, places, c0, out, writer, lane, 0);
             }
@@ -394,7 +394,7 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const PT *__restrict__ P, int64_t nrows,
     int64_t row0, const T *__restrict__ Zold, int64_t ldz, const T *__restrict__ X, int64_t ldx,
     typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d, int64_t long_threshold,
-    bool skip_sinks, int rows_per_block, Mirror<T> mirror, double *__restrict__ partials) {
+    bool skip_sinks, int rows_per_block, Mirror<T> mirror, bool nt_store, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     static_assert(LPR < kWave, "use spmm_update_kernel for rows that fill a wave");
     static_assert(LPR % U == 0, "a sub-wave's edge buffer is consumed in whole groups of U");
@@ -448,7 +448,7 @@ __global__ CLANE_SUBROW_BOUNDS void spmm_update_subrow_kernel(
                     const int64_t r = row_begin + mine;
                     A rsum = A(0);
                     Pack<T, VEC> out{};
-                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out);
+                    if (col_ok) rsum = finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out, nt_store);
                     if constexpr (MIRRORED)
                         mirror_store_prefetched<T, VEC, LPR>(mirror, m0, m1, places, c0, out, col_ok, sl, sub_base);
                     rsum = group_sum<LPR>(rsum);
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(WAVES *kWave) void spmm_long_kernel(
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) acc[k] += red[w][lane][k];
                 }
-                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out);
+                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, e1 > e0, Znew + r * ldo + c0, out, false);
             }
             mirror_store<T, VEC, kWave>(mirror, r, c0, out, writer, lane, 0);
         }
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
     const int32_t *__restrict__ class_rows, const int64_t *__restrict__ slot_ptr, int64_t row0,
     const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
-    Mirror<T> mirror, double *__restrict__ partials) {
+    Mirror<T> mirror, bool nt_store, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
     __shared__ A s_part[kCombineWaves > 1 ? kCombineWaves - 1 : 1][kWave][VEC];
     const int i = blockIdx.x;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
                 }
                 const Pack<T, VEC> x = load_pack_stream<T, VEC>(X + r * ldx + c0);
                 const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
-                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out);
+                rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out, nt_store);
             }
             mirror_store<T, VEC, kWave>(mirror, r, c0, out, ok, lane, 0);
         }

@@ -66,8 +66,9 @@ extern "C" {
  * 256 MiB Infinity Cache).  The instances with two fp32 rows per instruction (512-byte rows: column tiles / slices)
  * then keep 4 (row kernel) / 6 (class chunks) row loads in flight per wave instead of 8 and run 8 / 7 waves per SIMD
  * instead of 6 / 5 -- config 3 in two column tiles 3.79 -> 3.71 ms per sweep; a cache-resident table (config 2) loses
- * 18 % with it.  The class chunks with four bf16 rows per instruction keep 4 (config 4: 7.10 -> 6.99 ms).  Other
- * instances ignore it. */
+ * 18 % with it.  The class chunks with four bf16 rows per instruction keep 4 (config 4: 7.10 -> 6.99 ms).  With the
+ * hint every finished row of z_new is also stored non-temporal (config 3 another 0.8 %; on a cache-resident table the
+ * next sweep gathers what this one wrote and non-temporal stores cost 4 %). */
 #define CLANE_SPMM_TABLE_BEYOND_CACHE 2
 
 /* Optional further destinations of the rows a clane_spmm_update* call finishes: row r (relative to the call's
