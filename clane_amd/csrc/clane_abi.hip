@@ -499,7 +499,7 @@ const char *clane_last_error(void) { return g_err; }
 #define CLANE_STR(x) CLANE_STR2(x)
 const char *clane_build_info(void) {
     return "arch=gfx950;SPMM_U=" CLANE_STR(CLANE_SPMM_U) ";LONG_U=" CLANE_STR(CLANE_LONG_U) ";LONG_WAVES=" CLANE_STR(
-        CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM)
+        CLANE_LONG_WAVES) ";ROWS_PER_BLOCK=" CLANE_STR(CLANE_ROWS_PER_BLOCK) ";NT_STREAM=" CLANE_STR(CLANE_NT_STREAM) ";NT_SLAB=" CLANE_STR(CLANE_NT_SLAB)
         ";TARGET_GRID=" CLANE_STR(CLANE_TARGET_GRID) ";SPMM_DYNAMIC=" CLANE_STR(CLANE_SPMM_DYNAMIC) ";SPMM_PREFETCH=" CLANE_STR(CLANE_SPMM_PREFETCH)
         ";COMBINE_WAVES=" CLANE_STR(CLANE_COMBINE_WAVES) ";XOR_DPP=" CLANE_STR(CLANE_XOR_DPP) ";COMBINE_LOADS=" CLANE_STR(CLANE_COMBINE_LOADS) ";SUBROW_U32=" CLANE_STR(CLANE_SUBROW_U32) ";CLASS_U32=" CLANE_STR(CLANE_CLASS_U32) ";CLASS_U16B=" CLANE_STR(CLANE_CLASS_U16B);
 }

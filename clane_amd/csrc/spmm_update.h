@@ -681,6 +681,35 @@ namespace clane {
 // in LDS, waves claim them from an LDS counter and request the next chunk's colidx / P before gathering the
 // current one, exactly like spmm_update_kernel does with rows.
 
+// The slab is written once by the chunk kernel and read once by the combine, a whole launch later: its lines only take
+// L2 / Infinity-Cache space from the rows being gathered.  CLANE_NT_SLAB bit 0 = non-temporal stores (default: config 3's
+// class pass 2.19 -> 2.14 ms, config 2 unchanged), bit 1 = non-temporal loads in the combine (nothing: 3.714 -> 3.701 with
+// the loads alone, 3.678 / 3.665 with both against 3.663 with the stores alone; profiles/r05_nt_streams.md).
+#ifndef CLANE_NT_SLAB
+#define CLANE_NT_SLAB 1
+#endif
+template <typename A, int VEC>
+__device__ __forceinline__ void slab_store(A *p, const Pack<A, VEC> &v) {
+    if constexpr ((CLANE_NT_SLAB & 1) && sizeof(Pack<A, VEC>) == 16) {
+        clane_u32x4 w;
+        __builtin_memcpy(&w, &v, 16);
+        __builtin_nontemporal_store(w, reinterpret_cast<clane_u32x4 *>(p));
+    } else {
+        store_pack<A, VEC>(p, v);
+    }
+}
+template <typename A, int VEC>
+__device__ __forceinline__ Pack<A, VEC> slab_load(const A *p) {
+    if constexpr ((CLANE_NT_SLAB & 2) && sizeof(Pack<A, VEC>) == 16) {
+        const clane_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const clane_u32x4 *>(p));
+        Pack<A, VEC> out;
+        __builtin_memcpy(&out, &v, 16);
+        return out;
+    } else {
+        return load_pack<A, VEC>(p);
+    }
+}
+
 template <typename T, typename PT, int VEC, int LPR, int U>
 __global__ __launch_bounds__(kBlock) void spmm_class_chunk_kernel(
     const int32_t *__restrict__ colidx, const PT *__restrict__ P, const int64_t *__restrict__ item_e0,
@@ -740,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void spmm_class_chunk_kernel(
                     Pack<A, VEC> o;
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];
-                    store_pack<A, VEC>(out + c0, o);
+                    slab_store<A, VEC>(out + c0, o);
                 }
             }
         }
@@ -792,7 +821,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
             for (; s + kCombineLoads <= b; s += kCombineLoads) {
                 Pack<A, VEC> part[kCombineLoads];
 #pragma unroll
-                for (int u = 0; u < kCombineLoads; ++u) part[u] = load_pack<A, VEC>(slab + (s + u) * ld_slab + c0);
+                for (int u = 0; u < kCombineLoads; ++u) part[u] = slab_load<A, VEC>(slab + (s + u) * ld_slab + c0);
 #pragma unroll
                 for (int u = 0; u < kCombineLoads; ++u) {
 #pragma unroll
@@ -801,7 +830,7 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
             }
 #pragma unroll 4
             for (; s < b; ++s) {
-                const Pack<A, VEC> part = load_pack<A, VEC>(slab + s * ld_slab + c0);
+                const Pack<A, VEC> part = slab_load<A, VEC>(slab + s * ld_slab + c0);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] += part.v[k];
             }
