@@ -24,6 +24,23 @@
 
 namespace clane {
 
+// The source row of a CSR row is read once per build_P: non-temporal (build_P at config 3 3.84 -> 3.80 / 3.83 ms, config 4
+// 7.02 / 6.97 -> 6.93 / 6.96: small, free).
+#ifndef CLANE_K1_NT_SRC
+#define CLANE_K1_NT_SRC 1
+#endif
+template <typename T, int VEC>
+__device__ __forceinline__ Pack<T, VEC> k1_src_load(const T *p) {
+    if constexpr (CLANE_K1_NT_SRC && sizeof(Pack<T, VEC>) == 16) {
+        const clane_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const clane_u32x4 *>(p));
+        Pack<T, VEC> out;
+        __builtin_memcpy(&out, &v, 16);
+        return out;
+    } else {
+        return load_pack<T, VEC>(p);
+    }
+}
+
 constexpr int kScoreReference = 0;
 constexpr int kScorePerEdge = 1;
 constexpr int kScoreRawDot = 2;
@@ -80,7 +97,7 @@ __device__ __forceinline__ RangeStats<typename Elem<T>::acc_t> score_edge_range(
     const T *zsrc = Z + src_row * ldz;
     const A nsrc = mode == kScorePerEdge ? sqrt(sq[src_row]) : A(0);
     Pack<T, VEC> s0{};
-    if (single && sl * VEC < d) s0 = load_pack<T, VEC>(zsrc + sl * VEC);
+    if (single && sl * VEC < d) s0 = k1_src_load<T, VEC>(zsrc + sl * VEC);
     A run_m = -A(INFINITY), run_s = A(0);
 
     for (int64_t e = ea; e < eb; e += kWave) {
@@ -313,7 +330,7 @@ __global__ CLANE_K1_BOUNDS void edge_score_subrow_kernel(
                     deg = int(dg);
                     eb = 0;
                     const int64_t gsrc = row0 + row_begin + row;
-                    s0 = load_pack<T, VEC>(Z + gsrc * ldz + c0s);
+                    s0 = k1_src_load<T, VEC>(Z + gsrc * ldz + c0s);
                     if (!col_ok) s0 = Pack<T, VEC>{};
                     nsrc = mode == kScorePerEdge ? sqrt(sq[gsrc]) : A(0);
                     run_m = -A(INFINITY);
