@@ -382,8 +382,9 @@ int spmm_update_split(const int64_t *rowptr, const int32_t *colidx, const PT *P,
             <<<unsigned(n_segments), kLongWaves * kWave, 0, (hipStream_t)stream>>>(
                 rowptr, colidx, P, split_rows, seg_ptr, seg_row, edges_per_segment, Z_old, ldz, d, slab, ld_slab);
         // a row's segments sit in the slab like a class row's slots: the same fixed-order combine + epilogue
-        spmm_class_combine_kernel<T, VEC><<<unsigned(n_split), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
-            split_rows, seg_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, false, delta_partials);
+        spmm_class_combine_kernel<T, VEC, LPR>
+            <<<unsigned(ceil_div(n_split, kWave / LPR)), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
+            split_rows, seg_ptr, n_split, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir, false, delta_partials);
     });
     return check_launch("spmm_update_split");
 }
@@ -425,8 +426,9 @@ int spmm_update_class(const int32_t *colidx, const PT *P, const int64_t *item_e0
         else if (n_blocks > 0)
             spmm_class_chunk_kernel<T, PT, VEC, LPR, U><<<unsigned(n_blocks), kBlock, 0, (hipStream_t)stream>>>(
                 colidx, P, item_e0, item_len, item_slot, items_per_block, Z_old, ldz, d, slab, ld_slab);
-        spmm_class_combine_kernel<T, VEC><<<unsigned(n_rows), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
-            class_rows, slot_ptr, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir,
+        spmm_class_combine_kernel<T, VEC, LPR>
+            <<<unsigned(ceil_div(n_rows, kWave / LPR)), kCombineWaves * kWave, 0, (hipStream_t)stream>>>(
+            class_rows, slot_ptr, n_rows, row0, slab, ld_slab, Z_old, ldz, X, ldx, gamma, Z_new, ldo, d, mir,
             (flags & CLANE_SPMM_TABLE_BEYOND_CACHE) != 0, delta_partials);
     });
     return check_launch("spmm_update_class");

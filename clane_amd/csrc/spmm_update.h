@@ -791,26 +791,32 @@ constexpr int kCombineWaves = CLANE_COMBINE_WAVES;
 #endif
 constexpr int kCombineLoads = CLANE_COMBINE_LOADS;
 
-template <typename T, int VEC>
+template <typename T, int VEC, int LPR>
 __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kernel(
-    const int32_t *__restrict__ class_rows, const int64_t *__restrict__ slot_ptr, int64_t row0,
+    const int32_t *__restrict__ class_rows, const int64_t *__restrict__ slot_ptr, int64_t n_rows, int64_t row0,
     const typename Elem<T>::acc_t *__restrict__ slab, int64_t ld_slab, const T *__restrict__ Zold, int64_t ldz,
     const T *__restrict__ X, int64_t ldx, typename Elem<T>::acc_t gamma, T *__restrict__ Znew, int64_t ldo, int d,
     Mirror<T> mirror, bool nt_store, double *__restrict__ partials) {
     using A = typename Elem<T>::acc_t;
+    // A row needs LPR lanes; a workgroup takes 64 / LPR rows, one per lane group (round 5: at 512-byte rows -- the column
+    // tiles -- half the lanes of the one-row form had nothing to do).  Each group walks its own row's slots: the
+    // association of a row's sum depends on its slot count and kCombineWaves alone, as before.
+    constexpr int kRows = kWave / LPR;
     __shared__ A s_part[kCombineWaves > 1 ? kCombineWaves - 1 : 1][kWave][VEC];
-    const int i = blockIdx.x;
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int64_t r = class_rows[i];
-    const int64_t s0 = slot_ptr[i], s1 = slot_ptr[i + 1];
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int64_t i = int64_t(blockIdx.x) * kRows + sub;
+    const bool live = i < n_rows;
+    const int64_t r = live ? class_rows[i] : 0;
+    const int64_t s0 = live ? slot_ptr[i] : 0, s1 = live ? slot_ptr[i + 1] : 0;
     const int64_t share = ceil_div(s1 - s0, int64_t(kCombineWaves));
     const int64_t a = s0 + wave * share < s1 ? s0 + wave * share : s1;
     const int64_t b = a + share < s1 ? a + share : s1;
     A rsum = A(0);
-    for (int t0 = 0; t0 < d; t0 += kWave * VEC) {       // the same trip count in every wave (barriers inside)
-        const int c0 = t0 + lane * VEC;
-        const bool ok = c0 < d;
+    for (int t0 = 0; t0 < d; t0 += LPR * VEC) {         // the same trip count in every wave (barriers inside)
+        const int c0 = t0 + sl * VEC;
+        const bool ok = live && c0 < d;
         A acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = A(0);
@@ -857,12 +863,12 @@ __global__ __launch_bounds__(kCombineWaves *kWave) void spmm_class_combine_kerne
                 const Pack<T, VEC> zo = load_pack_stream<T, VEC>(Zold + (row0 + r) * ldz + c0);
                 rsum += finish_pack<T, VEC>(x, zo, acc, gamma, true, Znew + r * ldo + c0, out, nt_store);
             }
-            mirror_store<T, VEC, kWave>(mirror, r, c0, out, ok, lane, 0);
+            if (live) mirror_store<T, VEC, LPR>(mirror, r, c0, out, ok, sl, sub * LPR);     // uniform over the row's lanes
         }
     }
     if (wave == 0) {
-        rsum = group_sum<kWave>(rsum);
-        if (lane == 0) partials[i] = double(rsum);
+        rsum = group_sum<LPR>(rsum);
+        if (live && sl == 0) partials[i] = double(rsum);
     }
 }
 
