@@ -480,13 +480,20 @@ __global__ __launch_bounds__(kBlock) void edge_softmax_class_kernel(const int64_
     if (my_e0 >= row_e1) return;
     const int64_t my_e1 = my_e0 + share < row_e1 ? my_e0 + share : row_e1;
     const int64_t s0 = slot_ptr[i], s1 = slot_ptr[i + 1];
+    // the first score of every thread is requested BEFORE the chunks' stats: it does not depend on them, and most class
+    // rows are a few hundred edges -- one score per thread -- so the launch is a chain of dependent round trips, not a
+    // stream (r04: 1.84 TB/s); this takes one of them out of the chain (config 3: 162 -> 155 us per build_P; config 4,
+    // whose time is in the multi-million-edge hubs: unchanged)
+    const int64_t e_first = my_e0 + threadIdx.x;
+    const A first = e_first < my_e1 ? scores[e_first] : A(0);
     A m = -A(INFINITY);
     for (int64_t s = s0 + lane; s < s1; s += kWave) m = fmax(m, stats[2 * s]);
     m = group_max<kWave>(m);
     A total = A(0);
     for (int64_t s = s0 + lane; s < s1; s += kWave) total += stats[2 * s + 1] * exp_acc<A>(stats[2 * s] - m);
     total = group_sum<kWave>(total);
-    for (int64_t e = my_e0 + threadIdx.x; e < my_e1; e += kBlock) scores[e] = exp_acc<A>(scores[e] - m) / total;
+    if (e_first < my_e1) scores[e_first] = exp_acc<A>(first - m) / total;
+    for (int64_t e = e_first + kBlock; e < my_e1; e += kBlock) scores[e] = exp_acc<A>(scores[e] - m) / total;
 }
 
 }  // namespace clane
