@@ -1003,6 +1003,19 @@ def test_column_tiles_of_a_one_gpu_sweep(tmp_path, monkeypatch):
     for _ in range(3):
         a, b = one.sweep(0.8), three.sweep(0.8)
         assert b == pytest.approx(a, rel=1e-6) and O.rel_l2(three.get_Z(), one.get_Z()) < 1e-6
+    # tiles x class rows phased in time (profiles/r05_tiles_phases_ab.jsonl: four phases under two tiles is what K1,
+    # which still reads whole rows, wants): the phases reorder a class row's edges, the tiles cut its columns
+    for phases in (2, 4):
+        phased = SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=3, class_threshold=8, class_chunk=64,
+                             class_phases=phases, phase_threshold=16)
+        assert phased.class_phases == phases and phased.kernel_config()["class_phases"] == phases
+        plain = SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=1, class_threshold=8, class_chunk=64)
+        for eng in (plain, phased):
+            eng.build_P()
+        assert O.rel_l2(phased.P_global(), plain.P_global()) < 1e-6
+        for _ in range(3):
+            a, b = plain.sweep(0.8), phased.sweep(0.8)
+            assert b == pytest.approx(a, rel=1e-6) and O.rel_l2(phased.get_Z(), plain.get_Z()) < 1e-6
     with pytest.raises(ValueError, match="column_tiles"):
         SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=0)
     # the default: only where it pays (cache sizes scaled down 32x so that a 40 MB table stands in for a 1.3 GB one)
