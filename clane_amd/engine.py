@@ -30,7 +30,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from . import _hip
+from . import _hip, xcd
 from .comm import TorchComm
 from .diagnostics import DiagnosticsMixin
 from .halo import build_halo_layout
@@ -206,7 +206,10 @@ class SweepEngine(StagingMixin, DiagnosticsMixin):
         self.class_chunk = int(class_chunk)
         self.class_k1 = bool(class_k1) and self.class_threshold > 0    # build_P scores the class rows XCD-affine too
         # heavy class rows are also phased in time (xcd.py): phases 1 = off
-        self.class_phases = int(PHASES_BY_ROWS_PER_WAVE[self.rows_per_wave] if class_phases is None else class_phases)
+        if class_phases is None:
+            class_phases = (xcd.PHASES_UNDER_COLUMN_TILES if len(self.tiles) > 1 else 0) or \
+                PHASES_BY_ROWS_PER_WAVE[self.rows_per_wave]
+        self.class_phases = int(class_phases)
         if self.class_threshold == 0 or self.class_phases < 1:
             self.class_phases = 1
         if self.class_phases & (self.class_phases - 1) or self.class_phases > 8:

@@ -62,6 +62,12 @@ CLASS_CHUNK = 256
 # 4.31 -> 4.01 ms with 4 phases (build_P 4.72 -> 4.44); its 512-byte column slice 1.98 -> 1.91 with 2; narrower rows
 # lose (their hot rows already fit).
 PHASES_BY_ROWS_PER_WAVE = {1: 4, 2: 2, 4: 1, 8: 1}
+# A one-GPU sweep cut into column tiles (engine._pick_tiles) plans for the TILE's row width, but build_P's K1 still reads
+# whole rows over the same edge order.  0 = by the tile's width (the table above); 4 is the measured better choice at
+# config 3 (two tiles of 512 bytes under 1-KiB rows: build_P 3.81 -> 3.65-3.67 ms, sweep 3.66-3.67 -> 3.65-3.66,
+# profiles/r05_tiles_phases_ab.jsonl) -- switch it together with a re-take of the PMC passes: class_phases is part of
+# kernel_config(), profiles/traffic.json's entry was measured with two.
+PHASES_UNDER_COLUMN_TILES = 0
 PHASE_THRESHOLD = 512
 CLASS_ITEMS_PIECE_EDGES = 1 << 28
 # Chunks per workgroup, at most.  Round 2 found 16 / 32 / 64 alike on config 3 and took 32; measured again in round 3

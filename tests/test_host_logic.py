@@ -1018,6 +1018,14 @@ def test_column_tiles_of_a_one_gpu_sweep(tmp_path, monkeypatch):
             assert b == pytest.approx(a, rel=1e-6) and O.rel_l2(phased.get_Z(), plain.get_Z()) < 1e-6
     with pytest.raises(ValueError, match="column_tiles"):
         SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=0)
+    # the prepared default (xcd.PHASES_UNDER_COLUMN_TILES: 0 = by the tile's width) applies to tiled engines only
+    from clane_amd import xcd
+    monkeypatch.setattr(xcd, "PHASES_UNDER_COLUMN_TILES", 4)
+    assert SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=3, class_threshold=8).class_phases == 4
+    assert SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=1, class_threshold=8).class_phases == one.class_phases
+    assert SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=3, class_threshold=8, class_phases=2).class_phases == 2
+    monkeypatch.setattr(xcd, "PHASES_UNDER_COLUMN_TILES", 0)
+    assert SweepEngine(csr, X, "cpu", OracleKernels(), column_tiles=3, class_threshold=8).class_phases == three.class_phases
     # the default: only where it pays (cache sizes scaled down 32x so that a 40 MB table stands in for a 1.3 GB one)
     from clane_amd import plan
     monkeypatch.setattr(E, "INFINITY_CACHE_BYTES", plan.INFINITY_CACHE_BYTES // 32)
